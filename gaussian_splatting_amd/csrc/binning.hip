@@ -1,0 +1,352 @@
+// binning.hip -- Gaussian -> tile assignment and per-tile depth ordering for gfx950.
+//
+// Replaces get_sorted_gaussian_list (tile_culling.cu:124-340).  The reference emits fp64 keys
+// z + (max_z+1)*tile in Gaussian order and runs one global torch::sort over all instances.  Here
+// the count pass already yields every tile's segment [tile_ranges[t], tile_ranges[t+1]), so
+//   1. k_tile_count    SAT test per (Gaussian, candidate tile); per-tile counters
+//   2. k_scan_tiles    exclusive prefix of the counters (one workgroup)
+//   3. k_tile_emit     same test; scatters key = (sortable z bits << 32 | gaussian) straight into
+//                      the tile's segment (counting sort on the tile digit)
+//   4. k_tile_sort     one workgroup per tile sorts its segment in LDS (bitonic network on unique
+//                      64-bit keys -> deterministic) and writes the Gaussian indices.
+// HBM traffic: 20 B in per Gaussian per pass, 8 B out + 8 B in + 4 B out per instance.
+//
+// The intersection test is bit-identical to the CPU restatement: fp32, no contraction, the same
+// operation order as tile_culling.cu:8-122, cos/sin of the OBB angle formed algebraically from
+// the eigenvector (b, lambda1 - a) instead of atan2f/cosf/sinf (whose last bits differ between
+// libdevice, OCML and glibc).
+#include "gs_common.h"
+
+namespace gs {
+
+constexpr int BIN_BLOCK = 256;
+
+struct Obb {
+    float p[8];   // tl, tr, bl, br  (x, y)
+    int radius_tiles;
+};
+
+// tile_culling.cu:69-122
+__device__ inline Obb compute_obb(float u, float v, float a, float b, float c, float mh) {
+    Obb o;
+    const float left = (a + c) / 2;
+    const float right = __builtin_sqrtf((a - c) * (a - c) / 4.0f + b * b);
+    const float l1 = left + right;
+    const float l2 = left - right;
+    const float r_major = mh * __builtin_sqrtf(l1);
+    const float r_minor = mh * __builtin_sqrtf(l2);
+    float ct, st;
+    if (__builtin_fabsf(b) < bits_f(0x24e69595u)) {   // fabsf(b) < 1e-16 (double compare)
+        if (a >= c) { ct = 1.0f; st = 0.0f; }
+        else { ct = -4.37113883e-8f; st = 1.0f; }     // cos/sin of float(pi/2)
+    } else {
+        const float y = l1 - a;
+        const float h = __builtin_sqrtf(b * b + y * y);
+        ct = b / h;
+        st = y / h;
+    }
+    o.p[0] = -1 * r_major * ct + r_minor * st + u;
+    o.p[1] = -1 * r_major * st - r_minor * ct + v;
+    o.p[2] = r_major * ct + r_minor * st + u;
+    o.p[3] = r_major * st - r_minor * ct + v;
+    o.p[4] = -1 * r_major * ct - r_minor * st + u;
+    o.p[5] = -1 * r_major * st + r_minor * ct + v;
+    o.p[6] = r_major * ct - r_minor * st + u;
+    o.p[7] = r_major * st + r_minor * ct + v;
+    o.radius_tiles = f2i(__builtin_ceilf(r_major / 16.0f) + 1);
+    return o;
+}
+
+// per-Gaussian part of the separating-axis test (tile_culling.cu:14-15,20-21,27-28,38-41,47-48,
+// 58-62): everything that does not depend on the tile
+struct Sat {
+    float mnx, mxx, mny, mxy;
+    float ax[2], ay[2], mn_o[2], mx_o[2];
+};
+
+__device__ inline Sat sat_setup(const Obb& o) {
+    Sat s;
+    const float* p = o.p;
+    s.mnx = fminf(fminf(p[0], p[2]), fminf(p[4], p[6]));
+    s.mxx = fmaxf(fmaxf(p[0], p[2]), fmaxf(p[4], p[6]));
+    s.mny = fminf(fminf(p[1], p[3]), fminf(p[5], p[7]));
+    s.mxy = fmaxf(fmaxf(p[1], p[3]), fmaxf(p[5], p[7]));
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int q = k == 0 ? 0 : 6;
+        s.ax[k] = p[2] - p[q];
+        s.ay[k] = p[3] - p[q + 1];
+        const float p0 = s.ax[k] * p[2] + s.ay[k] * p[3];
+        const float p1 = s.ax[k] * p[q] + s.ay[k] * p[q + 1];
+        s.mn_o[k] = fminf(p0, p1);
+        s.mx_o[k] = fmaxf(p0, p1);
+    }
+    return s;
+}
+
+// tile_culling.cu:8-66 for tile bounds [l, r] x [t, b]
+__device__ inline bool sat_overlaps(const Sat& s, float l, float r, float t, float b) {
+    if (s.mnx > r || s.mxx < l) return false;
+    if (s.mny > b || s.mxy < t) return false;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const float tl = s.ax[k] * l + s.ay[k] * t;
+        const float tr = s.ax[k] * r + s.ay[k] * t;
+        const float bl = s.ax[k] * l + s.ay[k] * b;
+        const float br = s.ax[k] * r + s.ay[k] * b;
+        const float mn_t = fminf(fminf(tl, tr), fminf(bl, br));
+        const float mx_t = fmaxf(fmaxf(tl, tr), fmaxf(bl, br));
+        if (mn_t > s.mx_o[k] || mx_t < s.mn_o[k]) return false;
+    }
+    return true;
+}
+
+struct Window {
+    int sx, ex, sy, ey;
+};
+
+// tile_culling.cu:138-156 (+ the tile-row restriction used for multi-GPU sharding)
+__device__ inline Window candidate_window(float u, float v, int r, int ntx, int nty, int row0,
+                                          int row1) {
+    Window w;
+    const int px = f2i(__builtin_floorf(u / 16.0f));
+    w.sx = f2i(fmaxf(0.0f, (float)(int)((unsigned)px - (unsigned)r)));
+    w.ex = f2i(fminf((float)ntx, (float)(int)((unsigned)px + (unsigned)r)));
+    const int py = f2i(__builtin_floorf(v / 16.0f));
+    w.sy = f2i(fmaxf(0.0f, (float)(int)((unsigned)py - (unsigned)r)));
+    w.ey = f2i(fminf((float)nty, (float)(int)((unsigned)py + (unsigned)r)));
+    w.sy = max(w.sy, row0);
+    w.ey = min(w.ey, row1);
+    return w;
+}
+
+template <typename F>
+__device__ inline void for_each_tile(const float* __restrict__ uvs,
+                                     const float* __restrict__ conic, int g, int ntx, int nty,
+                                     float mh, int row0, int row1, F emit) {
+    const float u = uvs[g * 2], v = uvs[g * 2 + 1];
+    const float a = conic[g * 3] + 0.25f;
+    const float b = conic[g * 3 + 1] / 2.0f;
+    const float c = conic[g * 3 + 2] + 0.25f;
+    const Obb o = compute_obb(u, v, a, b, c, mh);
+    const Window w = candidate_window(u, v, o.radius_tiles, ntx, nty, row0, row1);
+    if (w.sx >= w.ex || w.sy >= w.ey) return;
+    const Sat s = sat_setup(o);
+    for (int tx = w.sx; tx < w.ex; tx++) {
+        const float l = (float)tx * 16.0f, r = (float)(tx + 1) * 16.0f;
+        for (int ty = w.sy; ty < w.ey; ty++) {
+            const float t = (float)ty * 16.0f, b2 = (float)(ty + 1) * 16.0f;
+            if (sat_overlaps(s, l, r, t, b2)) emit(ty * ntx + tx);
+        }
+    }
+}
+
+__global__ __launch_bounds__(BIN_BLOCK) void k_tile_count(const float* __restrict__ uvs,
+                                                          const float* __restrict__ conic, int V,
+                                                          int ntx, int nty, float mh, int row0,
+                                                          int row1, int* __restrict__ counts) {
+    const int g = blockIdx.x * BIN_BLOCK + threadIdx.x;
+    if (g >= V) return;
+    for_each_tile(uvs, conic, g, ntx, nty, mh, row0, row1,
+                  [&](int tile) { atomicAdd(counts + tile, 1); });
+}
+
+// exclusive prefix of counts[T] -> ranges[T+1]; single workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void k_scan_tiles(const int* __restrict__ counts, int T,
+                                                     int* __restrict__ ranges) {
+    __shared__ int s_wave[16];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < T; base += 1024 * 4) {
+        int v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = base + tid * 4 + k;
+            v[k] = i < T ? counts[i] : 0;
+            sum += v[k];
+        }
+        int incl = sum;   // inclusive wave scan
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int n = __shfl_up(incl, d);
+            if (lane >= d) incl += n;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int wave_off = 0;
+        for (int w = 0; w < wave; w++) wave_off += s_wave[w];
+        int run = s_carry + wave_off + incl - sum;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = base + tid * 4 + k;
+            if (i < T) ranges[i] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = run;
+        __syncthreads();
+    }
+    if (tid == 0) ranges[T] = s_carry;
+}
+
+__device__ inline uint32_t sortable_bits(float z) {   // monotone float -> uint map
+    const uint32_t u = __float_as_uint(z);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(BIN_BLOCK) void k_tile_emit(
+    const float* __restrict__ uvs, const float* __restrict__ xyz_cam,
+    const float* __restrict__ conic, int V, int ntx, int nty, float mh, int row0, int row1,
+    const int* __restrict__ ranges, int* __restrict__ cursor, uint64_t* __restrict__ keys) {
+    const int g = blockIdx.x * BIN_BLOCK + threadIdx.x;
+    if (g >= V) return;
+    const uint64_t key = ((uint64_t)sortable_bits(xyz_cam[g * 3 + 2]) << 32) | (uint32_t)g;
+    for_each_tile(uvs, conic, g, ntx, nty, mh, row0, row1, [&](int tile) {
+        const int pos = ranges[tile] + atomicAdd(cursor + tile, 1);
+        keys[pos] = key;
+    });
+}
+
+// ---- per-tile sort -------------------------------------------------------------------------------
+constexpr int SORT_BLOCK = 256;
+constexpr int SORT_LDS_KEYS = 8192;   // 64 KiB of LDS: two workgroups per CU
+
+// Bitonic network in its all-ascending form: phase k starts with a "flip" step (element i of a
+// k-block against element k-1-i) followed by half-cleaners of stride j = k/4 .. 1.  Every
+// comparator puts the smaller key at the lower index, so +inf padding at indices >= n never
+// moves and can stay virtual.  Pair index p touches only elements [128*(p/64), 128*(p/64)+127]
+// in a flip with k <= 128 or a half-cleaner with j <= 64: such steps need wave-level ordering
+// only.
+__device__ inline bool step_is_wide(int k, int j) { return j == 0 ? k > 128 : j > 64; }
+
+template <typename Mem>
+__device__ inline void bitonic_step(Mem s, int n, int n_pad, int k, int j, int tid) {
+    for (int p = tid; p < (n_pad >> 1); p += SORT_BLOCK) {
+        int lo, hi;
+        if (j == 0) {   // flip
+            const int h = k >> 1;
+            const int blk = p / h, off = p & (h - 1);
+            lo = blk * k + off;
+            hi = blk * k + (k - 1 - off);
+        } else {
+            lo = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+            hi = lo + j;
+        }
+        if (hi >= n) continue;   // partner is virtual +inf: already ordered
+        const uint64_t a = s[lo], b = s[hi];
+        if (a > b) {
+            s[lo] = b;
+            s[hi] = a;
+        }
+    }
+}
+
+template <typename Mem>
+__device__ inline void bitonic_sort(Mem s, int n, int n_pad, int tid) {
+    for (int k = 2; k <= n_pad; k <<= 1) {
+        // steps of this phase: j = 0 (flip), k/4, k/8, ..., 1
+        int j = 0;
+        while (true) {
+            bitonic_step(s, n, n_pad, k, j, tid);
+            const int nj = (j == 0) ? (k >> 2) : (j >> 1);
+            const bool last = nj == 0;
+            // next step: nj within this phase, or the flip of phase 2k
+            const bool next_wide = last ? ((k << 1) <= n_pad && step_is_wide(k << 1, 0))
+                                        : step_is_wide(k, nj);
+            if (step_is_wide(k, j) || next_wide) {
+                __threadfence_block();
+                __syncthreads();
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            if (last) break;
+            j = nj;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort(const int* __restrict__ ranges,
+                                                          uint64_t* __restrict__ keys,
+                                                          int* __restrict__ sorted, int tile0) {
+    __shared__ uint64_t s_keys[SORT_LDS_KEYS];
+    const int tile = tile0 + blockIdx.x;
+    const int s0 = ranges[tile];
+    const int n = ranges[tile + 1] - s0;
+    const int tid = threadIdx.x;
+    if (n <= 0) return;
+    if (n == 1) {
+        if (tid == 0) sorted[s0] = (int)(uint32_t)keys[s0];
+        return;
+    }
+    int n_pad = 2;
+    while (n_pad < n) n_pad <<= 1;
+    if (n <= SORT_LDS_KEYS) {
+        for (int i = tid; i < n; i += SORT_BLOCK) s_keys[i] = keys[s0 + i];
+        __syncthreads();
+        bitonic_sort(s_keys, n, n_pad, tid);
+        for (int i = tid; i < n; i += SORT_BLOCK) sorted[s0 + i] = (int)(uint32_t)s_keys[i];
+    } else {
+        // oversize tile: the same network directly on the tile's global segment (one workgroup,
+        // so workgroup-scope ordering suffices)
+        uint64_t* gk = keys + s0;
+        bitonic_sort(gk, n, n_pad, tid);
+        for (int i = tid; i < n; i += SORT_BLOCK) sorted[s0 + i] = (int)(uint32_t)gk[i];
+    }
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" {
+
+int gs_tile_count(const void* uvs, const void* conic, int V, int n_tiles_x, int n_tiles_y,
+                  float mh_dist, int tile_row0, int tile_row1, int32_t* tile_counts,
+                  int32_t* tile_ranges, void* stream) {
+    GS_REQUIRE(n_tiles_x > 0 && n_tiles_y > 0, "tile grid must be positive");
+    GS_REQUIRE(tile_row0 >= 0 && tile_row1 <= n_tiles_y && tile_row0 <= tile_row1,
+               "bad tile row range");
+    hipStream_t s = (hipStream_t)stream;
+    const int T = n_tiles_x * n_tiles_y;
+    if (hipMemsetAsync(tile_counts, 0, sizeof(int) * (size_t)T, s) != hipSuccess) {
+        gs::set_error("tile_count: memset failed");
+        return GS_EHIP;
+    }
+    if (V > 0) {
+        k_tile_count<<<div_up(V, BIN_BLOCK), BIN_BLOCK, 0, s>>>(
+            (const float*)uvs, (const float*)conic, V, n_tiles_x, n_tiles_y, mh_dist, tile_row0,
+            tile_row1, tile_counts);
+    }
+    k_scan_tiles<<<1, 1024, 0, s>>>(tile_counts, T, tile_ranges);
+    return check_launch("tile_count");
+}
+
+int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void* conic, int V,
+                      int n_tiles_x, int n_tiles_y, float mh_dist, int tile_row0, int tile_row1,
+                      const int32_t* tile_ranges, int32_t* tile_cursor, uint64_t* keys, int64_t S,
+                      int32_t* sorted_gaussians, void* stream) {
+    GS_REQUIRE(tile_row0 >= 0 && tile_row1 <= n_tiles_y && tile_row0 <= tile_row1,
+               "bad tile row range");
+    hipStream_t s = (hipStream_t)stream;
+    const int T = n_tiles_x * n_tiles_y;
+    if (S <= 0 || V <= 0) return GS_OK;
+    if (hipMemsetAsync(tile_cursor, 0, sizeof(int) * (size_t)T, s) != hipSuccess) {
+        gs::set_error("tile_emit_sort: memset failed");
+        return GS_EHIP;
+    }
+    k_tile_emit<<<div_up(V, BIN_BLOCK), BIN_BLOCK, 0, s>>>(
+        (const float*)uvs, (const float*)xyz_camera_frame, (const float*)conic, V, n_tiles_x,
+        n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, tile_cursor, keys);
+    const int t0 = tile_row0 * n_tiles_x;
+    const int nt = (tile_row1 - tile_row0) * n_tiles_x;
+    if (nt > 0) k_tile_sort<<<nt, SORT_BLOCK, 0, s>>>(tile_ranges, keys, sorted_gaussians, t0);
+    return check_launch("tile_emit_sort");
+}
+
+}  // extern "C"

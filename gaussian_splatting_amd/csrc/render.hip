@@ -1,0 +1,526 @@
+// render.hip -- tile renderer for gfx950: forward compositing, backward, depth.
+//
+// Replaces render_tiles_kernel (render.cu:8-189), render_tiles_backward_kernel
+// (render_backward.cu:12-285) and render_depth_kernel (depth.cu:7-115).
+//
+// Mapping.  One 256-thread workgroup (4 waves) per 16x16 tile; wave w owns the 8x8 pixel
+// quadrant (w&1, w>>1), lane l the pixel (l&7, l>>3) inside it, so that a wave covers a compact
+// patch: a splat that misses the patch is skipped by the whole wave with one ballot.  Workgroups
+// are laid out so that each XCD renders a contiguous band of tiles (block b runs on XCD b%8):
+// neighbouring tiles share Gaussians and hit the same 4 MiB L2.
+//
+// Data flow.  Per chunk of 256 splats the workgroup gathers the packed geometry record
+// (gs_pack_splats: u, v, a, b, c, det, 1/det, opacity -- two 16-byte loads) and the colour
+// coefficients of the depth-sorted Gaussians into LDS; every pixel then walks the chunk with
+// wave-uniform (broadcast) LDS reads.  Barriers are uniform (Q2 of SURVEY.md is not replicated).
+// Forward leaves the chunk loop as soon as every pixel of the tile is saturated
+// (result-preserving: a saturated pixel ignores all later splats, render.cu:106).
+//
+// Backward starts at the tile's largest num_splats_per_pixel instead of the end of the list,
+// skips the reduction for waves none of whose lanes the splat reaches, reduces the 6+3*N_SH
+// per-splat gradient sums over the wave with DPP adds, combines the four waves in LDS and issues
+// ONE global atomic per value per (splat, tile) -- the reference issues eight (one per warp),
+// unconditionally.
+//
+// Numerics.  The fp32 forward is bit-identical to the CPU restatement: same operation order and
+// operand precisions as render.cu (including its double-literal promotions), IEEE division,
+// det_expf in place of __expf.  Backward forms alpha and the skip decisions bit-identically
+// (render_backward.cu:141-170) and evaluates the gradient formulas in T.
+#include "gs_common.h"
+
+namespace gs {
+
+constexpr int RB = 256;      // workgroup size = pixels per tile
+
+// splats staged in LDS per step (at most one per thread); smaller for the wide test-only
+// instantiations so that every kernel stays below 64 KiB of static LDS
+template <typename T, int N_SH> struct Chunk {
+    static constexpr int value = (sizeof(T) * N_SH <= 8) ? 256 : (sizeof(T) * N_SH <= 36) ? 128 : 64;
+};
+
+template <typename T> struct alignas(16) Vec4 { T x, y, z, w; };
+
+template <int N_SH> struct ColW { static constexpr int value = (3 * N_SH + 3) & ~3; };
+
+// reference chunk sizes, needed only for bug-compatibility with render_backward.cu:185 (Q1)
+template <typename T> __host__ __device__ constexpr int ref_chunk(int n_sh);
+template <> __host__ __device__ constexpr int ref_chunk<float>(int n_sh) {
+    return n_sh == 1 ? 960 : n_sh == 4 ? 576 : n_sh == 9 ? 320 : 160;
+}
+template <> __host__ __device__ constexpr int ref_chunk<double>(int n_sh) {
+    return n_sh == 1 ? 320 : n_sh == 4 ? 160 : n_sh == 9 ? 128 : 64;
+}
+
+// XCD-aware tile order: block b -> tile index inside [0, nt)
+__device__ inline int tile_of_block(int b, int nt) {
+    const int per = (nt + 7) >> 3;
+    return (b & 7) * per + (b >> 3);
+}
+
+struct PixelMap {
+    int u, v;
+};
+__device__ inline PixelMap pixel_of_thread(int tile_x, int tile_y, int tid) {
+    const int w = tid >> 6, l = tid & 63;
+    PixelMap p;
+    p.u = tile_x * 16 + ((w & 1) << 3) + (l & 7);
+    p.v = tile_y * 16 + ((w >> 1) << 3) + (l >> 3);
+    return p;
+}
+
+// gather one chunk of splats into LDS.  idx_out (optional) keeps the Gaussian indices.
+template <typename T, int N_SH>
+__device__ inline void stage_chunk(const T* __restrict__ packed, const T* __restrict__ rgb,
+                                   const int* __restrict__ sorted, int first, int count, int tid,
+                                   T* s_geom, T* s_col, int* s_idx) {
+    constexpr int CW = ColW<N_SH>::value;
+    if (tid < count) {
+        const int g = sorted[first + tid];
+        const Vec4<T>* src = reinterpret_cast<const Vec4<T>*>(packed + (size_t)g * 8);
+        Vec4<T>* dst = reinterpret_cast<Vec4<T>*>(s_geom + tid * 8);
+        dst[0] = src[0];
+        dst[1] = src[1];
+        const T* c = rgb + (size_t)g * 3 * N_SH;
+#pragma unroll
+        for (int k = 0; k < 3 * N_SH; k++) s_col[tid * CW + k] = c[k];
+        if (s_idx) s_idx[tid] = g;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int N_SH>
+__global__ __launch_bounds__(RB) void k_render_fwd(
+    const T* __restrict__ packed, const T* __restrict__ rgb, const T* __restrict__ view_dir,
+    const int* __restrict__ ranges, const int* __restrict__ sorted, const T* __restrict__ bg,
+    int W, int H, int ntx, int tile0, int nt, int* __restrict__ nsp_out, T* __restrict__ fw_out,
+    T* __restrict__ image) {
+    constexpr bool fast = sizeof(T) == 4;
+    constexpr int CW = ColW<N_SH>::value;
+    constexpr int RCHUNK = Chunk<T, N_SH>::value;
+    __shared__ alignas(16) T s_geom[RCHUNK * 8];
+    __shared__ alignas(16) T s_col[RCHUNK * CW];
+
+    const int t_local = tile_of_block(blockIdx.x, nt);
+    if (t_local >= nt) return;
+    const int tile = tile0 + t_local;
+    const int tid = threadIdx.x;
+    const PixelMap px = pixel_of_thread(tile % ntx, tile / ntx, tid);
+    const bool valid = px.u < W && px.v < H;
+    const int s0 = ranges[tile];
+    const int n_tile = ranges[tile + 1] - s0;
+
+    T Y[N_SH];
+    if constexpr (N_SH > 1) {
+        T d[3] = {0, 0, 0};
+        if (valid) {
+            const T* vd = view_dir + ((size_t)px.v * W + px.u) * 3;
+            d[0] = vd[0]; d[1] = vd[1]; d[2] = vd[2];
+        }
+        sh_basis<T, N_SH>(d, Y);
+    } else {
+        Y[0] = T(GS_SH_0);
+    }
+
+    T acc = 0, fw = 0;
+    T img[3] = {0, 0, 0};
+    int nsp = 0;
+    bool done = !valid;
+    const T pu = T(px.u), pv = T(px.v);
+
+    for (int base = 0; base < n_tile; base += RCHUNK) {
+        const int cnt = min(RCHUNK, n_tile - base);
+        stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, nullptr);
+        __syncthreads();
+        for (int i = 0; i < cnt; i++) {
+            if (__ballot(!done) == 0) break;   // wave-uniform
+            if (!done) {
+                if (acc > Thr<T>::sat_gt()) {   // render.cu:106
+                    done = true;
+                } else {
+                    const Vec4<T> g0 = *reinterpret_cast<const Vec4<T>*>(s_geom + i * 8);
+                    const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(s_geom + i * 8 + 4);
+                    const T du = pu - g0.x, dv = pv - g0.y;
+                    const T a = g0.z, b = g0.w, c = g1.x, det = g1.y, opa = g1.w;
+                    const T mh = (c * du * du - (b + b) * du * dv + a * dv * dv) / det;
+                    T alpha = 0;
+                    if (mh > T(0)) alpha = opa * gexp<T>(T(-0.5) * mh);
+                    nsp++;
+                    if (!(fast && alpha < Thr<T>::alpha_min())) {   // render.cu:145
+                        fw = 1.0 - acc;
+                        const T weight = alpha * (1.0 - acc);       // double, narrowed
+                        T col[3];
+                        sh_to_rgb<T, N_SH>(s_col + i * CW, Y, col);
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) img[ch] += col[ch] * weight;
+                        acc += weight;
+                    }
+                }
+            }
+        }
+        if (__syncthreads_and(done || acc > Thr<T>::sat_gt())) break;
+    }
+
+    if (valid) {
+        if (acc < Thr<T>::bg_lt()) {   // render.cu:169
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) img[ch] += bg[ch] * (1.0 - acc);
+        }
+        const size_t p = (size_t)px.v * W + px.u;
+        nsp_out[p] = nsp;
+        fw_out[p] = fw;
+        image[p * 3 + 0] = img[0];
+        image[p * 3 + 1] = img[1];
+        image[p * 3 + 2] = img[2];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wave reductions
+// ---------------------------------------------------------------------------------------------------
+// Sum over the 64 lanes, result valid in lane 63.  Four in-row DPP shifts (Hillis-Steele inside
+// each 16-lane row), then row_bcast:15 / row_bcast:31 carry the row sums across.
+#define GS_DPP(x, ctrl, row_mask, bound)                                                           \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl),  \
+                                                          (row_mask), 0xf, (bound)))
+__device__ inline float wave_sum(float v) {
+    v += GS_DPP(v, 0x111, 0xf, true);    // row_shr:1
+    v += GS_DPP(v, 0x112, 0xf, true);    // row_shr:2
+    v += GS_DPP(v, 0x114, 0xf, true);    // row_shr:4
+    v += GS_DPP(v, 0x118, 0xf, true);    // row_shr:8  -> lane 15 of each row = row sum
+    v += GS_DPP(v, 0x142, 0xa, false);   // row_bcast:15 into rows 1 and 3
+    v += GS_DPP(v, 0x143, 0xc, false);   // row_bcast:31 into rows 2 and 3 -> lane 63 = total
+    return v;
+}
+__device__ inline double wave_sum(double v) {   // gradcheck-only path: plain shuffles
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_up(v, d);
+        if ((int)(threadIdx.x & 63) >= d) v += o;
+    }
+    return v;
+}
+
+template <typename T> __device__ inline void lds_add(T* p, T v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <typename T> __device__ inline void global_add(T* p, T v) { unsafeAtomicAdd(p, v); }
+
+// ---------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int N_SH>
+__global__ __launch_bounds__(RB) void k_render_bwd(
+    const T* __restrict__ packed, const T* __restrict__ rgb, const T* __restrict__ view_dir,
+    const int* __restrict__ ranges, const int* __restrict__ sorted, const T* __restrict__ bg,
+    const int* __restrict__ nsp_in, const T* __restrict__ fw_in, const T* __restrict__ grad_image,
+    int W, int H, int ntx, int tile0, int nt, T* __restrict__ g_rgb, T* __restrict__ g_opa,
+    T* __restrict__ g_uv, T* __restrict__ g_conic) {
+    constexpr bool fast = sizeof(T) == 4;
+    constexpr int CW = ColW<N_SH>::value;
+    constexpr int C = 3 * N_SH;
+    constexpr int NV = C + 6;   // rgb coeffs, opacity, u, v, conic x3
+    constexpr int REF_CH = ref_chunk<T>(N_SH);
+    constexpr int RCHUNK = Chunk<T, N_SH>::value;
+    __shared__ alignas(16) T s_geom[RCHUNK * 8];
+    __shared__ alignas(16) T s_col[RCHUNK * CW];
+    __shared__ int s_idx[RCHUNK];
+    __shared__ T s_acc[RCHUNK * NV];
+    __shared__ int s_max[4];
+
+    const int t_local = tile_of_block(blockIdx.x, nt);
+    if (t_local >= nt) return;
+    const int tile = tile0 + t_local;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const PixelMap px = pixel_of_thread(tile % ntx, tile / ntx, tid);
+    const bool valid = px.u < W && px.v < H;
+    const int s0 = ranges[tile];
+    const int n_tile = ranges[tile + 1] - s0;
+    if (n_tile <= 0) return;
+
+    int nsp = 0;
+    T weight = 0;
+    T gi[3] = {0, 0, 0};
+    T Y[N_SH];
+    {
+        T d[3] = {0, 0, 0};
+        if (valid) {
+            const size_t p = (size_t)px.v * W + px.u;
+            nsp = nsp_in[p];
+            weight = fw_in[p];
+            gi[0] = grad_image[p * 3 + 0];
+            gi[1] = grad_image[p * 3 + 1];
+            gi[2] = grad_image[p * 3 + 2];
+            if constexpr (N_SH > 1) {
+                d[0] = view_dir[p * 3 + 0]; d[1] = view_dir[p * 3 + 1]; d[2] = view_dir[p * 3 + 2];
+            }
+        }
+        if constexpr (N_SH > 1) sh_basis<T, N_SH>(d, Y);
+        else Y[0] = T(GS_SH_0);
+    }
+    // the tile's deepest used splat (render_backward.cu:131 makes everything beyond it a no-op)
+    int m = nsp;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d));
+    if (lane == 0) s_max[wave] = m;
+    __syncthreads();
+    const int n_used = min(n_tile, max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
+    if (n_used <= 0) return;
+
+    const T pu = T(px.u), pv = T(px.v);
+    T color_accum[3] = {0, 0, 0};
+    bool bg_init = false;
+    const T bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+
+    const int last_chunk = (n_used - 1) / RCHUNK;
+    for (int chunk = last_chunk; chunk >= 0; chunk--) {
+        const int base = chunk * RCHUNK;
+        const int cnt = min(RCHUNK, n_used - base);
+        __syncthreads();   // previous chunk fully flushed
+        stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, s_idx);
+        for (int k = tid; k < cnt * NV; k += RB) s_acc[k] = 0;
+        __syncthreads();
+
+        for (int i = cnt - 1; i >= 0; i--) {
+            const int k = base + i;
+            const bool reach = valid && k < nsp;
+            if (__ballot(reach) == 0) continue;   // wave-uniform: no lane reaches this splat
+            T val[NV];
+#pragma unroll
+            for (int j = 0; j < NV; j++) val[j] = 0;
+            bool contrib = false;
+            if (reach) {
+                const Vec4<T> g0 = *reinterpret_cast<const Vec4<T>*>(s_geom + i * 8);
+                const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(s_geom + i * 8 + 4);
+                const T du = pu - g0.x, dv = pv - g0.y;
+                const T a = g0.z, b = g0.w, c = g1.x, rdet = g1.z, opa = g1.w;
+                // render_backward.cu:153-165 (multiplies by 1/det; forward divides)
+                const T mh = (c * du * du - (b + b) * du * dv + a * dv * dv) * rdet;
+                T norm_prob = 0;
+                if (mh > T(0)) norm_prob = gexp<T>(T(-0.5) * mh);
+                T alpha = opa * norm_prob;
+                if (alpha > Thr<T>::sat_gt()) alpha = Thr<T>::alpha_cap();   // min(0.9999, .)
+                if (!fast || alpha >= Thr<T>::alpha_min()) {
+                    contrib = true;
+                    if (!bg_init) {   // render_backward.cu:172-181
+                        const T bw = 1.0 - (alpha * weight + 1.0 - weight);
+                        if (bw > Thr<T>::bgw_gt()) {
+                            color_accum[0] += bg0 * bw;
+                            color_accum[1] += bg1 * bw;
+                            color_accum[2] += bg2 * bw;
+                        }
+                        bg_init = true;
+                    }
+                    const T r1ma = 1.0 / (1.0 - alpha);
+                    if ((k % REF_CH) < nsp - 1) weight = weight * r1ma;   // Q1 (chunk-local index)
+                    T col[3];
+                    sh_to_rgb<T, N_SH>(s_col + i * CW, Y, col);
+                    T grad_alpha = 0;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        const T grl = alpha * weight * gi[ch];
+#pragma unroll
+                        for (int s = 0; s < N_SH; s++) val[N_SH * ch + s] = Y[s] * grl;
+                        grad_alpha += (col[ch] * weight - color_accum[ch] * r1ma) * gi[ch];
+                    }
+                    val[C + 0] = norm_prob * grad_alpha;
+                    const T grad_prob = opa * grad_alpha;
+                    const T grad_mh = T(-0.5) * norm_prob * grad_prob;
+                    val[C + 1] = -(-b * dv - b * dv + 2 * c * du) * rdet * grad_mh;
+                    val[C + 2] = -(2 * a * dv - b * du - b * du) * rdet * grad_mh;
+                    const T cf = (a * dv * dv - b * du * dv - b * du * dv + c * du * du) * rdet * rdet;
+                    val[C + 3] = (-c * cf + dv * dv * rdet) * grad_mh;
+                    val[C + 4] = (b * cf - du * dv * rdet) * grad_mh;
+                    val[C + 5] = (-a * cf + du * du * rdet) * grad_mh;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) color_accum[ch] += col[ch] * alpha * weight;
+                }
+            }
+            if (__ballot(contrib) == 0) continue;   // every reaching lane skipped the splat
+#pragma unroll
+            for (int j = 0; j < NV; j++) val[j] = wave_sum(val[j]);
+            if (lane == 63) {
+#pragma unroll
+                for (int j = 0; j < NV; j++) lds_add(&s_acc[i * NV + j], val[j]);
+            }
+        }
+        __syncthreads();
+        // one global atomic per value per (splat, tile)
+        if (tid < cnt) {
+            const int g = s_idx[tid];
+            const T* a = s_acc + tid * NV;
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < NV; j++) any |= (a[j] != T(0));
+            if (any) {
+#pragma unroll
+                for (int j = 0; j < C; j++) global_add(g_rgb + (size_t)g * C + j, a[j]);
+                global_add(g_opa + g, a[C + 0]);
+                global_add(g_uv + (size_t)g * 2 + 0, a[C + 1]);
+                global_add(g_uv + (size_t)g * 2 + 1, a[C + 2]);
+                global_add(g_conic + (size_t)g * 3 + 0, a[C + 3]);
+                global_add(g_conic + (size_t)g * 3 + 1, a[C + 4]);
+                global_add(g_conic + (size_t)g * 3 + 2, a[C + 5]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// depth (depth.cu:7-115), fp32 only
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RB) void k_render_depth(const float* __restrict__ packed,
+                                                     const float* __restrict__ xyz_cam,
+                                                     const int* __restrict__ ranges,
+                                                     const int* __restrict__ sorted, int W, int H,
+                                                     int ntx, int nt, float alpha_threshold,
+                                                     float* __restrict__ depth) {
+    constexpr int RCHUNK = 256;
+    __shared__ alignas(16) float s_geom[RCHUNK * 8];
+    __shared__ int s_idx[RCHUNK];
+    const int tile = tile_of_block(blockIdx.x, nt);
+    if (tile >= nt) return;
+    const int tid = threadIdx.x;
+    const PixelMap px = pixel_of_thread(tile % ntx, tile / ntx, tid);
+    const bool valid = px.u < W && px.v < H;
+    const int s0 = ranges[tile];
+    const int n_tile = ranges[tile + 1] - s0;
+    float acc = 0.0f;
+    bool done = !valid;
+    const float pu = (float)px.u, pv = (float)px.v;
+    for (int base = 0; base < n_tile; base += RCHUNK) {
+        const int cnt = min(RCHUNK, n_tile - base);
+        if (tid < cnt) {
+            const int g = sorted[s0 + base + tid];
+            const Vec4<float>* src = reinterpret_cast<const Vec4<float>*>(packed + (size_t)g * 8);
+            Vec4<float>* dst = reinterpret_cast<Vec4<float>*>(s_geom + tid * 8);
+            dst[0] = src[0];
+            dst[1] = src[1];
+            s_idx[tid] = g;
+        }
+        __syncthreads();
+        for (int i = 0; i < cnt; i++) {
+            if (__ballot(!done) == 0) break;
+            if (!done) {
+                const Vec4<float> g0 = *reinterpret_cast<const Vec4<float>*>(s_geom + i * 8);
+                const Vec4<float> g1 = *reinterpret_cast<const Vec4<float>*>(s_geom + i * 8 + 4);
+                const float du = pu - g0.x, dv = pv - g0.y;
+                const float a = g0.z, b = g0.w, c = g1.x, det = g1.y, opa = g1.w;
+                const float mh = (c * du * du - (b + b) * du * dv + a * dv * dv) / det;
+                float alpha = 0.0f;
+                if (mh > 0.0f) alpha = opa * det_expf(-0.5f * mh);
+                const float weight = alpha * (1.0 - acc);
+                acc += weight;
+                if (acc > alpha_threshold) {
+                    const int g = s_idx[i];
+                    const float x = xyz_cam[g * 3 + 0], y = xyz_cam[g * 3 + 1],
+                                z = xyz_cam[g * 3 + 2];
+                    depth[(size_t)px.v * W + px.u] = __builtin_sqrtf(x * x + y * y + z * z);
+                    done = true;
+                }
+            }
+        }
+        if (__syncthreads_and(done)) break;
+    }
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+#define DISPATCH_T(dtype, CALL)                                                                    \
+    if ((dtype) == GS_F32) {                                                                       \
+        using T = float;                                                                           \
+        CALL;                                                                                      \
+    } else if ((dtype) == GS_F64) {                                                                \
+        using T = double;                                                                          \
+        CALL;                                                                                      \
+    } else {                                                                                       \
+        gs::set_error("Inputs must be float32 or float64");                                        \
+        return GS_EINVAL;                                                                          \
+    }
+
+#define DISPATCH_SH(n_sh, CALL)                                                                    \
+    switch (n_sh) {                                                                                \
+        case 1: { constexpr int N_SH = 1; CALL; } break;                                           \
+        case 4: { constexpr int N_SH = 4; CALL; } break;                                           \
+        case 9: { constexpr int N_SH = 9; CALL; } break;                                           \
+        case 16: { constexpr int N_SH = 16; CALL; } break;                                         \
+        default:                                                                                   \
+            gs::set_error("Unsupported number of SH coefficients: %d", n_sh);                      \
+            return GS_EINVAL;                                                                      \
+    }
+
+static int check_rows(int H, int row0, int row1) {
+    const int nty = (H + 15) / 16;
+    if (row0 < 0 || row1 > nty || row0 > row1) {
+        gs::set_error("bad tile row range [%d, %d) for %d tile rows", row0, row1, nty);
+        return GS_EINVAL;
+    }
+    return GS_OK;
+}
+
+extern "C" {
+
+int gs_render_tiles(const void* packed, const void* rgb, const void* view_dir_by_pixel,
+                    const int32_t* tile_ranges, const int32_t* sorted_gaussians,
+                    const void* background_rgb, int W, int H, int n_sh, int tile_row0,
+                    int tile_row1, int32_t* num_splats_per_pixel, void* final_weight_per_pixel,
+                    void* image, int dtype, void* stream) {
+    GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
+    if (int e = check_rows(H, tile_row0, tile_row1)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    const int ntx = (W + 15) / 16;
+    const int nt = (tile_row1 - tile_row0) * ntx;
+    if (nt == 0) return GS_OK;
+    const int grid = ((nt + 7) / 8) * 8;
+    DISPATCH_T(dtype, DISPATCH_SH(n_sh, (k_render_fwd<T, N_SH><<<grid, RB, 0, s>>>(
+                                            (const T*)packed, (const T*)rgb,
+                                            (const T*)view_dir_by_pixel, tile_ranges,
+                                            sorted_gaussians, (const T*)background_rgb, W, H, ntx,
+                                            tile_row0 * ntx, nt, num_splats_per_pixel,
+                                            (T*)final_weight_per_pixel, (T*)image))));
+    return check_launch("render_tiles");
+}
+
+int gs_render_tiles_backward(const void* packed, const void* rgb, const void* view_dir_by_pixel,
+                             const int32_t* tile_ranges, const int32_t* sorted_gaussians,
+                             const void* background_rgb, const int32_t* num_splats_per_pixel,
+                             const void* final_weight_per_pixel, const void* grad_image, int W,
+                             int H, int n_sh, int tile_row0, int tile_row1, void* grad_rgb,
+                             void* grad_opacity, void* grad_uv, void* grad_conic, int dtype,
+                             void* stream) {
+    GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
+    if (int e = check_rows(H, tile_row0, tile_row1)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    const int ntx = (W + 15) / 16;
+    const int nt = (tile_row1 - tile_row0) * ntx;
+    if (nt == 0) return GS_OK;
+    const int grid = ((nt + 7) / 8) * 8;
+    DISPATCH_T(dtype,
+               DISPATCH_SH(n_sh, (k_render_bwd<T, N_SH><<<grid, RB, 0, s>>>(
+                                     (const T*)packed, (const T*)rgb, (const T*)view_dir_by_pixel,
+                                     tile_ranges, sorted_gaussians, (const T*)background_rgb,
+                                     num_splats_per_pixel, (const T*)final_weight_per_pixel,
+                                     (const T*)grad_image, W, H, ntx, tile_row0 * ntx, nt,
+                                     (T*)grad_rgb, (T*)grad_opacity, (T*)grad_uv,
+                                     (T*)grad_conic))));
+    return check_launch("render_tiles_backward");
+}
+
+int gs_render_depth(const void* packed, const void* xyz_camera_frame, const int32_t* tile_ranges,
+                    const int32_t* sorted_gaussians, int W, int H, float alpha_threshold,
+                    void* depth_image, void* stream) {
+    GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
+    hipStream_t s = (hipStream_t)stream;
+    const int ntx = (W + 15) / 16, nty = (H + 15) / 16;
+    const int nt = ntx * nty;
+    const int grid = ((nt + 7) / 8) * 8;
+    k_render_depth<<<grid, RB, 0, s>>>((const float*)packed, (const float*)xyz_camera_frame,
+                                       tile_ranges, sorted_gaussians, W, H, ntx, nt,
+                                       alpha_threshold, (float*)depth_image);
+    return check_launch("render_depth");
+}
+
+}  // extern "C"

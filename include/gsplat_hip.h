@@ -1,0 +1,139 @@
+/* gsplat_hip.h -- C ABI of libgsplat_hip.so: the MI355X (gfx950) rasterization hot path.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one function of the reference's
+ * `splat_cuda` extension (joeyan/gaussian_splatting src/bindings.cpp:118-159) and takes plain
+ * device pointers + sizes + a hipStream_t (as void*); no torch types, no exceptions, no hidden
+ * allocation, no device synchronisation.  Work is enqueued on `stream` and the call returns.
+ *
+ * Conventions
+ *   dtype      GS_F32 (0) or GS_F64 (1); all floating tensors of one call share it.
+ *   layouts    row-major, contiguous, exactly the reference's tensor shapes (cited per function).
+ *   outputs    caller-allocated.  Backward outputs marked "accumulated" are added into
+ *              (atomicAdd semantics, render_backward.cu:269-281) and must be zeroed by the caller.
+ *   return     0 on success, a negative GS_E* code otherwise; gs_last_error() gives the text.
+ *   tile rows  [tile_row0, tile_row1) restricts binning/rendering to those rows of 16-px tiles
+ *              (multi-GPU sharding); pass 0 and n_tiles_y for the whole image.
+ */
+#ifndef GSPLAT_HIP_H
+#define GSPLAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_F32 0
+#define GS_F64 1
+
+#define GS_OK 0
+#define GS_EINVAL (-1)   /* bad argument (shape, dtype, n_sh not in {1,4,9,16}, ...) */
+#define GS_EHIP (-2)     /* a HIP runtime call or kernel launch failed */
+
+#define GS_TILE 16       /* tile edge in pixels (splat_py/structs.py:4) */
+#define GS_PACKED_WIDTH 8 /* scalars per packed splat record, see gs_pack_splats */
+
+const char* gs_last_error(void);
+int gs_abi_version(void);
+
+/* ---- per-Gaussian projection ------------------------------------------------------------ */
+/* camera_projection_cuda (bindings.cpp:121; projection.cu:9-54).  xyz[N,3], K[3,3] -> uv[N,2] */
+int gs_camera_projection(const void* xyz, const void* K, int N, void* uv, int dtype, void* stream);
+/* camera_projection_backward_cuda (bindings.cpp:122; projection_backward.cu:9-90).
+ * rows with z <= 0 are left untouched (Q10). */
+int gs_camera_projection_backward(const void* xyz, const void* K, const void* uv_grad_out, int N,
+                                  void* xyz_grad_in, int dtype, void* stream);
+/* compute_sigma_world_cuda (bindings.cpp:127; projection.cu:57-152).
+ * quaternion[N,4] (w,x,y,z), scale[N,3] (log) -> sigma_world[N,3,3] */
+int gs_compute_sigma_world(const void* quaternion, const void* scale, int N, void* sigma_world,
+                           int dtype, void* stream);
+/* compute_sigma_world_backward_cuda (bindings.cpp:128; projection_backward.cu:174-382) */
+int gs_compute_sigma_world_backward(const void* quaternion, const void* scale,
+                                    const void* sigma_world_grad_out, int N,
+                                    void* quaternion_grad_in, void* scale_grad_in, int dtype,
+                                    void* stream);
+/* compute_projection_jacobian_cuda (bindings.cpp:133; projection.cu:155-211). -> J[N,2,3] */
+int gs_compute_projection_jacobian(const void* xyz, const void* K, int N, void* J, int dtype,
+                                   void* stream);
+/* compute_projection_jacobian_backward_cuda (bindings.cpp:138; projection_backward.cu:93-166) */
+int gs_compute_projection_jacobian_backward(const void* xyz, const void* K,
+                                            const void* jac_grad_out, int N, void* xyz_grad_in,
+                                            int dtype, void* stream);
+/* compute_conic_cuda (bindings.cpp:143; projection.cu:214-311).
+ * sigma_world[N,3,3], J[N,2,3], camera_T_world[4,4] -> conic[N,3] = (S00, S01+S10, S11) */
+int gs_compute_conic(const void* sigma_world, const void* J, const void* camera_T_world, int N,
+                     void* conic, int dtype, void* stream);
+/* compute_conic_backward_cuda (bindings.cpp:145; projection_backward.cu:385-550) */
+int gs_compute_conic_backward(const void* sigma_world, const void* J, const void* camera_T_world,
+                              const void* conic_grad_out, int N, void* sigma_world_grad_in,
+                              void* J_grad_in, int dtype, void* stream);
+
+/* ---- spherical harmonics ------------------------------------------------------------------ */
+/* precompute_rgb_from_sh_cuda (bindings.cpp:148-152; precompute_sh.cu:8-58,113-250).
+ * xyz[N,3], sh_coeff[N,3,n_sh] (or [N,3] when n_sh==1), matrix[4,4] whose translation column is
+ * the camera centre (Q8; read on the device, no host sync) -> rgb[N,3] */
+int gs_precompute_rgb_from_sh(const void* xyz, const void* sh_coeff, const void* matrix, int N,
+                              int n_sh, void* rgb, int dtype, void* stream);
+/* precompute_rgb_from_sh_backward_cuda (bindings.cpp:153-157; precompute_sh.cu:61-111,252-389) */
+int gs_precompute_rgb_from_sh_backward(const void* xyz, const void* matrix, const void* grad_rgb,
+                                       int N, int n_sh, void* grad_sh, int dtype, void* stream);
+
+/* ---- tile binning + per-tile depth sort (fp32 only) ----------------------------------------- */
+/* get_sorted_gaussian_list (bindings.cpp:147; tile_culling.cu:124-340) is split in two so that
+ * the caller owns every allocation:
+ *
+ *   1. gs_tile_count   OBB/SAT test of every Gaussian against its candidate tiles
+ *                      (tile_culling.cu:8-177), per-tile counts and their exclusive prefix:
+ *                      tile_ranges[T+1] == splat_start_end_idx_by_tile_idx.  tile_ranges[T] is the
+ *                      instance count S (read it back to size the outputs of step 2).
+ *   2. gs_tile_emit_sort  re-runs the test, scatters (z bits, gaussian) keys into each tile's
+ *                      segment and sorts every segment front-to-back in LDS
+ *                      (tile_culling.cu:179-242,327-329).  Order == the reference's fp64 key
+ *                      z + (max_z+1)*tile (tile_culling.cu:236-237) with ties broken by ascending
+ *                      Gaussian index.
+ *
+ * uvs[V,2], xyz_camera_frame[V,3], conic[V,3]; n_tiles = n_tiles_x*n_tiles_y.
+ * tile_cursor: int32[n_tiles] scratch; keys: uint64[S] scratch. */
+int gs_tile_count(const void* uvs, const void* conic, int V, int n_tiles_x, int n_tiles_y,
+                  float mh_dist, int tile_row0, int tile_row1, int32_t* tile_counts /*[T]*/,
+                  int32_t* tile_ranges /*[T+1]*/, void* stream);
+int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void* conic, int V,
+                      int n_tiles_x, int n_tiles_y, float mh_dist, int tile_row0, int tile_row1,
+                      const int32_t* tile_ranges, int32_t* tile_cursor, uint64_t* keys, int64_t S,
+                      int32_t* sorted_gaussians /*[S]*/, void* stream);
+
+/* ---- tile renderer ---------------------------------------------------------------------------- */
+/* Packs the per-splat geometry the render kernels read into one record per visible Gaussian:
+ *   packed[V][8] = (u, v, a, b, c, det, 1/det, opacity), a/b/c as render.cu:117-128 forms them
+ *   (+0.25 dilation for fp32, none for fp64).  uvs[V,2], opacity[V,1], conic[V,3]. */
+int gs_pack_splats(const void* uvs, const void* opacity, const void* conic, int V, void* packed,
+                   int dtype, void* stream);
+/* render_tiles_cuda (bindings.cpp:119; render.cu:8-422).  rgb[V,3,n_sh]; view_dir_by_pixel[H,W,3]
+ * (ignored when n_sh==1); background_rgb[3] -> num_splats_per_pixel int32[H,W],
+ * final_weight_per_pixel[H,W], image[H,W,3].  `packed` comes from gs_pack_splats. */
+int gs_render_tiles(const void* packed, const void* rgb, const void* view_dir_by_pixel,
+                    const int32_t* tile_ranges, const int32_t* sorted_gaussians,
+                    const void* background_rgb, int W, int H, int n_sh, int tile_row0,
+                    int tile_row1, int32_t* num_splats_per_pixel, void* final_weight_per_pixel,
+                    void* image, int dtype, void* stream);
+/* render_tiles_backward_cuda (bindings.cpp:120; render_backward.cu:12-595).
+ * grad_rgb[V,3,n_sh], grad_opacity[V,1], grad_uv[V,2], grad_conic[V,3] are accumulated.
+ * Bug-compatible with render_backward.cu:185. */
+int gs_render_tiles_backward(const void* packed, const void* rgb, const void* view_dir_by_pixel,
+                             const int32_t* tile_ranges, const int32_t* sorted_gaussians,
+                             const void* background_rgb, const int32_t* num_splats_per_pixel,
+                             const void* final_weight_per_pixel, const void* grad_image, int W,
+                             int H, int n_sh, int tile_row0, int tile_row1, void* grad_rgb,
+                             void* grad_opacity, void* grad_uv, void* grad_conic, int dtype,
+                             void* stream);
+/* render_depth_cuda (bindings.cpp:158; depth.cu:7-177), fp32 only.  depth_image[H,W] is written
+ * only where the accumulated alpha passes alpha_threshold (caller pre-fills with -1). */
+int gs_render_depth(const void* packed, const void* xyz_camera_frame, const int32_t* tile_ranges,
+                    const int32_t* sorted_gaussians, int W, int H, float alpha_threshold,
+                    void* depth_image, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_HIP_H */
