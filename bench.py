@@ -1,0 +1,312 @@
+"""bench.py -- forward+backward rasterization throughput on synthetic scenes (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload D] [--path fused|reference]
+
+A step = one pass of the hot path over one frame: rasterize() forward + full backward to dense
+parameter gradients.  Inputs (Gaussian parameters, camera, grad_image) are resident
+in HBM before the timed region.  One rank per GPU; for N > 1 the frame is sharded by tile rows
+(strong scaling: the same frame on more GPUs) and rank 0 prints the line.
+
+Prints ONE JSON line with the contract fields plus
+  roofline      dominant entry point: algorithmic bytes / its mean GPU duration (events on the launch
+                stream, recorded inside the timed region) against the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (literal restatement of the reference algorithm; the reference ships no
+                CPU path) timed on this host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def algorithmic_bytes(N, V, S, P, n_coeff):
+    """SURVEY.md 8(d), fp32, C = 3*n_coeff colour coefficients.  Per entry point and per frame."""
+    C = 3 * n_coeff
+    per = {
+        # per-Gaussian forward: read xyz for the cull; read q, s, opacity, coeffs; write the 40 B record
+        "per_gaussian_forward": N * 12 + V * (32 + 4 * C + 40),
+        "gs_tile_count": V * 20,
+        "gs_tile_emit_sort": V * 20 + S * (12 + 12 + 4),
+        "gs_render_tiles": S * (4 + 36) + P * 20,
+        "gs_render_tiles_backward": S * (4 + 36 + 36) + P * 20,
+        # per-Gaussian backward: re-read record 40 + render-grad record 36 + params 44; dense grad rows
+        "per_gaussian_backward": V * 120 + N * 4 * (11 + C),
+    }
+    per["frame"] = sum(per.values())
+    return per
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="D", choices=["A", "B", "C", "D"])
+    ap.add_argument("--path", default="auto", choices=["auto", "fused", "reference"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(workload, budget_s):
+    """Times the CPU oracle on this host (all cores, OpenMP) on a bounded sample of the workload:
+    the per-Gaussian stages and the binning for ALL Gaussians, and render forward+backward over a
+    band of tile rows sized to the time budget; the per-frame cost is the band's render time scaled
+    to the full image plus the full-frame per-Gaussian and binning time."""
+    from gaussian_splatting_amd.splat_py.rasterize import frustum_culling_mask
+    from gaussian_splatting_amd.splat_py.utils import transform_points_torch
+    from gaussian_splatting_amd.synthetic import DEFAULTS, WORKLOADS, make_grad_image, make_scene
+    from oracle import gs_oracle as orc
+
+    orc.set_modes(0, 0)
+    N, W, H, deg = WORKLOADS[workload]
+    g, cam, T = make_scene(N, W, H, deg, seed=0)
+    gi = make_grad_image(W, H, seed=1)
+    ntx, nty = (W + 15) // 16, (H + 15) // 16
+    bg = torch.zeros(3)
+    t0 = time.perf_counter()
+    xyz_c = transform_points_torch(g.xyz, T)
+    uv = torch.zeros(N, 2)
+    orc.camera_projection_cuda(xyz_c, cam.K, uv)
+    keep = ~frustum_culling_mask(xyz_c, uv, cam, DEFAULTS["near_thresh"], DEFAULTS["far_thresh"],
+                                 DEFAULTS["cull_mask_padding"])
+    uv, xyz_c = uv[keep].contiguous(), xyz_c[keep].contiguous()
+    V = uv.shape[0]
+    q, s = g.quaternion[keep].contiguous(), g.scale[keep].contiguous()
+    sigma = torch.zeros(V, 3, 3)
+    orc.compute_sigma_world_cuda(q, s, sigma)
+    J = torch.zeros(V, 2, 3)
+    orc.compute_projection_jacobian_cuda(xyz_c, cam.K, J)
+    conic = torch.zeros(V, 3)
+    orc.compute_conic_cuda(sigma, J, T, conic)
+    opacity = torch.sigmoid(g.opacity[keep]).contiguous()
+    xyz_v = g.xyz[keep].contiguous()
+    Tinv = torch.inverse(T).contiguous()
+    if g.sh is not None:
+        coeffs = torch.cat((g.rgb[keep].unsqueeze(2), g.sh[keep]), dim=2).contiguous()
+        rgb = torch.zeros(V, 3)
+        orc.precompute_rgb_from_sh_cuda(xyz_v, coeffs, Tinv, rgb)
+    else:
+        rgb = g.rgb[keep].contiguous()
+    t_pg_fwd = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    sorted_g, ranges = orc.get_sorted_gaussian_list(1024, uv, xyz_c, conic, ntx, nty, DEFAULTS["mh_dist"])
+    t_bin = time.perf_counter() - t0
+    S = int(sorted_g.numel())
+
+    img = torch.zeros(H, W, 3)
+    nsp = torch.zeros(H, W, dtype=torch.int32)
+    fw = torch.zeros(H, W)
+    rays = torch.zeros(1, 1, 1)
+    g_rgb, g_opa, g_uv, g_conic = torch.zeros(V, 3), torch.zeros(V, 1), torch.zeros(V, 2), torch.zeros(V, 3)
+
+    def band(r0, r1):
+        t0 = time.perf_counter()
+        orc.render_tiles_cuda(uv, opacity, rgb, conic, rays, ranges, sorted_g, bg, nsp, fw, img, tile_rows=(r0, r1))
+        orc.render_tiles_backward_cuda(uv, opacity, rgb, conic, rays, ranges, sorted_g, bg, nsp, fw, gi, g_rgb,
+                                       g_opa, g_uv, g_conic, tile_rows=(r0, r1))
+        return time.perf_counter() - t0
+
+    mid = nty // 2
+    t_probe = band(mid, mid + 1)                       # one central tile row to size the band
+    rows = int(max(1, min(nty, (budget_s - t_probe) / max(t_probe, 1e-6))))
+    r0 = max(0, mid - rows // 2)
+    r1 = min(nty, r0 + rows)
+    g_rgb.zero_(); g_opa.zero_(); g_uv.zero_(); g_conic.zero_()
+    t_band = band(r0, r1)
+    band_px = (min(H, r1 * 16) - r0 * 16) * W
+
+    t0 = time.perf_counter()
+    if g.sh is not None:
+        g_sh = torch.zeros(V, 3, coeffs.shape[2])
+        orc.precompute_rgb_from_sh_backward_cuda(xyz_v, Tinv, g_rgb, g_sh)
+    g_sigma, g_J = torch.zeros(V, 3, 3), torch.zeros(V, 2, 3)
+    orc.compute_conic_backward_cuda(sigma, J, T, g_conic, g_sigma, g_J)
+    g_xyz1, g_xyz2 = torch.zeros(V, 3), torch.zeros(V, 3)
+    orc.compute_projection_jacobian_backward_cuda(xyz_c, cam.K, g_J, g_xyz1)
+    g_q, g_s = torch.zeros(V, 4), torch.zeros(V, 3)
+    orc.compute_sigma_world_backward_cuda(q, s, g_sigma, g_q, g_s)
+    orc.camera_projection_backward_cuda(xyz_c, cam.K, g_uv, g_xyz2)
+    t_pg_bwd = time.perf_counter() - t0
+
+    frame_s = t_band * (H * W) / band_px + t_pg_fwd + t_bin + t_pg_bwd
+    return {
+        "value": round(H * W / frame_s / 1e6, 4),
+        "unit": "Mpixels/s",
+        "cores": orc.num_threads(),
+        "kind": "port",
+        "sample": (f"workload {workload}: per-Gaussian fwd {t_pg_fwd:.2f}s + binning/sort {t_bin:.2f}s + "
+                   f"per-Gaussian bwd {t_pg_bwd:.2f}s over all {N} Gaussians (V={V}, S={S}); render fwd+bwd "
+                   f"over tile rows [{r0},{r1}) of {nty} ({band_px} px) in {t_band:.2f}s, scaled to the full "
+                   f"image; CPU oracle = the build's literal C++/OpenMP restatement of the reference kernels"),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gaussian_splatting_amd import _hip
+    from gaussian_splatting_amd.synthetic import DEFAULTS, WORKLOADS, make_grad_image, make_scene
+
+    _hip.lib()   # fail loudly if the HIP extension is missing
+    N, W, H, deg = WORKLOADS[args.workload]
+    g, cam, T = make_scene(N, W, H, deg, seed=0, device=dev)
+    for name in ("xyz", "rgb", "opacity", "scale", "quaternion", "sh"):
+        p = getattr(g, name)
+        if p is not None:
+            p.requires_grad_(True)
+    grad_image = make_grad_image(W, H, seed=1, device=dev)
+    bg = torch.zeros(3, device=dev)
+
+    path = args.path
+    fused_mod = None
+    if path in ("auto", "fused"):
+        try:
+            from gaussian_splatting_amd import fused as fused_mod
+        except ImportError:
+            if path == "fused":
+                raise
+        path = "fused" if fused_mod is not None else "reference"
+
+    if world > 1:
+        from gaussian_splatting_amd.sharded import ShardedRasterizer
+        rast = ShardedRasterizer(cam.height, world, rank, fused=(path == "fused"))
+
+        def forward():
+            return rast.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, **DEFAULTS)
+    elif path == "fused":
+        def forward():
+            return fused_mod.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, **DEFAULTS)
+    else:
+        from gaussian_splatting_amd.splat_py.rasterize import rasterize
+
+        def forward():
+            return rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, **DEFAULTS)
+
+    stats = {}
+
+    def step():
+        for name in ("xyz", "rgb", "opacity", "scale", "quaternion", "sh"):
+            p = getattr(g, name)
+            if p is not None:
+                p.grad = None
+        image, mask, uv = forward()
+        image.backward(grad_image)
+        stats["V"] = uv.shape[0]
+        return image
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    _hip.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timing = _hip.collect_timing()
+    _hip.enable_timing(False)
+
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+
+    ms_per_step = elapsed / args.steps * 1e3
+    P = W * H
+    value = P / (ms_per_step * 1e-3) / 1e6
+
+    # measured counts of the timed scene
+    S = int(stats.get("S", 0)) or int(_count_instances(g, T, cam, DEFAULTS, dev))
+    V = int(stats["V"])
+    n_coeff = (deg + 1) ** 2
+    alg = algorithmic_bytes(N, V, S, P, n_coeff)
+    per_entry = {k: (sum(v) / len(v), len(v) / args.steps) for k, v in timing.items() if v}
+    # dominant entry point = largest GPU time per step
+    dom = max(per_entry, key=lambda k: per_entry[k][0] * per_entry[k][1]) if per_entry else None
+    roofline = None
+    if dom is not None:
+        dur_ms = per_entry[dom][0]
+        a = alg.get(dom)
+        if a is not None and world > 1:
+            a = a / world   # each rank's launch covers its share of the tiles
+        ach = (a / (dur_ms * 1e-3) / 1e9) if a else None
+        roofline = {
+            "bound": "hbm", "kernel": dom, "achieved": round(ach, 2) if ach else None, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5) if ach else None, "traffic": None,
+            "launch_ms": round(dur_ms, 4), "algorithmic_bytes": int(a) if a else None,
+            "frame_algorithmic_bytes": int(alg["frame"]),
+            "frame_frac": round(alg["frame"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "entry_ms_per_step": {k: round(v[0] * v[1], 4) for k, v in sorted(per_entry.items())},
+        }
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.workload, args.cpu_seconds)
+
+    if rank == 0:
+        line = {
+            "metric": "forward+backward Mpixels/s @ ~1MP, N Gaussians", "value": round(value, 3),
+            "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {N} Gaussians, {W}x{H}, SH degree {deg}, seed 0",
+                       "N": N, "V": V, "S": S, "P": P, "path": path,
+                       "parallelism": "single" if world == 1 else f"tile-rows x{world}"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def _count_instances(g, T, cam, defaults, dev):
+    """S of the timed scene (one extra untimed binning pass)."""
+    from gaussian_splatting_amd import splat_cuda
+    from gaussian_splatting_amd.splat_py.cuda_autograd_functions import (
+        CameraPointProjection, ComputeConic, ComputeProjectionJacobian, ComputeSigmaWorld)
+    from gaussian_splatting_amd.splat_py.rasterize import frustum_culling_mask
+    from gaussian_splatting_amd.splat_py.utils import transform_points_torch
+    with torch.no_grad():
+        xyz_c = transform_points_torch(g.xyz, T)
+        uv = CameraPointProjection.apply(xyz_c, cam.K)
+        keep = ~frustum_culling_mask(xyz_c, uv, cam, defaults["near_thresh"], defaults["far_thresh"],
+                                     defaults["cull_mask_padding"])
+        uv, xyz_c = uv[keep].contiguous(), xyz_c[keep].contiguous()
+        sigma = ComputeSigmaWorld.apply(g.quaternion[keep].contiguous(), g.scale[keep].contiguous())
+        J = ComputeProjectionJacobian.apply(xyz_c, cam.K)
+        conic = ComputeConic.apply(sigma, J, T)
+        ntx, nty = (cam.width + 15) // 16, (cam.height + 15) // 16
+        s, _ = splat_cuda.get_sorted_gaussian_list(1024, uv, xyz_c, conic, ntx, nty, defaults["mh_dist"])
+        return s.numel()
+
+
+if __name__ == "__main__":
+    main()

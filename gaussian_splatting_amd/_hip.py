@@ -1,0 +1,87 @@
+"""Loader for libgsplat_hip.so, the C-ABI library declared in include/gsplat_hip.h.
+
+The product path has no CPU fallback: if the library is missing or a call fails this module
+raises.  Build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C gaussian_splatting_amd/csrc`.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsplat_hip.so")
+
+GS_F32 = 0
+GS_F64 = 1
+
+# every entry point include/gsplat_hip.h declares
+EXPORTS = [
+    "gs_last_error", "gs_abi_version",
+    "gs_camera_projection", "gs_camera_projection_backward",
+    "gs_compute_sigma_world", "gs_compute_sigma_world_backward",
+    "gs_compute_projection_jacobian", "gs_compute_projection_jacobian_backward",
+    "gs_compute_conic", "gs_compute_conic_backward",
+    "gs_precompute_rgb_from_sh", "gs_precompute_rgb_from_sh_backward",
+    "gs_tile_count", "gs_tile_emit_sort",
+    "gs_pack_splats", "gs_render_tiles", "gs_render_tiles_backward", "gs_render_depth",
+]
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f"{LIB_PATH} not found: the HIP extension is not built. "
+                "Run `make -C gaussian_splatting_amd/csrc` (there is no CPU fallback).")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.gs_last_error.restype = ctypes.c_char_p
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        raise RuntimeError(lib().gs_last_error().decode())
+
+
+# ---- optional per-entry-point timing (bench.py) --------------------------------------------------------
+# When enabled, every C-ABI call is bracketed by events recorded on torch's current stream -- the
+# stream the kernels are launched on -- so the elapsed time of one entry point is the GPU time of
+# the kernels it enqueues.
+_timers = None
+
+
+def enable_timing(on=True):
+    global _timers
+    _timers = {} if on else None
+
+
+def collect_timing():
+    """-> {entry point: [ms, ...]} for the calls made since enable_timing(); synchronises."""
+    import torch
+
+    torch.cuda.synchronize()
+    out = {name: [a.elapsed_time(b) for a, b in pairs] for name, pairs in (_timers or {}).items()}
+    if _timers is not None:
+        _timers.clear()
+    return out
+
+
+def call(name, *args):
+    fn = getattr(lib(), name)
+    if _timers is None:
+        check(fn(*args))
+        return
+    import torch
+
+    a = torch.cuda.Event(enable_timing=True)
+    b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    check(fn(*args))
+    b.record()
+    _timers.setdefault(name, []).append((a, b))

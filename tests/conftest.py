@@ -1,0 +1,43 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture
+def oracle_backend():
+    """Routes the host-side mirror to the CPU oracle for the duration of one test (test-only:
+    the product never selects a CPU provider)."""
+    from gaussian_splatting_amd import backend
+    from oracle import gs_oracle
+
+    prev = backend._backend
+    gs_oracle.set_modes(0, 0)
+    gs_oracle.set_sh_band1_mode(0)
+    backend.use(gs_oracle)
+    yield gs_oracle
+    gs_oracle.set_modes(0, 0)
+    gs_oracle.set_sh_band1_mode(0)
+    backend.use(prev)
+
+
+@pytest.fixture
+def hip_backend():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gaussian_splatting_amd import backend, splat_cuda
+
+    prev = backend._backend
+    backend.use(splat_cuda)
+    yield splat_cuda
+    backend.use(prev)

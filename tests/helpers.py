@@ -1,0 +1,59 @@
+"""Shared test helpers: fixture loading and scene construction."""
+import os
+
+import numpy as np
+import torch
+
+from gaussian_splatting_amd.splat_py.structs import Camera, Gaussians
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SH_0 = 0.28209479177387814
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def t(a, device="cpu", dtype=None):
+    x = torch.from_numpy(np.asarray(a))
+    if dtype is not None:
+        x = x.to(dtype)
+    return x.to(device).contiguous()
+
+
+def scene_from_fixture(fx, device="cpu", requires_grad=False, opacity_key="in_opacity"):
+    def p(key):
+        x = t(fx[key], device)
+        return x.requires_grad_(True) if requires_grad else x
+
+    sh = p("in_sh") if "in_sh" in fx.files else None
+    g = Gaussians(p("in_xyz"), p("in_rgb"), p(opacity_key), p("in_scale"), p("in_quaternion"), sh)
+    cam = Camera(int(fx["in_width"]), int(fx["in_height"]), t(fx["in_K"], device))
+    return g, cam, t(fx["in_camera_T_world"], device)
+
+
+def scene6(device="cpu"):
+    """The reference's 6-Gaussian test scene (test/gaussian_test_data.py:6-86), from the fixture;
+    opacity already passed through inverse_sigmoid as test_rasterize.py:18 does."""
+    fx = load("ref_host_scene6.npz")
+    return scene_from_fixture(fx, device, opacity_key="in_opacity_logit") + (fx,)
+
+
+def rel_err(g, ref):
+    """max |g - ref| / max(|ref|, 1e-6 * max|ref|)"""
+    g = g.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    if ref.numel() == 0:
+        return 0.0
+    floor = 1e-6 * ref.abs().max().item()
+    den = torch.clamp(ref.abs(), min=max(floor, 1e-300))
+    return ((g - ref).abs() / den).max().item()
+
+
+def scaled_err(g, ref):
+    """max |g - ref| / max|ref| -- error relative to the tensor's scale"""
+    g = g.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    if ref.numel() == 0:
+        return 0.0
+    return ((g - ref).abs().max() / ref.abs().max().clamp(min=1e-300)).item()

@@ -1,0 +1,40 @@
+"""The C-ABI library loads and exports every symbol include/gsplat_hip.h declares (no compute
+calls: runs without a GPU)."""
+import ctypes
+import os
+import re
+
+from gaussian_splatting_amd import _hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "gsplat_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_boundary():
+    names = declared_symbols()
+    # one entry point per function of src/bindings.cpp:118-159 (get_sorted_gaussian_list is split
+    # in two, render takes the packed record from gs_pack_splats)
+    for n in ["gs_camera_projection", "gs_camera_projection_backward", "gs_compute_sigma_world",
+              "gs_compute_sigma_world_backward", "gs_compute_projection_jacobian",
+              "gs_compute_projection_jacobian_backward", "gs_compute_conic", "gs_compute_conic_backward",
+              "gs_precompute_rgb_from_sh", "gs_precompute_rgb_from_sh_backward", "gs_tile_count",
+              "gs_tile_emit_sort", "gs_pack_splats", "gs_render_tiles", "gs_render_tiles_backward",
+              "gs_render_depth", "gs_last_error", "gs_abi_version"]:
+        assert n in names
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_hip.LIB_PATH), "build the HIP library first (python -c 'import __graft_entry__ as g; g.build()')"
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    missing = [n for n in declared_symbols() if not hasattr(lib, n)]
+    assert not missing, missing
+    assert lib.gs_abi_version() >= 1
+
+
+def test_python_loader_lists_the_same_symbols():
+    assert sorted(_hip.EXPORTS) == declared_symbols()

@@ -1,0 +1,90 @@
+"""Host-side logic that needs neither GPU nor kernels: data contracts, ray helpers, argument
+validation of the splat_cuda shim (reference: test/test_structs.py, test/test_utils.py,
+src/checks.cuh)."""
+import math
+
+import pytest
+import torch
+
+from gaussian_splatting_amd import splat_cuda
+from gaussian_splatting_amd.splat_py.structs import Camera, Gaussians, Tiles
+from gaussian_splatting_amd.splat_py.utils import (compute_rays, compute_rays_in_world_frame,
+                                                   transform_points_torch)
+
+from .helpers import scene6
+
+
+def test_tiles_1080p():
+    """test/test_structs.py:10-26"""
+    tiles = Tiles(1080, 1920, torch.device("cpu"))
+    assert (tiles.image_height_padded, tiles.image_width_padded) == (1088, 1920)
+    assert (tiles.y_tiles_count, tiles.x_tiles_count, tiles.tile_count) == (68, 120, 8160)
+
+
+def test_transform_points():
+    """test/test_utils.py:28-46"""
+    pts = torch.arange(1.0, 10.0).reshape(-1, 3)
+    s = math.sqrt(2) / 2
+    transform = torch.eye(4)
+    # rotation of q = (0, s, 0, s) (w, x, y, z): 180 deg about (x+z)/sqrt2
+    q = torch.tensor([0.0, s, 0.0, s])
+    w, x, y, z = q
+    R = torch.tensor([[1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * z * w, 2 * x * z + 2 * y * w],
+                      [2 * x * y + 2 * z * w, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * x * w],
+                      [2 * x * z - 2 * y * w, 2 * y * z + 2 * x * w, 1 - 2 * x * x - 2 * y * y]])
+    transform[:3, :3] = R
+    transform[:3, 3] = torch.tensor([1.0, 2.0, 3.0])
+    out = transform_points_torch(pts, transform)
+    expected = torch.tensor([4.0, 0.0, 4.0, 7.0, -3.0, 7.0, 10.0, -6.0, 10.0]).reshape(-1, 3)
+    assert out.allclose(expected, atol=1e-6)
+    back = transform_points_torch(out, torch.inverse(transform))
+    assert back.allclose(pts, atol=1e-5)
+
+
+def test_rays_known_answers():
+    """test/test_utils.py:47-90"""
+    _, cam, T, _ = scene6()
+    rays = compute_rays(cam).reshape(480, 640, 3)
+    exp = {(0, 0): (-0.5403921008110046, -0.4250645041465759, 0.7261518836021423),
+           (240, 320): (0.0, 0.0, 1.0),
+           (0, 639): (0.5391948819160461, -0.425452321767807, 0.7268144488334656)}
+    for (v, u), e in exp.items():
+        for k in range(3):
+            assert abs(rays[v, u, k].item() - e[k]) < 1e-6
+    w = compute_rays_in_world_frame(cam, T)
+    assert w.shape == (480, 640, 3)
+    exp = {(0, 0): (-0.5390445590019226, -0.6224945187568665, 0.5673900842666626),
+           (240, 320): (-0.004399406723678112, -0.2905626893043518, 0.9568459391593933),
+           (0, 639): (0.540492832660675, -0.6134769916534424, 0.5757721662521362)}
+    for (v, u), e in exp.items():
+        for k in range(3):
+            assert abs(w[v, u, k].item() - e[k]) < 1e-6
+
+
+def test_gaussians_filter_append():
+    g, _, _, _ = scene6()
+    keep = torch.tensor([True, False, True, True, False, True])
+    g.filter_in_place(keep)
+    assert len(g) == 4 and g.opacity.shape == (4, 1)
+    g.append(g.xyz, g.rgb, g.opacity, g.scale, g.quaternion)
+    assert len(g) == 8
+    with pytest.raises(AssertionError):
+        Gaussians(torch.zeros(3, 3), torch.zeros(3, 3), torch.zeros(3), torch.zeros(3, 3), torch.zeros(3, 4))
+
+
+def test_shim_rejects_cpu_tensors():
+    """src/checks.cuh:5: non-device tensors are an error (RuntimeError), never a silent fallback"""
+    xyz, K, uv = torch.zeros(4, 3), torch.eye(3), torch.zeros(4, 2)
+    with pytest.raises(RuntimeError, match="not a CUDA tensor"):
+        splat_cuda.camera_projection_cuda(xyz, K, uv)
+    with pytest.raises(RuntimeError, match="not a CUDA tensor"):
+        splat_cuda.get_sorted_gaussian_list(1024, uv, xyz, xyz, 4, 4, 3.0)
+    with pytest.raises(RuntimeError, match="not a CUDA tensor"):
+        splat_cuda.render_depth_cuda(xyz, uv, uv, xyz, uv, uv, 0.2, uv)
+
+
+def test_get_splats_nan_guard(oracle_backend):
+    from gaussian_splatting_amd.splat_py.tile_culling import get_splats
+    bad = torch.tensor([[0.0, float("nan"), 1.0]])
+    with pytest.raises(FloatingPointError):
+        get_splats(torch.zeros(1, 2), Tiles(32, 32, "cpu"), torch.ones(1, 3), bad, 3.0)
