@@ -144,16 +144,18 @@ __device__ inline void for_each_tile(const float* __restrict__ uvs,
 __global__ __launch_bounds__(BIN_BLOCK) void k_tile_count(const float* __restrict__ uvs,
                                                           const float* __restrict__ conic, int V,
                                                           int ntx, int nty, float mh, int row0,
-                                                          int row1, int* __restrict__ counts) {
+                                                          int row1, int* __restrict__ counts,
+                                                          const int* __restrict__ v_dev) {
     const int g = blockIdx.x * BIN_BLOCK + threadIdx.x;
-    if (g >= V) return;
+    if (g >= (v_dev ? *v_dev : V)) return;
     for_each_tile(uvs, conic, g, ntx, nty, mh, row0, row1,
                   [&](int tile) { atomicAdd(counts + tile, 1); });
 }
 
 // exclusive prefix of counts[T] -> ranges[T+1]; single workgroup of 1024 threads
 __global__ __launch_bounds__(1024) void k_scan_tiles(const int* __restrict__ counts, int T,
-                                                     int* __restrict__ ranges) {
+                                                     int* __restrict__ ranges,
+                                                     const int* __restrict__ v_dev) {
     __shared__ int s_wave[16];
     __shared__ int s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -188,7 +190,10 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const int* __restrict__ cou
         if (tid == 1023) s_carry = run;
         __syncthreads();
     }
-    if (tid == 0) ranges[T] = s_carry;
+    if (tid == 0) {
+        ranges[T] = s_carry;
+        if (v_dev) ranges[T + 1] = *v_dev;
+    }
 }
 
 __device__ inline uint32_t sortable_bits(float z) {   // monotone float -> uint map
@@ -306,9 +311,9 @@ using namespace gs;
 
 extern "C" {
 
-int gs_tile_count(const void* uvs, const void* conic, int V, int n_tiles_x, int n_tiles_y,
-                  float mh_dist, int tile_row0, int tile_row1, int32_t* tile_counts,
-                  int32_t* tile_ranges, void* stream) {
+static int tile_count_impl(const void* uvs, const void* conic, int V, int n_tiles_x, int n_tiles_y,
+                           float mh_dist, int tile_row0, int tile_row1, int32_t* tile_counts,
+                           int32_t* tile_ranges, const int32_t* v_dev, void* stream) {
     GS_REQUIRE(n_tiles_x > 0 && n_tiles_y > 0, "tile grid must be positive");
     GS_REQUIRE(tile_row0 >= 0 && tile_row1 <= n_tiles_y && tile_row0 <= tile_row1,
                "bad tile row range");
@@ -321,10 +326,26 @@ int gs_tile_count(const void* uvs, const void* conic, int V, int n_tiles_x, int 
     if (V > 0) {
         k_tile_count<<<div_up(V, BIN_BLOCK), BIN_BLOCK, 0, s>>>(
             (const float*)uvs, (const float*)conic, V, n_tiles_x, n_tiles_y, mh_dist, tile_row0,
-            tile_row1, tile_counts);
+            tile_row1, tile_counts, v_dev);
     }
-    k_scan_tiles<<<1, 1024, 0, s>>>(tile_counts, T, tile_ranges);
+    k_scan_tiles<<<1, 1024, 0, s>>>(tile_counts, T, tile_ranges, v_dev);
     return check_launch("tile_count");
+}
+
+int gs_tile_count(const void* uvs, const void* conic, int V, int n_tiles_x, int n_tiles_y,
+                  float mh_dist, int tile_row0, int tile_row1, int32_t* tile_counts,
+                  int32_t* tile_ranges, void* stream) {
+    return tile_count_impl(uvs, conic, V, n_tiles_x, n_tiles_y, mh_dist, tile_row0, tile_row1,
+                           tile_counts, tile_ranges, nullptr, stream);
+}
+
+int gs_tile_count_bounded(const void* uvs, const void* conic, int capacity,
+                          const int32_t* visible_count, int n_tiles_x, int n_tiles_y,
+                          float mh_dist, int tile_row0, int tile_row1, int32_t* tile_counts,
+                          int32_t* tile_ranges, void* stream) {
+    GS_REQUIRE(visible_count != nullptr, "visible_count must be a device pointer");
+    return tile_count_impl(uvs, conic, capacity, n_tiles_x, n_tiles_y, mh_dist, tile_row0,
+                           tile_row1, tile_counts, tile_ranges, visible_count, stream);
 }
 
 int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void* conic, int V,

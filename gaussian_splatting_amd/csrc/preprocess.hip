@@ -1,0 +1,412 @@
+// preprocess.hip -- fused per-Gaussian stage of a frame, forward and backward.
+//
+// Replaces the PyTorch glue and the six per-Gaussian kernels of the reference's rasterize()
+// (splat_py/rasterize.py:29-99 + projection.cu, precompute_sh.cu; SURVEY.md rows a1-a6, a9 and, for
+// the backward, a12-a17): world->camera transform, pinhole projection, frustum cull, stream
+// compaction of the survivors (order preserving, so visible index == the reference's boolean-mask
+// index), sigmoid(opacity), Sigma_world, projection Jacobian, 2D covariance ("conic"), view-dependent
+// colour from SH, and the packed record the render kernels read.  One pass over the parameters:
+// 12 B (xyz) per Gaussian for the cull, then 32 + 4*C B in and ~120 B out per visible Gaussian.
+// The reference runs a batched 4x4 matmul, ~10 boolean-mask gathers, a cat and six kernels with
+// host synchronisations in between.
+//
+//   k_camera_center   camera centre = -A^-1 t of camera_T_world (fp64, one thread); the reference
+//                     takes torch.inverse() on the host side (rasterize.py:92)
+//   k_cull_count      cull predicate per Gaussian, per-workgroup survivor counts
+//   k_scan_counts     exclusive prefix over workgroups (+ total V)
+//   k_preprocess      recompute the predicate, rank survivors (wave ballot + prefix), compute and
+//                     write everything at the compacted index
+//   k_preprocess_bwd  one thread per Gaussian of the FULL set: survivors chain the render gradients
+//                     (uv, conic, opacity, rgb) back to the parameters, culled rows get zeros --
+//                     the dense [N, ...] gradient tensors are written exactly once, no memset,
+//                     no index_put
+//
+// Every forward quantity is computed with the same device functions and operation order as the
+// stand-alone kernels (pg_math.h), so given the same camera-frame coordinates the results are
+// bit-identical to them and to the CPU restatement.
+#include "pg_math.h"
+
+namespace gs {
+
+constexpr int PP_BLOCK = 256;
+
+struct Frustum {
+    float near, far, u_lo, u_hi, v_lo, v_hi;   // rasterize.py:33-49, compared in fp32
+};
+
+__global__ void k_camera_center(const float* __restrict__ M, float* __restrict__ center) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double a = M[0], b = M[1], c = M[2], d = M[4], e = M[5], f = M[6], g = M[8], h = M[9],
+                 i = M[10];
+    const double tx = M[3], ty = M[7], tz = M[11];
+    const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+    const double det = a * A + b * B + c * C;
+    const double inv[9] = {A / det, -(b * i - c * h) / det, (b * f - c * e) / det,
+                           B / det, (a * i - c * g) / det, -(a * f - c * d) / det,
+                           C / det, -(a * h - b * g) / det, (a * e - b * d) / det};
+    center[0] = (float)(-(inv[0] * tx + inv[1] * ty + inv[2] * tz));
+    center[1] = (float)(-(inv[3] * tx + inv[4] * ty + inv[5] * tz));
+    center[2] = (float)(-(inv[6] * tx + inv[7] * ty + inv[8] * tz));
+}
+
+// utils.py:60-72 as explicit fp32 arithmetic: ((m0*x + m1*y) + m2*z) + m3
+__device__ inline void to_camera(const float* __restrict__ M, float x, float y, float z, float* c) {
+    c[0] = M[0] * x + M[1] * y + M[2] * z + M[3];
+    c[1] = M[4] * x + M[5] * y + M[6] * z + M[7];
+    c[2] = M[8] * x + M[9] * y + M[10] * z + M[11];
+}
+
+__device__ inline bool is_culled(const float* c, const float* __restrict__ K, const Frustum& fr,
+                                 float* uv) {
+    uv[0] = K[0] * c[0] / c[2] + K[2];   // projection.cu:16-18
+    uv[1] = K[4] * c[1] / c[2] + K[5];
+    return (c[2] < fr.near) | (c[2] > fr.far) | (uv[0] < fr.u_lo) | (uv[0] > fr.u_hi) |
+           (uv[1] < fr.v_lo) | (uv[1] > fr.v_hi);
+}
+
+__global__ __launch_bounds__(PP_BLOCK) void k_cull_count(const float* __restrict__ xyz,
+                                                         const float* __restrict__ M,
+                                                         const float* __restrict__ K, int N,
+                                                         Frustum fr, int* __restrict__ block_counts) {
+    __shared__ int s_cnt[PP_BLOCK / GS_WAVE];
+    const int g = blockIdx.x * PP_BLOCK + threadIdx.x;
+    bool vis = false;
+    if (g < N) {
+        float c[3], uv[2];
+        to_camera(M, xyz[g * 3 + 0], xyz[g * 3 + 1], xyz[g * 3 + 2], c);
+        vis = !is_culled(c, K, fr, uv);
+    }
+    const int n = __popcll(__ballot(vis));
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// exclusive prefix of counts[n] in place of offsets[n]; total -> total_out[0].  One workgroup.
+__global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ counts, int n,
+                                                      int* __restrict__ offsets,
+                                                      int* __restrict__ total_out) {
+    __shared__ int s_wave[16];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 4096) {
+        int v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = base + tid * 4 + k;
+            v[k] = i < n ? counts[i] : 0;
+            sum += v[k];
+        }
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int off = s_carry;
+        for (int w = 0; w < wave; w++) off += s_wave[w];
+        int run = off + incl - sum;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = base + tid * 4 + k;
+            if (i < n) offsets[i] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = run;
+        __syncthreads();
+    }
+    if (tid == 0) total_out[0] = s_carry;
+}
+
+// activation of the opacity logit (rasterize.py:60-62: torch.sigmoid), IEEE-only form
+__device__ inline float sigmoid_det(float x) { return 1.0f / (1.0f + det_expf(-x)); }
+
+struct PreOut {
+    float* uv;        // [V,2]
+    float* conic;     // [V,3]
+    float* opacity;   // [V,1]  sigmoid(logit)
+    float* rgb;       // [V,3]  colour the renderer consumes
+    float* xyz_cam;   // [V,3]
+    float* packed;    // [V,8]
+    int* vis_idx;     // [V]    visible -> Gaussian
+    int* rank;        // [N]    Gaussian -> visible index or -1
+    uint8_t* culled;  // [N]    culling mask (1 = culled), rasterize.py:33-49
+};
+
+template <int N_SH>
+__global__ __launch_bounds__(PP_BLOCK) void k_preprocess(
+    const float* __restrict__ xyz, const float* __restrict__ quat, const float* __restrict__ scale,
+    const float* __restrict__ opacity, const float* __restrict__ rgb, const float* __restrict__ sh,
+    const float* __restrict__ M, const float* __restrict__ K, const float* __restrict__ center,
+    int N, Frustum fr, const int* __restrict__ block_offsets, PreOut o) {
+    __shared__ int s_cnt[PP_BLOCK / GS_WAVE];
+    const int g = blockIdx.x * PP_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool vis = false;
+    float c[3] = {0, 0, 1}, uv[2] = {0, 0}, p[3] = {0, 0, 0};
+    if (g < N) {
+        p[0] = xyz[g * 3 + 0]; p[1] = xyz[g * 3 + 1]; p[2] = xyz[g * 3 + 2];
+        to_camera(M, p[0], p[1], p[2], c);
+        vis = !is_culled(c, K, fr, uv);
+    }
+    const unsigned long long bal = __ballot(vis);
+    if (lane == 0) s_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int v = block_offsets[blockIdx.x] + __popcll(bal & ((1ull << lane) - 1));
+    for (int w = 0; w < wave; w++) v += s_cnt[w];
+    if (g >= N) return;
+    o.culled[g] = vis ? 0 : 1;
+    o.rank[g] = vis ? v : -1;
+    if (!vis) return;
+
+    o.vis_idx[v] = g;
+    o.uv[v * 2 + 0] = uv[0];
+    o.uv[v * 2 + 1] = uv[1];
+    o.xyz_cam[v * 3 + 0] = c[0];
+    o.xyz_cam[v * 3 + 1] = c[1];
+    o.xyz_cam[v * 3 + 2] = c[2];
+
+    const float q4[4] = {quat[g * 4 + 0], quat[g * 4 + 1], quat[g * 4 + 2], quat[g * 4 + 3]};
+    const float s3[3] = {scale[g * 3 + 0], scale[g * 3 + 1], scale[g * 3 + 2]};
+    float S9[9], W[9], J6[6], c3[3];
+    sigma_world_of(q4, s3, S9);
+    load_rotation(M, W);
+    J6[0] = K[0] / c[2];                       // projection.cu:169-174
+    J6[1] = 0;
+    J6[2] = -K[0] * c[0] / (c[2] * c[2]);
+    J6[3] = 0;
+    J6[4] = K[4] / c[2];
+    J6[5] = -K[4] * c[1] / (c[2] * c[2]);
+    conic_of(J6, W, S9, c3);
+    o.conic[v * 3 + 0] = c3[0];
+    o.conic[v * 3 + 1] = c3[1];
+    o.conic[v * 3 + 2] = c3[2];
+
+    const float opa = sigmoid_det(opacity[g]);
+    o.opacity[v] = opa;
+
+    float col[3];
+    if constexpr (N_SH == 1) {
+        col[0] = rgb[g * 3 + 0]; col[1] = rgb[g * 3 + 1]; col[2] = rgb[g * 3 + 2];
+    } else {
+        // precompute_sh.cu:28-55 with coefficient 0 = rgb and 1.. = sh (rasterize.py:89)
+        float d[3] = {p[0] - center[0], p[1] - center[1], p[2] - center[2]};
+        const float r = 1.0f / __builtin_sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        d[0] *= r; d[1] *= r; d[2] *= r;
+        float Y[N_SH];
+        sh_basis<float, N_SH>(d, Y);
+        const float* shg = sh + (size_t)g * 3 * (N_SH - 1);
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            float t = 0;
+            t += Y[0] * rgb[g * 3 + ch];
+#pragma unroll
+            for (int s = 1; s < N_SH; s++) t += Y[s] * shg[(N_SH - 1) * ch + (s - 1)];
+            t *= GS_R_SH_0;
+            col[ch] = t;
+        }
+    }
+    o.rgb[v * 3 + 0] = col[0];
+    o.rgb[v * 3 + 1] = col[1];
+    o.rgb[v * 3 + 2] = col[2];
+
+    // packed render record, identical to k_pack (render.cu:117-129)
+    const float a = c3[0] + 0.25;
+    const float b = c3[1] * 0.5;
+    const float cc = c3[2] + 0.25;
+    const float det = a * cc - b * b;
+    const float rdet = 1.0 / det;
+    float4* pk = reinterpret_cast<float4*>(o.packed + (size_t)v * 8);
+    pk[0] = make_float4(uv[0], uv[1], a, b);
+    pk[1] = make_float4(cc, det, rdet, opa);
+}
+
+struct PreGrad {
+    float* xyz;         // [N,3]
+    float* quaternion;  // [N,4]
+    float* scale;       // [N,3]
+    float* opacity;     // [N,1]
+    float* rgb;         // [N,3]
+    float* sh;          // [N,3,N_SH-1] or null
+};
+
+template <int N_SH>
+__global__ __launch_bounds__(PP_BLOCK) void k_preprocess_bwd(
+    const float* __restrict__ xyz, const float* __restrict__ quat, const float* __restrict__ scale,
+    const float* __restrict__ M, const float* __restrict__ K, const float* __restrict__ center,
+    const int* __restrict__ rank, const float* __restrict__ opacity_act,
+    const float* __restrict__ g_uv, const float* __restrict__ g_conic,
+    const float* __restrict__ g_opa, const float* __restrict__ g_rgb, int N, PreGrad o) {
+    const int g = blockIdx.x * PP_BLOCK + threadIdx.x;
+    if (g >= N) return;
+    const int v = rank[g];
+    float gx[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0}, gs[3] = {0, 0, 0}, go = 0, gc[3] = {0, 0, 0};
+    float* gsh = N_SH > 1 ? o.sh + (size_t)g * 3 * (N_SH - 1) : nullptr;
+    if (v < 0) {
+        if constexpr (N_SH > 1) {
+#pragma unroll
+            for (int k = 0; k < 3 * (N_SH - 1); k++) gsh[k] = 0;
+        }
+    } else {
+        const float p[3] = {xyz[g * 3 + 0], xyz[g * 3 + 1], xyz[g * 3 + 2]};
+        float c[3];
+        to_camera(M, p[0], p[1], p[2], c);
+        // colour: precompute_sh.cu:61-111, then the split of cat(rgb, sh) (rasterize.py:89)
+        const float gr[3] = {g_rgb[v * 3 + 0], g_rgb[v * 3 + 1], g_rgb[v * 3 + 2]};
+        if constexpr (N_SH == 1) {
+            gc[0] = gr[0]; gc[1] = gr[1]; gc[2] = gr[2];
+        } else {
+            float d[3] = {p[0] - center[0], p[1] - center[1], p[2] - center[2]};
+            const float r = 1.0f / __builtin_sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            d[0] *= r; d[1] *= r; d[2] *= r;
+            float Y[N_SH];
+            sh_basis<float, N_SH>(d, Y);
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const float gl = gr[ch] * GS_R_SH_0;
+                gc[ch] = gl * Y[0];
+#pragma unroll
+                for (int s = 1; s < N_SH; s++) gsh[(N_SH - 1) * ch + (s - 1)] = gl * Y[s];
+            }
+        }
+        // opacity: d sigmoid = y (1 - y)
+        const float y = opacity_act[v];
+        go = g_opa[v] * (1.0f - y) * y;
+        // conic -> Sigma_world, J (projection_backward.cu:385-471)
+        const float q4[4] = {quat[g * 4 + 0], quat[g * 4 + 1], quat[g * 4 + 2], quat[g * 4 + 3]};
+        const float s3[3] = {scale[g * 3 + 0], scale[g * 3 + 1], scale[g * 3 + 2]};
+        float S9[9], W[9], J6[6], gS9[9], gJ6[6];
+        sigma_world_of(q4, s3, S9);
+        load_rotation(M, W);
+        const float z = c[2], z2 = c[2] * c[2], z3 = c[2] * c[2] * c[2];
+        const float fx = K[0], fy = K[4];
+        J6[0] = fx / z; J6[1] = 0; J6[2] = -fx * c[0] / z2;
+        J6[3] = 0; J6[4] = fy / z; J6[5] = -fy * c[1] / z2;
+        const float gc3[3] = {g_conic[v * 3 + 0], g_conic[v * 3 + 1], g_conic[v * 3 + 2]};
+        conic_bwd_of(J6, W, S9, gc3, gS9, gJ6);
+        // Sigma_world -> quaternion, scale (projection_backward.cu:174-315)
+        sigma_world_bwd_of(q4, s3, gS9, gq, gs);
+        // J -> camera-frame xyz (projection_backward.cu:93-120)
+        float gcam[3];
+        gcam[0] = gJ6[2] * -fx / z2;
+        gcam[1] = gJ6[5] * -fy / z2;
+        gcam[2] = gJ6[0] * -fx / z2 + gJ6[4] * -fy / z2 + gJ6[2] * 2 * c[0] * fx / z3 +
+                  gJ6[5] * 2 * c[1] * fy / z3;
+        // uv -> camera-frame xyz (projection_backward.cu:9-36; nothing when z <= 0, Q10)
+        if (z > 0.0f) {
+            const float gu = g_uv[v * 2 + 0], gv = g_uv[v * 2 + 1];
+            gcam[0] += gu * (fx / z);
+            gcam[1] += gv * (fy / z);
+            gcam[2] += gu * (-fx * c[0] / z2) + gv * (-fy * c[1] / z2);
+        }
+        // camera frame -> world: transpose of the rotation block (backward of utils.py:64)
+        gx[0] = M[0] * gcam[0] + M[4] * gcam[1] + M[8] * gcam[2];
+        gx[1] = M[1] * gcam[0] + M[5] * gcam[1] + M[9] * gcam[2];
+        gx[2] = M[2] * gcam[0] + M[6] * gcam[1] + M[10] * gcam[2];
+    }
+    o.xyz[g * 3 + 0] = gx[0]; o.xyz[g * 3 + 1] = gx[1]; o.xyz[g * 3 + 2] = gx[2];
+    o.quaternion[g * 4 + 0] = gq[0]; o.quaternion[g * 4 + 1] = gq[1];
+    o.quaternion[g * 4 + 2] = gq[2]; o.quaternion[g * 4 + 3] = gq[3];
+    o.scale[g * 3 + 0] = gs[0]; o.scale[g * 3 + 1] = gs[1]; o.scale[g * 3 + 2] = gs[2];
+    o.opacity[g] = go;
+    o.rgb[g * 3 + 0] = gc[0]; o.rgb[g * 3 + 1] = gc[1]; o.rgb[g * 3 + 2] = gc[2];
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+static Frustum make_frustum(int W, int H, float near, float far, float padding) {
+    Frustum fr;
+    fr.near = near;
+    fr.far = far;
+    fr.u_lo = -1.0f * padding;
+    fr.u_hi = (float)W + padding;
+    fr.v_lo = -1.0f * padding;
+    fr.v_hi = (float)H + padding;
+    return fr;
+}
+
+#define DISPATCH_SH(n_sh, CALL)                                                                    \
+    switch (n_sh) {                                                                                \
+        case 1: { constexpr int N_SH = 1; CALL; } break;                                           \
+        case 4: { constexpr int N_SH = 4; CALL; } break;                                           \
+        case 9: { constexpr int N_SH = 9; CALL; } break;                                           \
+        case 16: { constexpr int N_SH = 16; CALL; } break;                                         \
+        default:                                                                                   \
+            gs::set_error("Unsupported number of SH coefficients: %d", n_sh);                      \
+            return GS_EINVAL;                                                                      \
+    }
+
+extern "C" {
+
+size_t gs_preprocess_workspace_ints(int N) { return (size_t)div_up(N > 0 ? N : 1, PP_BLOCK) * 2 + 8; }
+
+int gs_preprocess_forward(const void* xyz, const void* quaternion, const void* scale,
+                          const void* opacity, const void* rgb, const void* sh, int n_sh,
+                          const void* camera_T_world, const void* K, int N, int W, int H,
+                          float near_thresh, float far_thresh, float cull_mask_padding,
+                          int32_t* workspace, void* camera_center, int32_t* visible_count,
+                          uint8_t* culling_mask, int32_t* rank, int32_t* vis_idx, void* uv,
+                          void* xyz_camera_frame, void* conic, void* opacity_act, void* rgb_render,
+                          void* packed, void* stream) {
+    GS_REQUIRE(n_sh == 1 || sh != nullptr, "sh must be given when n_sh > 1");
+    hipStream_t s = (hipStream_t)stream;
+    const Frustum fr = make_frustum(W, H, near_thresh, far_thresh, cull_mask_padding);
+    const int nb = div_up(N > 0 ? N : 1, PP_BLOCK);
+    int* block_counts = workspace;
+    int* block_offsets = workspace + nb;
+    k_camera_center<<<1, 64, 0, s>>>((const float*)camera_T_world, (float*)camera_center);
+    k_cull_count<<<nb, PP_BLOCK, 0, s>>>((const float*)xyz, (const float*)camera_T_world,
+                                         (const float*)K, N, fr, block_counts);
+    k_scan_counts<<<1, 1024, 0, s>>>(block_counts, nb, block_offsets, visible_count);
+    PreOut o;
+    o.uv = (float*)uv;
+    o.conic = (float*)conic;
+    o.opacity = (float*)opacity_act;
+    o.rgb = (float*)rgb_render;
+    o.xyz_cam = (float*)xyz_camera_frame;
+    o.packed = (float*)packed;
+    o.vis_idx = vis_idx;
+    o.rank = rank;
+    o.culled = culling_mask;
+    DISPATCH_SH(n_sh, (k_preprocess<N_SH><<<nb, PP_BLOCK, 0, s>>>(
+                          (const float*)xyz, (const float*)quaternion, (const float*)scale,
+                          (const float*)opacity, (const float*)rgb, (const float*)sh,
+                          (const float*)camera_T_world, (const float*)K,
+                          (const float*)camera_center, N, fr, block_offsets, o)));
+    return check_launch("preprocess_forward");
+}
+
+int gs_preprocess_backward(const void* xyz, const void* quaternion, const void* scale, int n_sh,
+                           const void* camera_T_world, const void* K, const void* camera_center,
+                           const int32_t* rank, const void* opacity_act, const void* grad_uv,
+                           const void* grad_conic, const void* grad_opacity, const void* grad_rgb,
+                           int N, void* grad_xyz, void* grad_quaternion, void* grad_scale,
+                           void* grad_opacity_logit, void* grad_rgb_param, void* grad_sh,
+                           void* stream) {
+    GS_REQUIRE(n_sh == 1 || grad_sh != nullptr, "grad_sh must be given when n_sh > 1");
+    hipStream_t s = (hipStream_t)stream;
+    if (N <= 0) return GS_OK;
+    PreGrad o;
+    o.xyz = (float*)grad_xyz;
+    o.quaternion = (float*)grad_quaternion;
+    o.scale = (float*)grad_scale;
+    o.opacity = (float*)grad_opacity_logit;
+    o.rgb = (float*)grad_rgb_param;
+    o.sh = (float*)grad_sh;
+    DISPATCH_SH(n_sh, (k_preprocess_bwd<N_SH><<<div_up(N, PP_BLOCK), PP_BLOCK, 0, s>>>(
+                          (const float*)xyz, (const float*)quaternion, (const float*)scale,
+                          (const float*)camera_T_world, (const float*)K,
+                          (const float*)camera_center, rank, (const float*)opacity_act,
+                          (const float*)grad_uv, (const float*)grad_conic,
+                          (const float*)grad_opacity, (const float*)grad_rgb, N, o)));
+    return check_launch("preprocess_backward");
+}
+
+}  // extern "C"

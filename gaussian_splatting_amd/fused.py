@@ -1,0 +1,178 @@
+"""Fast path with the contract of splat_py.rasterize.rasterize (reference: splat_py/rasterize.py:18-112):
+
+    image, culling_mask, uv = rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh,
+                                        cull_mask_padding, mh_dist, use_sh_precompute, background_rgb)
+
+Two autograd nodes instead of six-plus-glue:
+
+    _Preprocess   gs_preprocess_forward + tile binning + per-tile sort   (parameters -> uv, conic,
+                  opacity, colour; non-differentiable: packed records, tile lists, culling mask)
+    _Render       gs_render_tiles / gs_render_tiles_backward
+
+so `uv` is still an autograd intermediate between two nodes: `uv.retain_grad()` followed by
+`uv.grad` gives the render-backward grad_uv exactly as the trainer expects (trainer.py:360,379).
+One 8-byte device->host read per frame (V and S, to size the outputs); the reference has ~25
+synchronisation points.  fp32, SH-precompute colour mode; anything else is routed
+to the reference-shaped path in splat_py.rasterize (still HIP kernels, never a CPU fallback).
+"""
+import ctypes
+
+import torch
+
+from . import _hip
+from .splat_py import rasterize as _reference_shaped
+from .splat_py.structs import TILE_EDGE_LENGTH_PX
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _cf(x):
+    return ctypes.c_float(float(x))
+
+
+class _Preprocess(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, quaternion, scale, opacity, rgb, sh, camera_T_world, K, width, height, near_thresh,
+                far_thresh, cull_mask_padding, mh_dist, tile_rows):
+        dev = xyz.device
+        N = xyz.shape[0]
+        n_sh = 1 if sh is None else sh.shape[2] + 1
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        ntx = (width + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
+        nty = (height + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
+        T = ntx * nty
+        row0, row1 = tile_rows if tile_rows is not None else (0, nty)
+
+        ws = torch.empty(_hip.lib().gs_preprocess_workspace_ints(N), **i32)
+        center = torch.empty(3, **f32)
+        count = torch.empty(1, **i32)
+        culling_mask = torch.empty(N, dtype=torch.bool, device=dev)   # kernel writes 0/1 bytes
+        rank = torch.empty(N, **i32)
+        vis_idx = torch.empty(N, **i32)
+        uv = torch.empty(N, 2, **f32)
+        xyz_cam = torch.empty(N, 3, **f32)
+        conic = torch.empty(N, 3, **f32)
+        opacity_act = torch.empty(N, 1, **f32)
+        rgb_render = torch.empty(N, 3, **f32)
+        packed = torch.empty(N, 8, **f32)
+        _hip.call("gs_preprocess_forward", _p(xyz), _p(quaternion), _p(scale), _p(opacity), _p(rgb), _p(sh), n_sh,
+                  _p(camera_T_world), _p(K), N, width, height, _cf(near_thresh), _cf(far_thresh),
+                  _cf(cull_mask_padding), _p(ws), _p(center), _p(count), _p(culling_mask), _p(rank), _p(vis_idx), _p(uv),
+                  _p(xyz_cam), _p(conic), _p(opacity_act), _p(rgb_render), _p(packed), _stream())
+
+        tile_counts = torch.empty(T, **i32)
+        ranges = torch.empty(T + 2, **i32)
+        _hip.call("gs_tile_count_bounded", _p(uv), _p(conic), N, _p(count), ntx, nty, _cf(mh_dist), row0, row1,
+                  _p(tile_counts), _p(ranges), _stream())
+        S, V = ranges[T:T + 2].tolist()   # the frame's only device->host read
+        sorted_g = torch.empty(S, **i32)
+        if S > 0:
+            keys = torch.empty(S, dtype=torch.int64, device=dev)
+            _hip.call("gs_tile_emit_sort", _p(uv), _p(xyz_cam), _p(conic), V, ntx, nty, _cf(mh_dist), row0, row1,
+                      _p(ranges), _p(tile_counts), _p(keys), ctypes.c_int64(S), _p(sorted_g), _stream())
+
+        ctx.save_for_backward(xyz, quaternion, scale, camera_T_world, K, center, rank, opacity_act)
+        ctx.n_sh = n_sh
+        ctx.sh_shape = None if sh is None else tuple(sh.shape)
+        uv_v, conic_v, opa_v, rgb_v = uv[:V], conic[:V], opacity_act[:V], rgb_render[:V]
+        aux = (packed, xyz_cam[:V], culling_mask, ranges[:T + 1], sorted_g, vis_idx[:V])
+        ctx.mark_non_differentiable(*aux)
+        return (uv_v, conic_v, opa_v, rgb_v) + aux
+
+    @staticmethod
+    def backward(ctx, g_uv, g_conic, g_opa, g_rgb, *unused):
+        xyz, quaternion, scale, camera_T_world, K, center, rank, opacity_act = ctx.saved_tensors
+        N = xyz.shape[0]
+        V = int(g_uv.shape[0]) if g_uv is not None else 0
+        dev = xyz.device
+
+        def dense(g, width):
+            if g is None:
+                return torch.zeros(max(V, 1), width, dtype=torch.float32, device=dev)
+            return g.contiguous()
+
+        g_uv, g_conic, g_opa, g_rgb = dense(g_uv, 2), dense(g_conic, 3), dense(g_opa, 1), dense(g_rgb, 3)
+        f32 = dict(dtype=torch.float32, device=dev)
+        grad_xyz = torch.empty(N, 3, **f32)
+        grad_q = torch.empty(N, 4, **f32)
+        grad_scale = torch.empty(N, 3, **f32)
+        grad_opacity = torch.empty(N, 1, **f32)
+        grad_rgb = torch.empty(N, 3, **f32)
+        grad_sh = torch.empty(ctx.sh_shape, **f32) if ctx.sh_shape is not None else None
+        _hip.call("gs_preprocess_backward", _p(xyz), _p(quaternion), _p(scale), ctx.n_sh, _p(camera_T_world), _p(K),
+                  _p(center), _p(rank), _p(opacity_act), _p(g_uv), _p(g_conic), _p(g_opa), _p(g_rgb), N,
+                  _p(grad_xyz), _p(grad_q), _p(grad_scale), _p(grad_opacity), _p(grad_rgb), _p(grad_sh), _stream())
+        return (grad_xyz, grad_q, grad_scale, grad_opacity, grad_rgb, grad_sh) + (None,) * 9
+
+
+class _Render(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, uv, conic, opacity, rgb, packed, ranges, sorted_g, background_rgb, height, width, tile_rows):
+        dev = uv.device
+        nty = (height + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
+        row0, row1 = tile_rows if tile_rows is not None else (0, nty)
+        # rows outside [row0, row1) are not written by the kernel: zero-fill only when sharded
+        alloc = torch.empty if tile_rows is None else torch.zeros
+        image = alloc(height, width, 3, dtype=torch.float32, device=dev)
+        nsp = alloc(height, width, dtype=torch.int32, device=dev)
+        fw = alloc(height, width, dtype=torch.float32, device=dev)
+        _hip.call("gs_render_tiles", _p(packed), _p(rgb), None, _p(ranges), _p(sorted_g), _p(background_rgb), width,
+                  height, 1, row0, row1, _p(nsp), _p(fw), _p(image), _hip.GS_F32, _stream())
+        ctx.save_for_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw)
+        ctx.dims = (height, width, row0, row1, uv.shape[0])
+        return image
+
+    @staticmethod
+    def backward(ctx, grad_image):
+        packed, rgb, ranges, sorted_g, background_rgb, nsp, fw = ctx.saved_tensors
+        height, width, row0, row1, V = ctx.dims
+        dev = packed.device
+        grad_image = grad_image.contiguous()
+        # one zero-filled slab [V, 9]: rgb 3 | opacity 1 | uv 2 | conic 3 (atomicAdd targets)
+        slab = torch.zeros(9 * V, dtype=torch.float32, device=dev)
+        g_rgb = slab[0:3 * V].view(V, 3)
+        g_opa = slab[3 * V:4 * V].view(V, 1)
+        g_uv = slab[4 * V:6 * V].view(V, 2)
+        g_conic = slab[6 * V:9 * V].view(V, 3)
+        _hip.call("gs_render_tiles_backward", _p(packed), _p(rgb), None, _p(ranges), _p(sorted_g),
+                  _p(background_rgb), _p(nsp), _p(fw), _p(grad_image), width, height, 1, row0, row1, _p(g_rgb),
+                  _p(g_opa), _p(g_uv), _p(g_conic), _hip.GS_F32, _stream())
+        return g_uv, g_conic, g_opa, g_rgb, None, None, None, None, None, None, None
+
+
+def supported(gaussians, camera_T_world, camera, use_sh_precompute):
+    if not gaussians.xyz.is_cuda or gaussians.xyz.dtype != torch.float32:
+        return False
+    if gaussians.sh is not None and not use_sh_precompute:
+        return False   # per-pixel SH evaluation: reference-shaped path (N_SH in {4,9,16} render kernels)
+    return True
+
+
+def rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_mask_padding, mh_dist,
+              use_sh_precompute, background_rgb, tile_rows=None, return_aux=False):
+    if not supported(gaussians, camera_T_world, camera, use_sh_precompute):
+        if tile_rows is not None:
+            raise RuntimeError("tile_rows is only supported on the fused fp32 SH-precompute path")
+        return _reference_shaped.rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh,
+                                           cull_mask_padding, mh_dist, use_sh_precompute, background_rgb)
+    g = gaussians
+    sh = g.sh.contiguous() if g.sh is not None else None
+    out = _Preprocess.apply(
+        g.xyz.contiguous(), g.quaternion.contiguous(), g.scale.contiguous(), g.opacity.contiguous(),
+        g.rgb.contiguous(), sh, camera_T_world.contiguous(), camera.K.contiguous(), int(camera.width),
+        int(camera.height), near_thresh, far_thresh, cull_mask_padding, mh_dist, tile_rows)
+    uv, conic, opacity, rgb, packed, xyz_cam, culling_mask, ranges, sorted_g, vis_idx = out
+    image = _Render.apply(uv, conic, opacity, rgb, packed, ranges, sorted_g, background_rgb.contiguous(),
+                          int(camera.height), int(camera.width), tile_rows)
+    if return_aux:
+        return image, culling_mask, uv, dict(conic=conic, opacity=opacity, rgb=rgb, packed=packed,
+                                             xyz_camera_frame=xyz_cam, tile_ranges=ranges,
+                                             sorted_gaussians=sorted_g, vis_idx=vis_idx)
+    return image, culling_mask, uv

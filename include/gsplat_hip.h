@@ -98,10 +98,53 @@ int gs_precompute_rgb_from_sh_backward(const void* xyz, const void* matrix, cons
 int gs_tile_count(const void* uvs, const void* conic, int V, int n_tiles_x, int n_tiles_y,
                   float mh_dist, int tile_row0, int tile_row1, int32_t* tile_counts /*[T]*/,
                   int32_t* tile_ranges /*[T+1]*/, void* stream);
+/* Same as gs_tile_count for the fused path, where the number of visible Gaussians V lives on the
+ * device (gs_preprocess_forward): rows >= *visible_count of the capacity-sized inputs are
+ * ignored.  tile_ranges has T+2 entries: [T] = S, [T+1] = V, so one 8-byte read returns both. */
+int gs_tile_count_bounded(const void* uvs, const void* conic, int capacity,
+                          const int32_t* visible_count, int n_tiles_x, int n_tiles_y,
+                          float mh_dist, int tile_row0, int tile_row1, int32_t* tile_counts /*[T]*/,
+                          int32_t* tile_ranges /*[T+2]*/, void* stream);
 int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void* conic, int V,
                       int n_tiles_x, int n_tiles_y, float mh_dist, int tile_row0, int tile_row1,
                       const int32_t* tile_ranges, int32_t* tile_cursor, uint64_t* keys, int64_t S,
                       int32_t* sorted_gaussians /*[S]*/, void* stream);
+
+/* ---- fused per-Gaussian stage (fp32) ----------------------------------------------------------------
+ * One pass replacing the PyTorch glue and per-Gaussian kernels of rasterize()
+ * (splat_py/rasterize.py:29-99: utils.py:60-72 transform, projection.cu:9-19, the frustum cull
+ * :33-49, the boolean-mask gathers :52-75, torch.sigmoid :60, projection.cu:57-257,
+ * precompute_sh.cu:8-58 on cat(rgb, sh) :89).  Survivors are compacted in Gaussian order, so
+ * the visible index equals the reference's boolean-mask index.
+ *   inputs   xyz[N,3] quaternion[N,4] scale[N,3] opacity[N,1] (logits) rgb[N,3]
+ *            sh[N,3,n_sh-1] (NULL when n_sh == 1), camera_T_world[4,4], K[3,3]
+ *   workspace int32[gs_preprocess_workspace_ints(N)]
+ *   outputs  camera_center[3]; visible_count[1] (= V, on the device); culling_mask uint8[N]
+ *            (1 = culled); rank int32[N] (visible index or -1); and, with capacity N rows of which
+ *            the first V are written: vis_idx int32, uv[.,2], xyz_camera_frame[.,3], conic[.,3],
+ *            opacity_act[.,1] = sigmoid, rgb_render[.,3], packed[.,8] (see gs_pack_splats). */
+size_t gs_preprocess_workspace_ints(int N);
+int gs_preprocess_forward(const void* xyz, const void* quaternion, const void* scale,
+                          const void* opacity, const void* rgb, const void* sh, int n_sh,
+                          const void* camera_T_world, const void* K, int N, int W, int H,
+                          float near_thresh, float far_thresh, float cull_mask_padding,
+                          int32_t* workspace, void* camera_center, int32_t* visible_count,
+                          uint8_t* culling_mask, int32_t* rank, int32_t* vis_idx, void* uv,
+                          void* xyz_camera_frame, void* conic, void* opacity_act, void* rgb_render,
+                          void* packed, void* stream);
+/* Backward of the above (projection_backward.cu:9-471, precompute_sh.cu:61-111 and the autograd of
+ * the glue: sigmoid', the cat split, the dense scatter of rasterize.py:52-75, matmul').  Takes the
+ * render gradients w.r.t. uv[V,2], conic[V,3], opacity_act[V,1], rgb_render[V,3] and writes the
+ * dense parameter gradients, every row exactly once (zeros for culled Gaussians): grad_xyz[N,3],
+ * grad_quaternion[N,4], grad_scale[N,3], grad_opacity_logit[N,1], grad_rgb_param[N,3],
+ * grad_sh[N,3,n_sh-1] (NULL when n_sh == 1). */
+int gs_preprocess_backward(const void* xyz, const void* quaternion, const void* scale, int n_sh,
+                           const void* camera_T_world, const void* K, const void* camera_center,
+                           const int32_t* rank, const void* opacity_act, const void* grad_uv,
+                           const void* grad_conic, const void* grad_opacity, const void* grad_rgb,
+                           int N, void* grad_xyz, void* grad_quaternion, void* grad_scale,
+                           void* grad_opacity_logit, void* grad_rgb_param, void* grad_sh,
+                           void* stream);
 
 /* ---- tile renderer ---------------------------------------------------------------------------- */
 /* Packs the per-splat geometry the render kernels read into one record per visible Gaussian:

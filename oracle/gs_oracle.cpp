@@ -534,6 +534,11 @@ int orc_num_threads() {
 #endif
 }
 float orc_det_expf(float x) { return det_expf(x); }
+// IEEE-only sigmoid used by the fused preprocess kernel in place of torch.sigmoid
+// (splat_py/rasterize.py:60-62); within a few ulp of it
+void orc_sigmoid_f32(const float* x, int N, float* y) {
+    for (int i = 0; i < N; i++) y[i] = 1.0f / (1.0f + det_expf(-x[i]));
+}
 
 #define INST(T, SFX)                                                                               \
     void orc_camera_projection_##SFX(const T* xyz, const T* K, int N, T* uv) {                     \

@@ -48,6 +48,14 @@ def set_sh_band1_mode(mode):
     lib().orc_set_sh_band1_mode(int(mode))
 
 
+def sigmoid_det(x):
+    """the IEEE-only sigmoid of the fused preprocess kernel (fp32 CPU tensor -> tensor)"""
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    lib().orc_sigmoid_f32(_p(x), x.numel(), _p(y))
+    return y
+
+
 def num_threads():
     return lib().orc_num_threads()
 

@@ -1,0 +1,225 @@
+"""GPU parity tests of the fused fast path (gaussian_splatting_amd.fused): stage-wise bit-exact
+against the CPU oracle, end-to-end against the reference-shaped path and the golden fixtures."""
+import numpy as np
+import pytest
+import torch
+
+from gaussian_splatting_amd import fused
+from gaussian_splatting_amd.splat_py.rasterize import rasterize as rasterize_mirror
+from gaussian_splatting_amd.synthetic import make_grad_image, make_scene
+
+from .helpers import load, scaled_err, scene6, scene_from_fixture, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GRAD_TOL = 1e-4
+PARAMS = ("xyz", "rgb", "opacity", "scale", "quaternion", "sh")
+
+
+def oracle():
+    from oracle import gs_oracle
+    gs_oracle.set_modes(0, 0)
+    gs_oracle.set_sh_band1_mode(0)
+    return gs_oracle
+
+
+def cpu_expected_stages(g, cam, T, near, far, pad, mh):
+    """the fused forward restated on the CPU with the oracle's kernels; the world->camera transform
+    is written as the same explicit fp32 expression the kernel uses"""
+    orc = oracle()
+    x, y, z = g.xyz[:, 0], g.xyz[:, 1], g.xyz[:, 2]
+    M = T
+    xyz_c = torch.stack([M[i, 0] * x + M[i, 1] * y + M[i, 2] * z + M[i, 3] for i in range(3)], dim=1).contiguous()
+    N = g.xyz.shape[0]
+    uv = torch.zeros(N, 2)
+    orc.camera_projection_cuda(xyz_c, cam.K, uv)
+    f = lambda v: torch.tensor(v, dtype=torch.float32)
+    culled = ((xyz_c[:, 2] < f(near)) | (xyz_c[:, 2] > f(far)) | (uv[:, 0] < f(-1.0 * pad)) |
+              (uv[:, 0] > f(cam.width + pad)) | (uv[:, 1] < f(-1.0 * pad)) | (uv[:, 1] > f(cam.height + pad)))
+    keep = ~culled
+    uv, xyz_c = uv[keep].contiguous(), xyz_c[keep].contiguous()
+    V = uv.shape[0]
+    sigma = torch.zeros(V, 3, 3)
+    orc.compute_sigma_world_cuda(g.quaternion[keep].contiguous(), g.scale[keep].contiguous(), sigma)
+    J = torch.zeros(V, 2, 3)
+    orc.compute_projection_jacobian_cuda(xyz_c, cam.K, J)
+    conic = torch.zeros(V, 3)
+    orc.compute_conic_cuda(sigma, J, T, conic)
+    opacity = orc.sigmoid_det(g.opacity[keep].contiguous())
+    A = T[:3, :3].double().numpy()
+    center = torch.from_numpy((-np.linalg.inv(A) @ T[:3, 3].double().numpy()).astype(np.float32))
+    if g.sh is not None:
+        coeffs = torch.cat((g.rgb[keep].unsqueeze(2), g.sh[keep]), dim=2).contiguous()
+        Minv = torch.eye(4)
+        Minv[:3, 3] = center
+        rgb = torch.zeros(V, 3)
+        orc.precompute_rgb_from_sh_cuda(g.xyz[keep].contiguous(), coeffs, Minv, rgb)
+    else:
+        rgb = g.rgb[keep].contiguous()
+    ntx, nty = (cam.width + 15) // 16, (cam.height + 15) // 16
+    sorted_g, ranges = orc.get_sorted_gaussian_list(1024, uv, xyz_c, conic, ntx, nty, mh)
+    return dict(culled=culled, uv=uv, xyz_c=xyz_c, conic=conic, opacity=opacity, rgb=rgb, sorted=sorted_g,
+                ranges=ranges, V=V)
+
+
+@pytest.mark.parametrize("N,W,H,deg,seed", [(1000, 256, 256, 0, 0), (20000, 640, 472, 3, 1), (5000, 200, 120, 1, 2),
+                                            (5000, 200, 120, 2, 3)])
+def test_fused_forward_stages_bit_exact(N, W, H, deg, seed):
+    orc = oracle()
+    g, cam, T = make_scene(N, W, H, deg, seed=seed)
+    T = T.clone()
+    T[:3, :3] = torch.tensor([[0.9999, 0.0089, 0.0073], [-0.0106, 0.9568, 0.2905], [-0.0044, -0.2906, 0.9568]])
+    T[:3, 3] = torch.tensor([0.05, -0.1, 0.3])
+    near, far, pad, mh = 2.0, 25.0, 20, 3.0
+    exp = cpu_expected_stages(g, cam, T, near, far, pad, mh)
+    gd, camd, Td = make_scene(N, W, H, deg, seed=seed, device=DEV)
+    bg = torch.full((3,), 0.5)
+    image, mask, uv, aux = fused.rasterize(gd, T.to(DEV), camd, near, far, pad, mh, True, bg.to(DEV), return_aux=True)
+    V = exp["V"]
+    assert 0 < V < N
+    assert torch.equal(mask.cpu(), exp["culled"])
+    assert torch.equal(uv.cpu(), exp["uv"])
+    assert torch.equal(aux["xyz_camera_frame"].cpu(), exp["xyz_c"])
+    assert torch.equal(aux["conic"].cpu(), exp["conic"])
+    assert torch.equal(aux["opacity"].cpu(), exp["opacity"])
+    assert torch.equal(aux["vis_idx"].cpu().long(), torch.nonzero(~exp["culled"]).flatten())
+    assert torch.equal(aux["tile_ranges"].cpu(), exp["ranges"])
+    assert torch.equal(aux["sorted_gaussians"].cpu(), exp["sorted"])
+    # colour: the camera centre is formed in fp64 on both sides but by different algorithms
+    assert (aux["rgb"].cpu() - exp["rgb"]).abs().max() < 2e-6
+    # render: the oracle on the kernel's own per-splat inputs -> bit-identical image
+    img = torch.zeros(H, W, 3)
+    nsp = torch.zeros(H, W, dtype=torch.int32)
+    fw = torch.zeros(H, W)
+    orc.render_tiles_cuda(exp["uv"], exp["opacity"], aux["rgb"].cpu().contiguous(), exp["conic"], torch.zeros(1, 1, 1),
+                          exp["ranges"], exp["sorted"], bg, nsp, fw, img)
+    assert torch.equal(image.cpu(), img)
+
+
+@pytest.mark.parametrize("N,W,H,deg,seed,bgval", [(1000, 256, 256, 0, 0, 0.0), (20000, 640, 472, 3, 1, 0.5)])
+def test_fused_matches_reference_shaped_path(hip_backend, N, W, H, deg, seed, bgval):
+    """same frame through the six-node path and through the fused path: forward within the
+    tolerance of an ulp-level difference in the world->camera transform, gradients 1e-4"""
+    bg = torch.full((3,), bgval, device=DEV)
+    gi = make_grad_image(W, H, seed=seed + 9, device=DEV)
+    outs = []
+    for fn in (rasterize_mirror, fused.rasterize):
+        g, cam, T = make_scene(N, W, H, deg, seed=seed, device=DEV)
+        for k in PARAMS:
+            if getattr(g, k) is not None:
+                getattr(g, k).requires_grad_(True)
+        img, mask, uv = fn(g, T, cam, 0.3, 500.0, 100, 3.0, True, bg)
+        uv.retain_grad()
+        img.backward(gi)
+        outs.append((img.detach(), mask, uv.detach(), uv.grad, {k: getattr(g, k).grad for k in PARAMS
+                                                                  if getattr(g, k) is not None}))
+    (i0, m0, u0, gu0, p0), (i1, m1, u1, gu1, p1) = outs
+    assert torch.equal(m0, m1)
+    assert (u0 - u1).abs().max() < 1e-3
+    diff = (i0 - i1).abs().amax(dim=2)
+    assert (diff > 1e-5).float().mean() < 2e-3 and diff.max() < 5e-3
+    assert scaled_err(gu1, gu0) < 5e-3
+    for k in p0:
+        assert p1[k].shape == p0[k].shape
+        assert scaled_err(p1[k], p0[k]) < 5e-3, f"{k}: {scaled_err(p1[k], p0[k])}"
+
+
+@pytest.mark.parametrize("tag", ["deg0", "deg3_pre"])
+def test_fused_matches_reference_host_fixtures(tag):
+    fx = load(f"ref_host_synth_{tag}.npz")
+    g, cam, T = scene_from_fixture(fx, DEV, requires_grad=True)
+    img, mask, uv = fused.rasterize(g, T, cam, float(fx["near"]), float(fx["far"]), int(fx["padding"]),
+                                    float(fx["mh_dist"]), True, t(fx["background"], DEV))
+    uv.retain_grad()
+    img.backward(t(fx["grad_image"], DEV))
+    assert np.array_equal(mask.cpu().numpy(), fx["mask"])
+    diff = np.abs(img.detach().cpu().numpy() - fx["image"]).max(axis=2)
+    assert (diff > 1e-5).mean() < 2e-3 and diff.max() < 5e-3
+    assert uv.grad is not None and scaled_err(uv.grad, t(fx["grad_uv"])) < 5e-3
+    for k in PARAMS:
+        if "grad_" + k in fx.files:
+            e = scaled_err(getattr(g, k).grad, t(fx["grad_" + k]))
+            assert e < 5e-3, f"{k}: {e}"
+
+
+def test_fused_backward_parity_vs_oracle_chain():
+    """dense parameter gradients of the fused backward against the oracle's per-stage backward
+    kernels chained on the CPU from the same render gradients"""
+    orc = oracle()
+    N, W, H, deg, seed = 8000, 320, 240, 3, 5
+    near, far, pad, mh = 0.3, 500.0, 100, 3.0
+    g, cam, T = make_scene(N, W, H, deg, seed=seed)
+    exp = cpu_expected_stages(g, cam, T, near, far, pad, mh)
+    gd, camd, Td = make_scene(N, W, H, deg, seed=seed, device=DEV)
+    for k in PARAMS:
+        getattr(gd, k).requires_grad_(True)
+    bg = torch.zeros(3, device=DEV)
+    image, mask, uv, aux = fused.rasterize(gd, Td, camd, near, far, pad, mh, True, bg, return_aux=True)
+    for k in ("conic", "opacity", "rgb"):
+        aux[k].retain_grad()
+    uv.retain_grad()
+    image.backward(make_grad_image(W, H, seed=3, device=DEV))
+    V = exp["V"]
+    keep = ~exp["culled"]
+    g_uv, g_conic = uv.grad.cpu().contiguous(), aux["conic"].grad.cpu().contiguous()
+    g_opa, g_rgb = aux["opacity"].grad.cpu().contiguous(), aux["rgb"].grad.cpu().contiguous()
+    # oracle chain
+    q, s = g.quaternion[keep].contiguous(), g.scale[keep].contiguous()
+    sigma = torch.zeros(V, 3, 3); orc.compute_sigma_world_cuda(q, s, sigma)
+    J = torch.zeros(V, 2, 3); orc.compute_projection_jacobian_cuda(exp["xyz_c"], cam.K, J)
+    g_sigma, g_J = torch.zeros(V, 3, 3), torch.zeros(V, 2, 3)
+    orc.compute_conic_backward_cuda(sigma, J, T, g_conic, g_sigma, g_J)
+    g_q, g_s = torch.zeros(V, 4), torch.zeros(V, 3)
+    orc.compute_sigma_world_backward_cuda(q, s, g_sigma, g_q, g_s)
+    gx1, gx2 = torch.zeros(V, 3), torch.zeros(V, 3)
+    orc.compute_projection_jacobian_backward_cuda(exp["xyz_c"], cam.K, g_J, gx1)
+    orc.camera_projection_backward_cuda(exp["xyz_c"], cam.K, g_uv, gx2)
+    g_cam = gx1 + gx2
+    g_xyz_v = g_cam @ T[:3, :3]           # rows: R^T g
+    A = T[:3, :3].double().numpy()
+    center = torch.from_numpy((-np.linalg.inv(A) @ T[:3, 3].double().numpy()).astype(np.float32))
+    Minv = torch.eye(4); Minv[:3, 3] = center
+    g_coeff = torch.zeros(V, 3, 16)
+    orc.precompute_rgb_from_sh_backward_cuda(g.xyz[keep].contiguous(), Minv, g_rgb, g_coeff)
+    y = exp["opacity"]
+    g_logit = g_opa * (1 - y) * y
+
+    def dense(v, shape):
+        out = torch.zeros(shape)
+        out[keep] = v
+        return out
+
+    expect = dict(xyz=dense(g_xyz_v, (N, 3)), quaternion=dense(g_q, (N, 4)), scale=dense(g_s, (N, 3)),
+                  opacity=dense(g_logit, (N, 1)), rgb=dense(g_coeff[:, :, 0], (N, 3)),
+                  sh=dense(g_coeff[:, :, 1:], (N, 3, 15)))
+    for k, e in expect.items():
+        got = getattr(gd, k).grad.cpu()
+        assert torch.equal(got[exp["culled"]], torch.zeros_like(got[exp["culled"]])), k
+        assert scaled_err(got, e) < 2e-5, f"{k}: {scaled_err(got, e)}"
+
+
+def test_fused_known_answers_and_uv_grad():
+    """test/test_rasterize.py:21-54 through the fused path; uv.retain_grad() semantics"""
+    g, cam, T, fx = scene6(DEV)
+    for k in ("xyz", "rgb", "opacity", "scale", "quaternion"):
+        getattr(g, k).requires_grad_(True)
+    img, mask, uv = fused.rasterize(g, T, cam, 0.3, 100.0, 10, 3.0, True, torch.zeros(3, device=DEV))
+    for ch, v in enumerate([0.47698545455932617, 0.0, 0.0]):
+        assert abs(img[340, 348, ch].item() - v) < 5e-6
+    for ch, v in enumerate([0.03330837935209274, 0.0, 0.267561137676239]):
+        assert abs(img[200, 348, ch].item() - v) < 5e-6
+    assert mask.tolist() == [True, True, True, False, False, False]
+    uv.retain_grad()
+    img.sum().backward()
+    assert uv.grad.shape == (3, 2) and torch.isfinite(uv.grad).all() and uv.grad.abs().sum() > 0
+    assert (g.xyz.grad[:3] == 0).all() and g.xyz.grad[3:].abs().sum() > 0
+
+
+def test_fused_everything_culled_and_no_grad_paths():
+    g, cam, T = make_scene(500, 128, 96, 0, seed=1, device=DEV)
+    img, mask, uv = fused.rasterize(g, T, cam, 1000.0, 2000.0, 100, 3.0, True, torch.full((3,), 0.25, device=DEV))
+    assert mask.all() and uv.shape == (0, 2)
+    assert torch.allclose(img, torch.full_like(img, 0.25))
+    with torch.no_grad():
+        img2, _, _ = fused.rasterize(g, T, cam, 0.3, 500.0, 100, 3.0, True, torch.zeros(3, device=DEV))
+    assert img2.shape == (96, 128, 3)
