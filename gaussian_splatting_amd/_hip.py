@@ -21,7 +21,7 @@ EXPORTS = [
     "gs_compute_projection_jacobian", "gs_compute_projection_jacobian_backward",
     "gs_compute_conic", "gs_compute_conic_backward",
     "gs_precompute_rgb_from_sh", "gs_precompute_rgb_from_sh_backward",
-    "gs_tile_count", "gs_tile_count_bounded", "gs_tile_emit_sort",
+    "gs_tile_workspace_ints", "gs_tile_count", "gs_tile_emit_sort",
     "gs_preprocess_workspace_ints", "gs_preprocess_forward", "gs_preprocess_backward",
     "gs_pack_splats", "gs_render_tiles", "gs_render_tiles_backward", "gs_render_depth",
 ]
@@ -43,6 +43,7 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.gs_last_error.restype = ctypes.c_char_p
         _lib.gs_preprocess_workspace_ints.restype = ctypes.c_size_t
+        _lib.gs_tile_workspace_ints.restype = ctypes.c_size_t
     return _lib
 
 

@@ -3,13 +3,23 @@
 // Replaces get_sorted_gaussian_list (tile_culling.cu:124-340).  The reference emits fp64 keys
 // z + (max_z+1)*tile in Gaussian order and runs one global torch::sort over all instances.  Here
 // the count pass already yields every tile's segment [tile_ranges[t], tile_ranges[t+1]), so
-//   1. k_tile_count    SAT test per (Gaussian, candidate tile); per-tile counters
-//   2. k_scan_tiles    exclusive prefix of the counters (one workgroup)
-//   3. k_tile_emit     same test; scatters key = (sortable z bits << 32 | gaussian) straight into
-//                      the tile's segment (counting sort on the tile digit)
-//   4. k_tile_sort     one workgroup per tile sorts its segment in LDS (bitonic network on unique
+//   1. k_bin_count     SAT test per (Gaussian, candidate tile).  Each of NB workgroups owns a
+//                      contiguous slice of the Gaussians and counts its hits per tile in an LDS
+//                      histogram (ds_add, no global atomics: device-scope atomics resolve at the
+//                      memory side at ~14 G/s chip-wide, which bounded the first version), then
+//                      stores the histogram as row b of hist[NB][T]
+//   2. k_bin_colscan   per tile: exclusive prefix over the NB workgroups (hist becomes each
+//                      workgroup's start offset inside the tile's segment) and the tile total
+//   3. k_scan_tiles    exclusive prefix of the tile totals (one workgroup) -> tile_ranges
+//   4. k_bin_emit      same slices, same test; LDS cursors start at ranges[t] + hist[b][t];
+//                      scatters key = (sortable z bits << 32 | gaussian) into the tile's segment
+//                      (a counting sort on the tile digit)
+//   5. k_tile_sort     one workgroup per tile sorts its segment in LDS (bitonic network on unique
 //                      64-bit keys -> deterministic) and writes the Gaussian indices.
-// HBM traffic: 20 B in per Gaussian per pass, 8 B out + 8 B in + 4 B out per instance.
+// Tile grids too large for an LDS histogram (T > 16384) fall back to global-atomic counters
+// (k_tile_count / k_tile_emit).
+// HBM traffic: 20 B in per Gaussian per pass, 8 B out + 8 B in + 4 B out per instance,
+// + 2 * NB * T * 4 B for the histogram matrix.
 //
 // The intersection test is bit-identical to the CPU restatement: fp32, no contraction, the same
 // operation order as tile_culling.cu:8-122, cos/sin of the OBB angle formed algebraically from
@@ -196,6 +206,51 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const int* __restrict__ cou
     }
 }
 
+// ---- privatized (LDS histogram) count / emit -----------------------------------------------------
+constexpr int PRIV_BLOCK = 512;
+constexpr int PRIV_MAX_TILES = 16384;   // 64 KiB of LDS
+constexpr int PRIV_NB = 512;            // workgroups (two per CU)
+
+__device__ inline void slice_of(int b, int V, int& g0, int& g1) {
+    const int chunk = (V + PRIV_NB - 1) / PRIV_NB;
+    g0 = min(V, b * chunk);
+    g1 = min(V, g0 + chunk);
+}
+
+__global__ __launch_bounds__(PRIV_BLOCK) void k_bin_count(const float* __restrict__ uvs,
+                                                          const float* __restrict__ conic, int V,
+                                                          int ntx, int nty, float mh, int row0,
+                                                          int row1, int* __restrict__ hist,
+                                                          const int* __restrict__ v_dev) {
+    extern __shared__ int s_hist[];
+    const int T = ntx * nty;
+    for (int t = threadIdx.x; t < T; t += PRIV_BLOCK) s_hist[t] = 0;
+    __syncthreads();
+    int g0, g1;
+    slice_of(blockIdx.x, v_dev ? *v_dev : V, g0, g1);
+    for (int g = g0 + threadIdx.x; g < g1; g += PRIV_BLOCK)
+        for_each_tile(uvs, conic, g, ntx, nty, mh, row0, row1,
+                      [&](int tile) { atomicAdd(&s_hist[tile], 1); });
+    __syncthreads();
+    int* row = hist + (size_t)blockIdx.x * T;
+    for (int t = threadIdx.x; t < T; t += PRIV_BLOCK) row[t] = s_hist[t];
+}
+
+// hist[b][t] <- sum_{b' < b} hist[b'][t];  counts[t] <- column total
+__global__ __launch_bounds__(256) void k_bin_colscan(int* __restrict__ hist, int T,
+                                                     int* __restrict__ counts) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    int run = 0;
+#pragma unroll 8
+    for (int b = 0; b < PRIV_NB; b++) {
+        const int h = hist[(size_t)b * T + t];
+        hist[(size_t)b * T + t] = run;
+        run += h;
+    }
+    counts[t] = run;
+}
+
 __device__ inline uint32_t sortable_bits(float z) {   // monotone float -> uint map
     const uint32_t u = __float_as_uint(z);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -204,14 +259,36 @@ __device__ inline uint32_t sortable_bits(float z) {   // monotone float -> uint 
 __global__ __launch_bounds__(BIN_BLOCK) void k_tile_emit(
     const float* __restrict__ uvs, const float* __restrict__ xyz_cam,
     const float* __restrict__ conic, int V, int ntx, int nty, float mh, int row0, int row1,
-    const int* __restrict__ ranges, int* __restrict__ cursor, uint64_t* __restrict__ keys) {
+    const int* __restrict__ ranges, int* __restrict__ cursor, uint64_t* __restrict__ keys,
+    const int* __restrict__ v_dev) {
     const int g = blockIdx.x * BIN_BLOCK + threadIdx.x;
-    if (g >= V) return;
+    if (g >= (v_dev ? *v_dev : V)) return;
     const uint64_t key = ((uint64_t)sortable_bits(xyz_cam[g * 3 + 2]) << 32) | (uint32_t)g;
     for_each_tile(uvs, conic, g, ntx, nty, mh, row0, row1, [&](int tile) {
         const int pos = ranges[tile] + atomicAdd(cursor + tile, 1);
         keys[pos] = key;
     });
+}
+
+__global__ __launch_bounds__(PRIV_BLOCK) void k_bin_emit(
+    const float* __restrict__ uvs, const float* __restrict__ xyz_cam,
+    const float* __restrict__ conic, int V, int ntx, int nty, float mh, int row0, int row1,
+    const int* __restrict__ ranges, const int* __restrict__ hist, uint64_t* __restrict__ keys,
+    const int* __restrict__ v_dev) {
+    extern __shared__ int s_cursor[];
+    const int T = ntx * nty;
+    const int* row = hist + (size_t)blockIdx.x * T;
+    for (int t = threadIdx.x; t < T; t += PRIV_BLOCK) s_cursor[t] = ranges[t] + row[t];
+    __syncthreads();
+    int g0, g1;
+    slice_of(blockIdx.x, v_dev ? *v_dev : V, g0, g1);
+    for (int g = g0 + threadIdx.x; g < g1; g += PRIV_BLOCK) {
+        const uint64_t key = ((uint64_t)sortable_bits(xyz_cam[g * 3 + 2]) << 32) | (uint32_t)g;
+        for_each_tile(uvs, conic, g, ntx, nty, mh, row0, row1, [&](int tile) {
+            const int pos = atomicAdd(&s_cursor[tile], 1);
+            keys[pos] = key;
+        });
+    }
 }
 
 // ---- per-tile sort -------------------------------------------------------------------------------
@@ -311,59 +388,72 @@ using namespace gs;
 
 extern "C" {
 
-static int tile_count_impl(const void* uvs, const void* conic, int V, int n_tiles_x, int n_tiles_y,
-                           float mh_dist, int tile_row0, int tile_row1, int32_t* tile_counts,
-                           int32_t* tile_ranges, const int32_t* v_dev, void* stream) {
+// LDS-histogram mode pays when there are many instances per tile; with few Gaussians the
+// NB x T histogram matrix costs more than the global atomics it saves.  The decision depends only
+// on (T, V) so that gs_tile_count and gs_tile_emit_sort agree.
+static bool use_private(int T, int V) {
+    return T <= PRIV_MAX_TILES && (int64_t)V * 8 > (int64_t)PRIV_NB * T;
+}
+
+size_t gs_tile_workspace_ints(int n_tiles) {
+    const size_t T = n_tiles > 0 ? (size_t)n_tiles : 1;
+    return T <= (size_t)PRIV_MAX_TILES ? T * (1 + (size_t)PRIV_NB) : T;
+}
+
+int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visible_count,
+                  int n_tiles_x, int n_tiles_y, float mh_dist, int tile_row0, int tile_row1,
+                  int32_t* workspace, int32_t* tile_ranges, void* stream) {
     GS_REQUIRE(n_tiles_x > 0 && n_tiles_y > 0, "tile grid must be positive");
     GS_REQUIRE(tile_row0 >= 0 && tile_row1 <= n_tiles_y && tile_row0 <= tile_row1,
                "bad tile row range");
     hipStream_t s = (hipStream_t)stream;
     const int T = n_tiles_x * n_tiles_y;
-    if (hipMemsetAsync(tile_counts, 0, sizeof(int) * (size_t)T, s) != hipSuccess) {
-        gs::set_error("tile_count: memset failed");
-        return GS_EHIP;
-    }
-    if (V > 0) {
-        k_tile_count<<<div_up(V, BIN_BLOCK), BIN_BLOCK, 0, s>>>(
+    int32_t* counts = workspace;
+    if (use_private(T, V)) {
+        int32_t* hist = workspace + T;
+        k_bin_count<<<PRIV_NB, PRIV_BLOCK, sizeof(int) * (size_t)T, s>>>(
             (const float*)uvs, (const float*)conic, V, n_tiles_x, n_tiles_y, mh_dist, tile_row0,
-            tile_row1, tile_counts, v_dev);
+            tile_row1, hist, visible_count);
+        k_bin_colscan<<<div_up(T, 256), 256, 0, s>>>(hist, T, counts);
+    } else {
+        if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)T, s) != hipSuccess) {
+            gs::set_error("tile_count: memset failed");
+            return GS_EHIP;
+        }
+        if (V > 0) {
+            k_tile_count<<<div_up(V, BIN_BLOCK), BIN_BLOCK, 0, s>>>(
+                (const float*)uvs, (const float*)conic, V, n_tiles_x, n_tiles_y, mh_dist,
+                tile_row0, tile_row1, counts, visible_count);
+        }
     }
-    k_scan_tiles<<<1, 1024, 0, s>>>(tile_counts, T, tile_ranges, v_dev);
+    k_scan_tiles<<<1, 1024, 0, s>>>(counts, T, tile_ranges, visible_count);
     return check_launch("tile_count");
 }
 
-int gs_tile_count(const void* uvs, const void* conic, int V, int n_tiles_x, int n_tiles_y,
-                  float mh_dist, int tile_row0, int tile_row1, int32_t* tile_counts,
-                  int32_t* tile_ranges, void* stream) {
-    return tile_count_impl(uvs, conic, V, n_tiles_x, n_tiles_y, mh_dist, tile_row0, tile_row1,
-                           tile_counts, tile_ranges, nullptr, stream);
-}
-
-int gs_tile_count_bounded(const void* uvs, const void* conic, int capacity,
-                          const int32_t* visible_count, int n_tiles_x, int n_tiles_y,
-                          float mh_dist, int tile_row0, int tile_row1, int32_t* tile_counts,
-                          int32_t* tile_ranges, void* stream) {
-    GS_REQUIRE(visible_count != nullptr, "visible_count must be a device pointer");
-    return tile_count_impl(uvs, conic, capacity, n_tiles_x, n_tiles_y, mh_dist, tile_row0,
-                           tile_row1, tile_counts, tile_ranges, visible_count, stream);
-}
-
 int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void* conic, int V,
-                      int n_tiles_x, int n_tiles_y, float mh_dist, int tile_row0, int tile_row1,
-                      const int32_t* tile_ranges, int32_t* tile_cursor, uint64_t* keys, int64_t S,
-                      int32_t* sorted_gaussians, void* stream) {
+                      const int32_t* visible_count, int n_tiles_x, int n_tiles_y, float mh_dist,
+                      int tile_row0, int tile_row1, const int32_t* tile_ranges, int32_t* workspace,
+                      uint64_t* keys, int64_t S, int32_t* sorted_gaussians, void* stream) {
     GS_REQUIRE(tile_row0 >= 0 && tile_row1 <= n_tiles_y && tile_row0 <= tile_row1,
                "bad tile row range");
     hipStream_t s = (hipStream_t)stream;
     const int T = n_tiles_x * n_tiles_y;
     if (S <= 0 || V <= 0) return GS_OK;
-    if (hipMemsetAsync(tile_cursor, 0, sizeof(int) * (size_t)T, s) != hipSuccess) {
-        gs::set_error("tile_emit_sort: memset failed");
-        return GS_EHIP;
+    if (use_private(T, V)) {
+        const int32_t* hist = workspace + T;
+        k_bin_emit<<<PRIV_NB, PRIV_BLOCK, sizeof(int) * (size_t)T, s>>>(
+            (const float*)uvs, (const float*)xyz_camera_frame, (const float*)conic, V, n_tiles_x,
+            n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, hist, keys, visible_count);
+    } else {
+        int32_t* cursor = workspace;
+        if (hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)T, s) != hipSuccess) {
+            gs::set_error("tile_emit_sort: memset failed");
+            return GS_EHIP;
+        }
+        k_tile_emit<<<div_up(V, BIN_BLOCK), BIN_BLOCK, 0, s>>>(
+            (const float*)uvs, (const float*)xyz_camera_frame, (const float*)conic, V, n_tiles_x,
+            n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, cursor, keys, visible_count);
     }
-    k_tile_emit<<<div_up(V, BIN_BLOCK), BIN_BLOCK, 0, s>>>(
-        (const float*)uvs, (const float*)xyz_camera_frame, (const float*)conic, V, n_tiles_x,
-        n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, tile_cursor, keys);
     const int t0 = tile_row0 * n_tiles_x;
     const int nt = (tile_row1 - tile_row0) * n_tiles_x;
     if (nt > 0) k_tile_sort<<<nt, SORT_BLOCK, 0, s>>>(tile_ranges, keys, sorted_gaussians, t0);

@@ -205,36 +205,21 @@ __global__ __launch_bounds__(PG_BLOCK) void k_sh_rgb_bwd(const T* __restrict__ x
     }
 }
 
-// render.cu:117-129 / render_backward.cu:141-152: the per-splat part of the per-pixel loop,
-// hoisted (identical values: it depends on the splat only)
 template <typename T>
 __global__ __launch_bounds__(PG_BLOCK) void k_pack(const T* __restrict__ uvs,
                                                    const T* __restrict__ opacity,
-                                                   const T* __restrict__ conic, int V,
+                                                   const T* __restrict__ conic,
+                                                   const T* __restrict__ rgb, int V,
                                                    T* __restrict__ packed) {
     const int i = blockIdx.x * PG_BLOCK + threadIdx.x;
     if (i >= V) return;
-    constexpr bool fast = sizeof(T) == 4;
-    T a, c;
-    const T b = conic[i * 3 + 1] * 0.5;
-    if (fast) {
-        a = conic[i * 3 + 0] + 0.25;
-        c = conic[i * 3 + 2] + 0.25;
-    } else {
-        a = conic[i * 3 + 0];
-        c = conic[i * 3 + 2];
-    }
-    const T det = a * c - b * b;
-    const T rdet = 1.0 / det;
-    T* p = packed + (size_t)i * GS_PACKED_WIDTH;
-    p[0] = uvs[i * 2 + 0];
-    p[1] = uvs[i * 2 + 1];
-    p[2] = a;
-    p[3] = b;
-    p[4] = c;
-    p[5] = det;
-    p[6] = rdet;
-    p[7] = opacity[i];
+    const T c3[3] = {conic[i * 3 + 0], conic[i * 3 + 1], conic[i * 3 + 2]};
+    T col[3] = {0, 0, 0};
+    if (rgb) { col[0] = rgb[i * 3 + 0]; col[1] = rgb[i * 3 + 1]; col[2] = rgb[i * 3 + 2]; }
+    T p[GS_PACKED_WIDTH];
+    pack_record<T>(uvs[i * 2 + 0], uvs[i * 2 + 1], c3, opacity[i], col, p);
+#pragma unroll
+    for (int k = 0; k < GS_PACKED_WIDTH; k++) packed[(size_t)i * GS_PACKED_WIDTH + k] = p[k];
 }
 
 template <typename F>
@@ -376,12 +361,12 @@ int gs_precompute_rgb_from_sh_backward(const void* xyz, const void* matrix, cons
     return GS_OK;
 }
 
-int gs_pack_splats(const void* uvs, const void* opacity, const void* conic, int V, void* packed,
-                   int dtype, void* stream) {
+int gs_pack_splats(const void* uvs, const void* opacity, const void* conic, const void* rgb, int V,
+                   void* packed, int dtype, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     DISPATCH_T(dtype, return launch1d(V, "pack_splats", [&](dim3 g, dim3 b) {
-                   k_pack<T><<<g, b, 0, s>>>((const T*)uvs, (const T*)opacity, (const T*)conic, V,
-                                             (T*)packed);
+                   k_pack<T><<<g, b, 0, s>>>((const T*)uvs, (const T*)opacity, (const T*)conic,
+                                             (const T*)rgb, V, (T*)packed);
                }));
 }
 

@@ -96,6 +96,53 @@ __device__ inline void view_dir_of(const T* __restrict__ xyz, const T* __restric
 }
 
 
+// Conservative squared cutoff radius of a splat for the fp32 alpha threshold (render.cu:145):
+// alpha >= 1/255  <=>  mh^2 <= tau = 2 ln(255 opacity), and mh^2 = d' S^-1 d >= |d|^2 / lmax(S),
+// so |d|^2 > tau * lmax  =>  alpha < 1/255.  The margin covers the rounding of the fp32
+// quadratic form (relative error ~ condition number * 2^-24) and of log/exp; parity tests against
+// the oracle (which evaluates every pixel) are bit-exact, so any non-conservative case would show.
+__device__ inline float cutoff_r2(float a, float b, float c, float det, float opa) {
+    if (!(det > 0.0f) || !(a > 0.0f) || !(c > 0.0f) || !(opa == opa)) return __builtin_inff();
+    const float s = opa * 255.0f * 1.001f;   // margin: opacity within rounding of 1/255
+    if (!(s > 1.0f)) return -1.0f;           // alpha <= opacity < 1/255 everywhere
+    const float tau = 2.0f * __builtin_logf(s);
+    const float half = 0.5f * (a + c);
+    const float lmax = half + __builtin_sqrtf(0.25f * (a - c) * (a - c) + b * b);
+    const float kappa = lmax * lmax / det;   // lmax / lmin
+    return tau * lmax * (1.05f + 8e-6f * kappa) + 1e-3f;
+}
+template <typename T> __device__ inline T cutoff_r2_t(T a, T b, T c, T det, T opa);
+template <> __device__ inline float cutoff_r2_t<float>(float a, float b, float c, float det, float opa) {
+    return cutoff_r2(a, b, c, det, opa);
+}
+template <> __device__ inline double cutoff_r2_t<double>(double, double, double, double, double) {
+    return (double)__builtin_inff();   // fp64 has no alpha threshold (render.cu:145: use_fast_exp)
+}
+
+// the packed render record (gs_pack_splats): the per-splat part of the per-pixel loop of
+// render.cu:117-129 / render_backward.cu:141-152, hoisted (identical values)
+template <typename T>
+__device__ inline void pack_record(T u, T v, const T* conic3, T opa, const T* col3, T* p) {
+    constexpr bool fast = sizeof(T) == 4;
+    T a, c;
+    const T b = conic3[1] * 0.5;
+    if (fast) {
+        a = conic3[0] + 0.25;
+        c = conic3[2] + 0.25;
+    } else {
+        a = conic3[0];
+        c = conic3[2];
+    }
+    const T det = a * c - b * b;
+    const T rdet = 1.0 / det;
+    p[0] = u; p[1] = v; p[2] = a; p[3] = b;
+    p[4] = c; p[5] = det; p[6] = rdet; p[7] = opa;
+    p[8] = cutoff_r2_t<T>(a, b, c, det, opa);
+    p[9] = col3 ? col3[0] : T(0);
+    p[10] = col3 ? col3[1] : T(0);
+    p[11] = col3 ? col3[2] : T(0);
+}
+
 // projection_backward.cu:174-315
 template <typename T>
 __device__ inline void sigma_world_bwd_of(const T* q4, const T* s3, const T* G, T* g_q4, T* g_s3) {

@@ -132,7 +132,7 @@ struct PreOut {
     float* opacity;   // [V,1]  sigmoid(logit)
     float* rgb;       // [V,3]  colour the renderer consumes
     float* xyz_cam;   // [V,3]
-    float* packed;    // [V,8]
+    float* packed;    // [V,12]
     int* vis_idx;     // [V]    visible -> Gaussian
     int* rank;        // [N]    Gaussian -> visible index or -1
     uint8_t* culled;  // [N]    culling mask (1 = culled), rasterize.py:33-49
@@ -215,15 +215,13 @@ __global__ __launch_bounds__(PP_BLOCK) void k_preprocess(
     o.rgb[v * 3 + 1] = col[1];
     o.rgb[v * 3 + 2] = col[2];
 
-    // packed render record, identical to k_pack (render.cu:117-129)
-    const float a = c3[0] + 0.25;
-    const float b = c3[1] * 0.5;
-    const float cc = c3[2] + 0.25;
-    const float det = a * cc - b * b;
-    const float rdet = 1.0 / det;
-    float4* pk = reinterpret_cast<float4*>(o.packed + (size_t)v * 8);
-    pk[0] = make_float4(uv[0], uv[1], a, b);
-    pk[1] = make_float4(cc, det, rdet, opa);
+    // packed render record, identical to k_pack
+    float pk[GS_PACKED_WIDTH];
+    pack_record<float>(uv[0], uv[1], c3, opa, col, pk);
+    float4* dst = reinterpret_cast<float4*>(o.packed + (size_t)v * GS_PACKED_WIDTH);
+    dst[0] = make_float4(pk[0], pk[1], pk[2], pk[3]);
+    dst[1] = make_float4(pk[4], pk[5], pk[6], pk[7]);
+    dst[2] = make_float4(pk[8], pk[9], pk[10], pk[11]);
 }
 
 struct PreGrad {

@@ -68,7 +68,8 @@ __device__ inline PixelMap pixel_of_thread(int tile_x, int tile_y, int tid) {
     return p;
 }
 
-// gather one chunk of splats into LDS.  idx_out (optional) keeps the Gaussian indices.
+// gather one chunk of splats into LDS: the 12-scalar packed record (three 16-byte loads) and, for
+// N_SH > 1, the [3, N_SH] colour coefficients.  s_idx (optional) keeps the Gaussian indices.
 template <typename T, int N_SH>
 __device__ inline void stage_chunk(const T* __restrict__ packed, const T* __restrict__ rgb,
                                    const int* __restrict__ sorted, int first, int count, int tid,
@@ -76,14 +77,31 @@ __device__ inline void stage_chunk(const T* __restrict__ packed, const T* __rest
     constexpr int CW = ColW<N_SH>::value;
     if (tid < count) {
         const int g = sorted[first + tid];
-        const Vec4<T>* src = reinterpret_cast<const Vec4<T>*>(packed + (size_t)g * 8);
-        Vec4<T>* dst = reinterpret_cast<Vec4<T>*>(s_geom + tid * 8);
+        const Vec4<T>* src = reinterpret_cast<const Vec4<T>*>(packed + (size_t)g * GS_PACKED_WIDTH);
+        Vec4<T>* dst = reinterpret_cast<Vec4<T>*>(s_geom + tid * GS_PACKED_WIDTH);
         dst[0] = src[0];
         dst[1] = src[1];
-        const T* c = rgb + (size_t)g * 3 * N_SH;
+        dst[2] = src[2];
+        if constexpr (N_SH > 1) {
+            const T* c = rgb + (size_t)g * 3 * N_SH;
 #pragma unroll
-        for (int k = 0; k < 3 * N_SH; k++) s_col[tid * CW + k] = c[k];
+            for (int k = 0; k < 3 * N_SH; k++) s_col[tid * CW + k] = c[k];
+        }
         if (s_idx) s_idx[tid] = g;
+    }
+}
+
+// colour of splat i of the staged chunk at this pixel's view direction
+template <typename T, int N_SH>
+__device__ inline void splat_colour(const T* s_geom, const T* s_col, int i, const T* Y, T* col) {
+    if constexpr (N_SH == 1) {
+        // sh_to_rgb with one coefficient per channel (spherical_harmonics.cuh:83)
+        const Vec4<T> g2 = *reinterpret_cast<const Vec4<T>*>(s_geom + i * GS_PACKED_WIDTH + 8);
+        col[0] = Y[0] * g2.y;
+        col[1] = Y[0] * g2.z;
+        col[2] = Y[0] * g2.w;
+    } else {
+        sh_to_rgb<T, N_SH>(s_col + i * ColW<N_SH>::value, Y, col);
     }
 }
 
@@ -99,8 +117,8 @@ __global__ __launch_bounds__(RB) void k_render_fwd(
     constexpr bool fast = sizeof(T) == 4;
     constexpr int CW = ColW<N_SH>::value;
     constexpr int RCHUNK = Chunk<T, N_SH>::value;
-    __shared__ alignas(16) T s_geom[RCHUNK * 8];
-    __shared__ alignas(16) T s_col[RCHUNK * CW];
+    __shared__ alignas(16) T s_geom[RCHUNK * GS_PACKED_WIDTH];
+    __shared__ alignas(16) T s_col[N_SH > 1 ? RCHUNK * CW : 4];
 
     const int t_local = tile_of_block(blockIdx.x, nt);
     if (t_local >= nt) return;
@@ -139,19 +157,22 @@ __global__ __launch_bounds__(RB) void k_render_fwd(
                 if (acc > Thr<T>::sat_gt()) {   // render.cu:106
                     done = true;
                 } else {
-                    const Vec4<T> g0 = *reinterpret_cast<const Vec4<T>*>(s_geom + i * 8);
-                    const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(s_geom + i * 8 + 4);
+                    const T* rec = s_geom + i * GS_PACKED_WIDTH;
+                    const Vec4<T> g0 = *reinterpret_cast<const Vec4<T>*>(rec);
                     const T du = pu - g0.x, dv = pv - g0.y;
+                    nsp++;
+                    // beyond the cutoff radius alpha < 1/255 is certain: same outcome as :145-148
+                    if (fast && du * du + dv * dv > rec[8]) continue;
+                    const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(rec + 4);
                     const T a = g0.z, b = g0.w, c = g1.x, det = g1.y, opa = g1.w;
                     const T mh = (c * du * du - (b + b) * du * dv + a * dv * dv) / det;
                     T alpha = 0;
                     if (mh > T(0)) alpha = opa * gexp<T>(T(-0.5) * mh);
-                    nsp++;
                     if (!(fast && alpha < Thr<T>::alpha_min())) {   // render.cu:145
                         fw = 1.0 - acc;
                         const T weight = alpha * (1.0 - acc);       // double, narrowed
                         T col[3];
-                        sh_to_rgb<T, N_SH>(s_col + i * CW, Y, col);
+                        splat_colour<T, N_SH>(s_geom, s_col, i, Y, col);
 #pragma unroll
                         for (int ch = 0; ch < 3; ch++) img[ch] += col[ch] * weight;
                         acc += weight;
@@ -223,8 +244,8 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
     constexpr int NV = C + 6;   // rgb coeffs, opacity, u, v, conic x3
     constexpr int REF_CH = ref_chunk<T>(N_SH);
     constexpr int RCHUNK = Chunk<T, N_SH>::value;
-    __shared__ alignas(16) T s_geom[RCHUNK * 8];
-    __shared__ alignas(16) T s_col[RCHUNK * CW];
+    __shared__ alignas(16) T s_geom[RCHUNK * GS_PACKED_WIDTH];
+    __shared__ alignas(16) T s_col[N_SH > 1 ? RCHUNK * CW : 4];
     __shared__ int s_idx[RCHUNK];
     __shared__ T s_acc[RCHUNK * NV];
     __shared__ int s_max[4];
@@ -291,16 +312,19 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
             for (int j = 0; j < NV; j++) val[j] = 0;
             bool contrib = false;
             if (reach) {
-                const Vec4<T> g0 = *reinterpret_cast<const Vec4<T>*>(s_geom + i * 8);
-                const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(s_geom + i * 8 + 4);
+                const T* rec = s_geom + i * GS_PACKED_WIDTH;
+                const Vec4<T> g0 = *reinterpret_cast<const Vec4<T>*>(rec);
+                const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(rec + 4);
                 const T du = pu - g0.x, dv = pv - g0.y;
                 const T a = g0.z, b = g0.w, c = g1.x, rdet = g1.z, opa = g1.w;
-                // render_backward.cu:153-165 (multiplies by 1/det; forward divides)
-                const T mh = (c * du * du - (b + b) * du * dv + a * dv * dv) * rdet;
-                T norm_prob = 0;
-                if (mh > T(0)) norm_prob = gexp<T>(T(-0.5) * mh);
-                T alpha = opa * norm_prob;
-                if (alpha > Thr<T>::sat_gt()) alpha = Thr<T>::alpha_cap();   // min(0.9999, .)
+                T norm_prob = 0, alpha = 0;
+                if (!(fast && du * du + dv * dv > rec[8])) {   // inside the cutoff radius
+                    // render_backward.cu:153-165 (multiplies by 1/det; forward divides)
+                    const T mh = (c * du * du - (b + b) * du * dv + a * dv * dv) * rdet;
+                    if (mh > T(0)) norm_prob = gexp<T>(T(-0.5) * mh);
+                    alpha = opa * norm_prob;
+                    if (alpha > Thr<T>::sat_gt()) alpha = Thr<T>::alpha_cap();   // min(0.9999, .)
+                }
                 if (!fast || alpha >= Thr<T>::alpha_min()) {
                     contrib = true;
                     if (!bg_init) {   // render_backward.cu:172-181
@@ -315,7 +339,7 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
                     const T r1ma = 1.0 / (1.0 - alpha);
                     if ((k % REF_CH) < nsp - 1) weight = weight * r1ma;   // Q1 (chunk-local index)
                     T col[3];
-                    sh_to_rgb<T, N_SH>(s_col + i * CW, Y, col);
+                    splat_colour<T, N_SH>(s_geom, s_col, i, Y, col);
                     T grad_alpha = 0;
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
@@ -377,7 +401,7 @@ __global__ __launch_bounds__(RB) void k_render_depth(const float* __restrict__ p
                                                      int ntx, int nt, float alpha_threshold,
                                                      float* __restrict__ depth) {
     constexpr int RCHUNK = 256;
-    __shared__ alignas(16) float s_geom[RCHUNK * 8];
+    __shared__ alignas(16) float s_geom[RCHUNK * GS_PACKED_WIDTH];
     __shared__ int s_idx[RCHUNK];
     const int tile = tile_of_block(blockIdx.x, nt);
     if (tile >= nt) return;
@@ -393,8 +417,9 @@ __global__ __launch_bounds__(RB) void k_render_depth(const float* __restrict__ p
         const int cnt = min(RCHUNK, n_tile - base);
         if (tid < cnt) {
             const int g = sorted[s0 + base + tid];
-            const Vec4<float>* src = reinterpret_cast<const Vec4<float>*>(packed + (size_t)g * 8);
-            Vec4<float>* dst = reinterpret_cast<Vec4<float>*>(s_geom + tid * 8);
+            const Vec4<float>* src =
+                reinterpret_cast<const Vec4<float>*>(packed + (size_t)g * GS_PACKED_WIDTH);
+            Vec4<float>* dst = reinterpret_cast<Vec4<float>*>(s_geom + tid * GS_PACKED_WIDTH);
             dst[0] = src[0];
             dst[1] = src[1];
             s_idx[tid] = g;
@@ -403,8 +428,10 @@ __global__ __launch_bounds__(RB) void k_render_depth(const float* __restrict__ p
         for (int i = 0; i < cnt; i++) {
             if (__ballot(!done) == 0) break;
             if (!done) {
-                const Vec4<float> g0 = *reinterpret_cast<const Vec4<float>*>(s_geom + i * 8);
-                const Vec4<float> g1 = *reinterpret_cast<const Vec4<float>*>(s_geom + i * 8 + 4);
+                const Vec4<float> g0 =
+                    *reinterpret_cast<const Vec4<float>*>(s_geom + i * GS_PACKED_WIDTH);
+                const Vec4<float> g1 =
+                    *reinterpret_cast<const Vec4<float>*>(s_geom + i * GS_PACKED_WIDTH + 4);
                 const float du = pu - g0.x, dv = pv - g0.y;
                 const float a = g0.z, b = g0.w, c = g1.x, det = g1.y, opa = g1.w;
                 const float mh = (c * du * du - (b + b) * du * dv + a * dv * dv) / det;

@@ -61,21 +61,21 @@ class _Preprocess(torch.autograd.Function):
         conic = torch.empty(N, 3, **f32)
         opacity_act = torch.empty(N, 1, **f32)
         rgb_render = torch.empty(N, 3, **f32)
-        packed = torch.empty(N, 8, **f32)
+        packed = torch.empty(N, 12, **f32)
         _hip.call("gs_preprocess_forward", _p(xyz), _p(quaternion), _p(scale), _p(opacity), _p(rgb), _p(sh), n_sh,
                   _p(camera_T_world), _p(K), N, width, height, _cf(near_thresh), _cf(far_thresh),
                   _cf(cull_mask_padding), _p(ws), _p(center), _p(count), _p(culling_mask), _p(rank), _p(vis_idx), _p(uv),
                   _p(xyz_cam), _p(conic), _p(opacity_act), _p(rgb_render), _p(packed), _stream())
 
-        tile_counts = torch.empty(T, **i32)
+        tile_counts = torch.empty(_hip.lib().gs_tile_workspace_ints(T), **i32)
         ranges = torch.empty(T + 2, **i32)
-        _hip.call("gs_tile_count_bounded", _p(uv), _p(conic), N, _p(count), ntx, nty, _cf(mh_dist), row0, row1,
+        _hip.call("gs_tile_count", _p(uv), _p(conic), N, _p(count), ntx, nty, _cf(mh_dist), row0, row1,
                   _p(tile_counts), _p(ranges), _stream())
         S, V = ranges[T:T + 2].tolist()   # the frame's only device->host read
         sorted_g = torch.empty(S, **i32)
         if S > 0:
             keys = torch.empty(S, dtype=torch.int64, device=dev)
-            _hip.call("gs_tile_emit_sort", _p(uv), _p(xyz_cam), _p(conic), V, ntx, nty, _cf(mh_dist), row0, row1,
+            _hip.call("gs_tile_emit_sort", _p(uv), _p(xyz_cam), _p(conic), N, _p(count), ntx, nty, _cf(mh_dist), row0, row1,
                       _p(ranges), _p(tile_counts), _p(keys), ctypes.c_int64(S), _p(sorted_g), _stream())
 
         ctx.save_for_backward(xyz, quaternion, scale, camera_T_world, K, center, rank, opacity_act)

@@ -209,26 +209,27 @@ def get_sorted_gaussian_list(max_tiles_per_gaussian, uvs, xyz_camera_frame, coni
     T = int(n_tiles_x) * int(n_tiles_y)
     row0, row1 = tile_rows if tile_rows is not None else (0, int(n_tiles_y))
     dev = uvs.device
-    counts = torch.empty(T, dtype=torch.int32, device=dev)
+    counts = torch.empty(_hip.lib().gs_tile_workspace_ints(T), dtype=torch.int32, device=dev)
     ranges = torch.empty(T + 1, dtype=torch.int32, device=dev)
     mh = ctypes.c_float(mh_dist)
-    _hip.call("gs_tile_count", _p(uvs), _p(conic), V, int(n_tiles_x), int(n_tiles_y), mh, row0, row1, _p(counts),
+    _hip.call("gs_tile_count", _p(uvs), _p(conic), V, None, int(n_tiles_x), int(n_tiles_y), mh, row0, row1, _p(counts),
                           _p(ranges), _stream())
     S = int(ranges[T].item())   # the one host read: sizes the result
     sorted_g = torch.empty(S, dtype=torch.int32, device=dev)
     if S > 0:
         keys = torch.empty(S, dtype=torch.int64, device=dev)
-        _hip.call("gs_tile_emit_sort", _p(uvs), _p(xyz_camera_frame), _p(conic), V, int(n_tiles_x), int(n_tiles_y), mh,
+        _hip.call("gs_tile_emit_sort", _p(uvs), _p(xyz_camera_frame), _p(conic), V, None, int(n_tiles_x), int(n_tiles_y), mh,
                                   row0, row1, _p(ranges), _p(counts), _p(keys), ctypes.c_int64(S), _p(sorted_g),
                                   _stream())
     return sorted_g, ranges
 
 
 # ---- render.cu / render_backward.cu / depth.cu --------------------------------------------------------------
-def _pack(uvs, opacity, conic, dt):
+def _pack(uvs, opacity, conic, dt, rgb=None):
     V = uvs.shape[0]
-    packed = torch.empty(V, 8, dtype=uvs.dtype, device=uvs.device)
-    _hip.call("gs_pack_splats", _p(uvs), _p(opacity), _p(conic), V, _p(packed), dt, _stream())
+    packed = torch.empty(V, 12, dtype=uvs.dtype, device=uvs.device)
+    col = _p(rgb) if (rgb is not None and _n_sh(rgb) == 1) else None
+    _hip.call("gs_pack_splats", _p(uvs), _p(opacity), _p(conic), col, V, _p(packed), dt, _stream())
     return packed
 
 
@@ -269,7 +270,7 @@ def render_tiles_cuda(uvs, opacity, rgb, conic, view_dir_by_pixel, splat_start_e
     _require(splat_start_end_idx_by_tile_idx.shape[0] == ((W + 15) // 16) * nty + 1,
              "splat_start_end_idx_by_tile_idx must have n_tiles + 1 entries")
     row0, row1 = tile_rows if tile_rows is not None else (0, nty)
-    packed = _pack(uvs, opacity, conic, dt)
+    packed = _pack(uvs, opacity, conic, dt, rgb)
     _hip.call("gs_render_tiles", _p(packed), _p(rgb), _p(view_dir_by_pixel), _p(splat_start_end_idx_by_tile_idx),
                                      _p(gaussian_idx_by_splat_idx), _p(background_rgb), W, H, n_sh, row0, row1,
                                      _p(num_splats_per_pixel), _p(final_weight_per_pixel), _p(rendered_image), dt,
@@ -305,7 +306,7 @@ def render_tiles_backward_cuda(uvs, opacity, rgb, conic, view_dir_by_pixel, spla
     _int(splat_start_end_idx_by_tile_idx=splat_start_end_idx_by_tile_idx,
          gaussian_idx_by_splat_idx=gaussian_idx_by_splat_idx, num_splats_per_pixel=num_splats_per_pixel)
     row0, row1 = tile_rows if tile_rows is not None else (0, nty)
-    packed = _pack(uvs, opacity, conic, dt)
+    packed = _pack(uvs, opacity, conic, dt, rgb)
     _hip.call("gs_render_tiles_backward", 
         _p(packed), _p(rgb), _p(view_dir_by_pixel), _p(splat_start_end_idx_by_tile_idx),
         _p(gaussian_idx_by_splat_idx), _p(background_rgb), _p(num_splats_per_pixel), _p(final_weight_per_pixel),

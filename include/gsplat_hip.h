@@ -32,7 +32,7 @@ extern "C" {
 #define GS_EHIP (-2)     /* a HIP runtime call or kernel launch failed */
 
 #define GS_TILE 16       /* tile edge in pixels (splat_py/structs.py:4) */
-#define GS_PACKED_WIDTH 8 /* scalars per packed splat record, see gs_pack_splats */
+#define GS_PACKED_WIDTH 12 /* scalars per packed splat record, see gs_pack_splats */
 
 const char* gs_last_error(void);
 int gs_abi_version(void);
@@ -94,21 +94,21 @@ int gs_precompute_rgb_from_sh_backward(const void* xyz, const void* matrix, cons
  *                      Gaussian index.
  *
  * uvs[V,2], xyz_camera_frame[V,3], conic[V,3]; n_tiles = n_tiles_x*n_tiles_y.
- * tile_cursor: int32[n_tiles] scratch; keys: uint64[S] scratch. */
-int gs_tile_count(const void* uvs, const void* conic, int V, int n_tiles_x, int n_tiles_y,
-                  float mh_dist, int tile_row0, int tile_row1, int32_t* tile_counts /*[T]*/,
-                  int32_t* tile_ranges /*[T+1]*/, void* stream);
-/* Same as gs_tile_count for the fused path, where the number of visible Gaussians V lives on the
- * device (gs_preprocess_forward): rows >= *visible_count of the capacity-sized inputs are
- * ignored.  tile_ranges has T+2 entries: [T] = S, [T+1] = V, so one 8-byte read returns both. */
-int gs_tile_count_bounded(const void* uvs, const void* conic, int capacity,
-                          const int32_t* visible_count, int n_tiles_x, int n_tiles_y,
-                          float mh_dist, int tile_row0, int tile_row1, int32_t* tile_counts /*[T]*/,
-                          int32_t* tile_ranges /*[T+2]*/, void* stream);
+ * visible_count: NULL, or a device pointer to the number of valid rows when the inputs are
+ *   capacity-V buffers whose fill level only the device knows (gs_preprocess_forward); rows
+ *   beyond it are ignored and tile_ranges then has T+2 entries, [T+1] = *visible_count, so that
+ *   one 8-byte read returns S and V.  Pass the same V and visible_count to both calls.
+ * workspace: int32[gs_tile_workspace_ints(n_tiles)] scratch written by step 1 and read by step 2
+ *   (per-workgroup tile histograms; keep it untouched between the two calls);
+ * keys: uint64[S] scratch. */
+size_t gs_tile_workspace_ints(int n_tiles);
+int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visible_count,
+                  int n_tiles_x, int n_tiles_y, float mh_dist, int tile_row0, int tile_row1,
+                  int32_t* workspace, int32_t* tile_ranges /*[T+1] or [T+2]*/, void* stream);
 int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void* conic, int V,
-                      int n_tiles_x, int n_tiles_y, float mh_dist, int tile_row0, int tile_row1,
-                      const int32_t* tile_ranges, int32_t* tile_cursor, uint64_t* keys, int64_t S,
-                      int32_t* sorted_gaussians /*[S]*/, void* stream);
+                      const int32_t* visible_count, int n_tiles_x, int n_tiles_y, float mh_dist,
+                      int tile_row0, int tile_row1, const int32_t* tile_ranges, int32_t* workspace,
+                      uint64_t* keys, int64_t S, int32_t* sorted_gaussians /*[S]*/, void* stream);
 
 /* ---- fused per-Gaussian stage (fp32) ----------------------------------------------------------------
  * One pass replacing the PyTorch glue and per-Gaussian kernels of rasterize()
@@ -122,7 +122,7 @@ int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void*
  *   outputs  camera_center[3]; visible_count[1] (= V, on the device); culling_mask uint8[N]
  *            (1 = culled); rank int32[N] (visible index or -1); and, with capacity N rows of which
  *            the first V are written: vis_idx int32, uv[.,2], xyz_camera_frame[.,3], conic[.,3],
- *            opacity_act[.,1] = sigmoid, rgb_render[.,3], packed[.,8] (see gs_pack_splats). */
+ *            opacity_act[.,1] = sigmoid, rgb_render[.,3], packed[.,12] (see gs_pack_splats). */
 size_t gs_preprocess_workspace_ints(int N);
 int gs_preprocess_forward(const void* xyz, const void* quaternion, const void* scale,
                           const void* opacity, const void* rgb, const void* sh, int n_sh,
@@ -147,11 +147,16 @@ int gs_preprocess_backward(const void* xyz, const void* quaternion, const void* 
                            void* stream);
 
 /* ---- tile renderer ---------------------------------------------------------------------------- */
-/* Packs the per-splat geometry the render kernels read into one record per visible Gaussian:
- *   packed[V][8] = (u, v, a, b, c, det, 1/det, opacity), a/b/c as render.cu:117-128 forms them
- *   (+0.25 dilation for fp32, none for fp64).  uvs[V,2], opacity[V,1], conic[V,3]. */
-int gs_pack_splats(const void* uvs, const void* opacity, const void* conic, int V, void* packed,
-                   int dtype, void* stream);
+/* Packs what the render kernels read per splat into one 48-byte (fp32) record per visible Gaussian:
+ *   packed[V][12] = (u, v, a, b | c, det, 1/det, opacity | r2, col0, col1, col2)
+ * a/b/c as render.cu:117-128 forms them (+0.25 dilation for fp32, none for fp64); r2 is a
+ * conservative squared cutoff radius: a pixel farther than sqrt(r2) from (u, v) provably has
+ * alpha < 1/255 and is skipped exactly as render.cu:145-148 would skip it (+inf for fp64, which
+ * has no alpha threshold); col = rgb[V,3] when rgb is given with n_sh == 1 (else unused: the
+ * kernels then gather the [3, n_sh] coefficients from `rgb` directly).
+ * uvs[V,2], opacity[V,1], conic[V,3], rgb[V,3] or NULL. */
+int gs_pack_splats(const void* uvs, const void* opacity, const void* conic, const void* rgb, int V,
+                   void* packed, int dtype, void* stream);
 /* render_tiles_cuda (bindings.cpp:119; render.cu:8-422).  rgb[V,3,n_sh]; view_dir_by_pixel[H,W,3]
  * (ignored when n_sh==1); background_rgb[3] -> num_splats_per_pixel int32[H,W],
  * final_weight_per_pixel[H,W], image[H,W,3].  `packed` comes from gs_pack_splats. */
