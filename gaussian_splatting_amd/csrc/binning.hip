@@ -14,8 +14,9 @@
 //   4. k_bin_emit      same slices, same test; LDS cursors start at ranges[t] + hist[b][t];
 //                      scatters key = (sortable z bits << 32 | gaussian) into the tile's segment
 //                      (a counting sort on the tile digit)
-//   5. k_tile_sort     one workgroup per tile sorts its segment in LDS (bitonic network on unique
-//                      64-bit keys -> deterministic) and writes the Gaussian indices.
+//   5. k_tile_sort_*   one workgroup per tile sorts its segment in LDS (register-blocked bitonic
+//                      network on unique 64-bit keys -> deterministic) and writes the Gaussian
+//                      indices; see "per-tile sort" below.
 // Tile grids too large for an LDS histogram (T > 16384) fall back to global-atomic counters
 // (k_tile_count / k_tile_emit).
 // HBM traffic: 20 B in per Gaussian per pass, 8 B out + 8 B in + 4 B out per instance,
@@ -292,94 +293,216 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_emit(
 }
 
 // ---- per-tile sort -------------------------------------------------------------------------------
+// Bitonic network in its all-ascending form on the tile's unique 64-bit keys: phase k starts with
+// a "flip" step (element i of a k-block against element k-1-i) followed by half-cleaners of stride
+// j = k/4 .. 1.  Every comparator puts the smaller key at the lower index, so the +inf padding at
+// indices >= n never moves and stays virtual.
+//
+// Register blocking: a thread owns SORT_R = 16 consecutive elements.  All phases with k <= 16 and
+// the half-cleaners with j < 16 of every later phase run in registers (one LDS round trip for 16
+// elements, 32-80 compare-exchanges in between); only the flip and the j >= 16 half-cleaners of
+// the phases k >= 32 go through LDS pair-wise.  For a 4096-key tile that is 36 pair steps + 9
+// register passes instead of 78 pair steps, and the small strides that bank-conflict in a
+// pair-wise step never touch LDS.  Element i lives at LDS slot i + i/16 (one pad slot per block),
+// which makes the 16-element block reads conflict-free (lane stride 34 banks).
+//
+// Size classes (separate launches, a workgroup whose tile is in another class exits at once) keep
+// LDS per workgroup -- and with it the number of resident workgroups per CU -- matched to the tile:
+//   n <= 1024: 8.5 KiB    n <= 4096: 34 KiB    n <= 8192: 68 KiB    larger: pair-wise on global memory.
 constexpr int SORT_BLOCK = 256;
-constexpr int SORT_LDS_KEYS = 8192;   // 64 KiB of LDS: two workgroups per CU
+constexpr int SORT_R = 16;
+constexpr int SORT_MAX_LDS_KEYS = 8192;
 
-// Bitonic network in its all-ascending form: phase k starts with a "flip" step (element i of a
-// k-block against element k-1-i) followed by half-cleaners of stride j = k/4 .. 1.  Every
-// comparator puts the smaller key at the lower index, so +inf padding at indices >= n never
-// moves and can stay virtual.  Pair index p touches only elements [128*(p/64), 128*(p/64)+127]
-// in a flip with k <= 128 or a half-cleaner with j <= 64: such steps need wave-level ordering
-// only.
-__device__ inline bool step_is_wide(int k, int j) { return j == 0 ? k > 128 : j > 64; }
+__device__ inline int slot(int i) { return i + (i >> 4); }
 
-template <typename Mem>
-__device__ inline void bitonic_step(Mem s, int n, int n_pad, int k, int j, int tid) {
-    for (int p = tid; p < (n_pad >> 1); p += SORT_BLOCK) {
-        int lo, hi;
-        if (j == 0) {   // flip
-            const int h = k >> 1;
+#define GS_CE(x, y)                                                                                \
+    do {                                                                                           \
+        const uint64_t _a = (x), _b = (y);                                                         \
+        const bool _sw = _a > _b;                                                                  \
+        (x) = _sw ? _b : _a;                                                                       \
+        (y) = _sw ? _a : _b;                                                                       \
+    } while (0)
+
+// half-cleaners of stride J, J/2, ..., 1 on 16 registers
+template <int J>
+__device__ inline void reg_half_cleaners(uint64_t (&v)[SORT_R]) {
+#pragma unroll
+    for (int j = J; j > 0; j >>= 1) {
+#pragma unroll
+        for (int p = 0; p < SORT_R / 2; p++) {
+            const int lo = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+            GS_CE(v[lo], v[lo + j]);
+        }
+    }
+}
+
+// all phases k = 2 .. 16 on 16 registers
+__device__ inline void reg_sort16(uint64_t (&v)[SORT_R]) {
+#pragma unroll
+    for (int k = 2; k <= SORT_R; k <<= 1) {
+        const int h = k >> 1;
+#pragma unroll
+        for (int p = 0; p < SORT_R / 2; p++) {   // flip
             const int blk = p / h, off = p & (h - 1);
-            lo = blk * k + off;
-            hi = blk * k + (k - 1 - off);
-        } else {
-            lo = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-            hi = lo + j;
+            GS_CE(v[blk * k + off], v[blk * k + (k - 1 - off)]);
         }
-        if (hi >= n) continue;   // partner is virtual +inf: already ordered
-        const uint64_t a = s[lo], b = s[hi];
-        if (a > b) {
-            s[lo] = b;
-            s[hi] = a;
-        }
-    }
-}
-
-template <typename Mem>
-__device__ inline void bitonic_sort(Mem s, int n, int n_pad, int tid) {
-    for (int k = 2; k <= n_pad; k <<= 1) {
-        // steps of this phase: j = 0 (flip), k/4, k/8, ..., 1
-        int j = 0;
-        while (true) {
-            bitonic_step(s, n, n_pad, k, j, tid);
-            const int nj = (j == 0) ? (k >> 2) : (j >> 1);
-            const bool last = nj == 0;
-            // next step: nj within this phase, or the flip of phase 2k
-            const bool next_wide = last ? ((k << 1) <= n_pad && step_is_wide(k << 1, 0))
-                                        : step_is_wide(k, nj);
-            if (step_is_wide(k, j) || next_wide) {
-                __threadfence_block();
-                __syncthreads();
-            } else {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = k >> 2; j > 0; j >>= 1) {
+#pragma unroll
+            for (int p = 0; p < SORT_R / 2; p++) {
+                const int lo = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                GS_CE(v[lo], v[lo + j]);
             }
-            if (last) break;
-            j = nj;
         }
     }
-    __threadfence_block();
-    __syncthreads();
 }
 
-__global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort(const int* __restrict__ ranges,
-                                                          uint64_t* __restrict__ keys,
-                                                          int* __restrict__ sorted, int tile0) {
-    __shared__ uint64_t s_keys[SORT_LDS_KEYS];
+template <bool FULL_SORT>
+__device__ inline void register_pass(uint64_t* s, int n, int n_pad, int tid) {
+    for (int blk = tid; blk < (n_pad >> 4); blk += SORT_BLOCK) {
+        const int base = blk << 4;
+        if (base >= n) continue;   // an all-padding block is already in order
+        uint64_t v[SORT_R];
+        const int sb = slot(base);
+#pragma unroll
+        for (int e = 0; e < SORT_R; e++) v[e] = (base + e < n) ? s[sb + e] : ~0ull;
+        if (FULL_SORT) reg_sort16(v);
+        else reg_half_cleaners<SORT_R / 2>(v);
+#pragma unroll
+        for (int e = 0; e < SORT_R; e++)
+            if (base + e < n) s[sb + e] = v[e];
+    }
+}
+
+// one pair-wise step on LDS (flip when j == 0), four pairs in flight per thread
+__device__ inline void pair_step_lds(uint64_t* s, int n, int n_pad, int k, int j, int tid) {
+    const int pairs = n_pad >> 1;
+    for (int p0 = tid; p0 < pairs; p0 += 4 * SORT_BLOCK) {
+        int lo[4], hi[4];
+        uint64_t a[4], b[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int p = p0 + u * SORT_BLOCK;
+            if (j == 0) {
+                const int h = k >> 1;
+                const int blk = p / h, off = p & (h - 1);
+                lo[u] = blk * k + off;
+                hi[u] = blk * k + (k - 1 - off);
+            } else {
+                lo[u] = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                hi[u] = lo[u] + j;
+            }
+            ok[u] = p < pairs && hi[u] < n;
+            if (ok[u]) {
+                a[u] = s[slot(lo[u])];
+                b[u] = s[slot(hi[u])];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (ok[u] && a[u] > b[u]) {
+                s[slot(lo[u])] = b[u];
+                s[slot(hi[u])] = a[u];
+            }
+        }
+    }
+}
+
+template <int CAP_LO, int CAP_HI>
+__global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_lds(const int* __restrict__ ranges,
+                                                              const uint64_t* __restrict__ keys,
+                                                              int* __restrict__ sorted, int tile0) {
+    extern __shared__ uint64_t s_keys[];
     const int tile = tile0 + blockIdx.x;
     const int s0 = ranges[tile];
     const int n = ranges[tile + 1] - s0;
+    if (n <= CAP_LO || n > CAP_HI) return;
     const int tid = threadIdx.x;
-    if (n <= 0) return;
     if (n == 1) {
         if (tid == 0) sorted[s0] = (int)(uint32_t)keys[s0];
         return;
     }
+    int n_pad = SORT_R;
+    while (n_pad < n) n_pad <<= 1;
+    for (int i = tid; i < n; i += SORT_BLOCK) s_keys[slot(i)] = keys[s0 + i];
+    __syncthreads();
+    register_pass<true>(s_keys, n, n_pad, tid);
+    __syncthreads();
+    for (int k = 2 * SORT_R; k <= n_pad; k <<= 1) {
+        pair_step_lds(s_keys, n, n_pad, k, 0, tid);
+        __syncthreads();
+        for (int j = k >> 2; j >= SORT_R; j >>= 1) {
+            pair_step_lds(s_keys, n, n_pad, k, j, tid);
+            __syncthreads();
+        }
+        register_pass<false>(s_keys, n, n_pad, tid);
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += SORT_BLOCK) sorted[s0 + i] = (int)(uint32_t)s_keys[slot(i)];
+}
+
+// oversize tile: the pair-wise network directly on the tile's global segment (one workgroup, so
+// workgroup-scope ordering suffices)
+__global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_global(const int* __restrict__ ranges,
+                                                                 uint64_t* __restrict__ keys,
+                                                                 int* __restrict__ sorted,
+                                                                 int tile0) {
+    const int tile = tile0 + blockIdx.x;
+    const int s0 = ranges[tile];
+    const int n = ranges[tile + 1] - s0;
+    if (n <= SORT_MAX_LDS_KEYS) return;
+    const int tid = threadIdx.x;
+    uint64_t* gk = keys + s0;
     int n_pad = 2;
     while (n_pad < n) n_pad <<= 1;
-    if (n <= SORT_LDS_KEYS) {
-        for (int i = tid; i < n; i += SORT_BLOCK) s_keys[i] = keys[s0 + i];
-        __syncthreads();
-        bitonic_sort(s_keys, n, n_pad, tid);
-        for (int i = tid; i < n; i += SORT_BLOCK) sorted[s0 + i] = (int)(uint32_t)s_keys[i];
-    } else {
-        // oversize tile: the same network directly on the tile's global segment (one workgroup,
-        // so workgroup-scope ordering suffices)
-        uint64_t* gk = keys + s0;
-        bitonic_sort(gk, n, n_pad, tid);
-        for (int i = tid; i < n; i += SORT_BLOCK) sorted[s0 + i] = (int)(uint32_t)gk[i];
+    for (int k = 2; k <= n_pad; k <<= 1) {
+        for (int j = 0, first = 1; first || j > 0; first = 0) {
+            for (int p = tid; p < (n_pad >> 1); p += SORT_BLOCK) {
+                int lo, hi;
+                if (j == 0) {
+                    const int h = k >> 1;
+                    const int blk = p / h, off = p & (h - 1);
+                    lo = blk * k + off;
+                    hi = blk * k + (k - 1 - off);
+                } else {
+                    lo = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                    hi = lo + j;
+                }
+                if (hi >= n) continue;
+                const uint64_t a = gk[lo], b = gk[hi];
+                if (a > b) {
+                    gk[lo] = b;
+                    gk[hi] = a;
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            j = (j == 0) ? (k >> 2) : (j >> 1);
+        }
     }
+    for (int i = tid; i < n; i += SORT_BLOCK) sorted[s0 + i] = (int)(uint32_t)gk[i];
+}
+
+static int launch_tile_sort(const int* ranges, uint64_t* keys, int* sorted, int tile0, int nt,
+                            int64_t S, hipStream_t s) {
+    if (nt <= 0) return GS_OK;
+    auto lds_bytes = [](int cap) { return (size_t)(cap + cap / SORT_R) * sizeof(uint64_t); };
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_tile_sort_lds<4096, 8192>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(8192));
+        attr_set = true;
+    }
+    k_tile_sort_lds<0, 1024><<<nt, SORT_BLOCK, lds_bytes(1024), s>>>(ranges, keys, sorted, tile0);
+    // larger classes can only be populated if the instance count allows it
+    if (S > 1024)
+        k_tile_sort_lds<1024, 4096><<<nt, SORT_BLOCK, lds_bytes(4096), s>>>(ranges, keys, sorted, tile0);
+    if (S > 4096)
+        k_tile_sort_lds<4096, 8192><<<nt, SORT_BLOCK, lds_bytes(8192), s>>>(ranges, keys, sorted, tile0);
+    if (S > SORT_MAX_LDS_KEYS)
+        k_tile_sort_global<<<nt, SORT_BLOCK, 0, s>>>(ranges, keys, sorted, tile0);
+    return GS_OK;
 }
 
 }  // namespace gs
@@ -456,7 +579,7 @@ int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void*
     }
     const int t0 = tile_row0 * n_tiles_x;
     const int nt = (tile_row1 - tile_row0) * n_tiles_x;
-    if (nt > 0) k_tile_sort<<<nt, SORT_BLOCK, 0, s>>>(tile_ranges, keys, sorted_gaussians, t0);
+    launch_tile_sort(tile_ranges, keys, sorted_gaussians, t0, nt, S, s);
     return check_launch("tile_emit_sort");
 }
 

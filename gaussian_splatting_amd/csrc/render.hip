@@ -223,6 +223,9 @@ __device__ inline double wave_sum(double v) {   // gradcheck-only path: plain sh
     return v;
 }
 
+__device__ inline float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ inline double fast_rcp(double x) { return 1.0 / x; }
+
 template <typename T> __device__ inline void lds_add(T* p, T v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -317,10 +320,10 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
                 const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(rec + 4);
                 const T du = pu - g0.x, dv = pv - g0.y;
                 const T a = g0.z, b = g0.w, c = g1.x, rdet = g1.z, opa = g1.w;
-                T norm_prob = 0, alpha = 0;
+                T norm_prob = 0, alpha = 0, mh = 0;
                 if (!(fast && du * du + dv * dv > rec[8])) {   // inside the cutoff radius
                     // render_backward.cu:153-165 (multiplies by 1/det; forward divides)
-                    const T mh = (c * du * du - (b + b) * du * dv + a * dv * dv) * rdet;
+                    mh = (c * du * du - (b + b) * du * dv + a * dv * dv) * rdet;
                     if (mh > T(0)) norm_prob = gexp<T>(T(-0.5) * mh);
                     alpha = opa * norm_prob;
                     if (alpha > Thr<T>::sat_gt()) alpha = Thr<T>::alpha_cap();   // min(0.9999, .)
@@ -336,29 +339,36 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
                         }
                         bg_init = true;
                     }
-                    const T r1ma = 1.0 / (1.0 - alpha);
-                    if ((k % REF_CH) < nsp - 1) weight = weight * r1ma;   // Q1 (chunk-local index)
-                    T col[3];
-                    splat_colour<T, N_SH>(s_geom, s_col, i, Y, col);
-                    T grad_alpha = 0;
+                    // From here on only gradient VALUES are formed (no threshold depends on
+                    // them): evaluated in T with the reference's formulas factored
+                    // (render_backward.cu:183-234) and contraction allowed; checked at 1e-4.
+                    {
+#pragma clang fp contract(fast)
+                        const T r1ma = fast_rcp(T(1) - alpha);
+                        if ((k % REF_CH) < nsp - 1) weight = weight * r1ma;   // Q1 (chunk-local index)
+                        T col[3];
+                        splat_colour<T, N_SH>(s_geom, s_col, i, Y, col);
+                        const T aw = alpha * weight;
+                        T grad_alpha = 0;
 #pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
-                        const T grl = alpha * weight * gi[ch];
+                        for (int ch = 0; ch < 3; ch++) {
+                            const T grl = aw * gi[ch];
 #pragma unroll
-                        for (int s = 0; s < N_SH; s++) val[N_SH * ch + s] = Y[s] * grl;
-                        grad_alpha += (col[ch] * weight - color_accum[ch] * r1ma) * gi[ch];
+                            for (int s = 0; s < N_SH; s++) val[N_SH * ch + s] = Y[s] * grl;
+                            grad_alpha += (col[ch] * weight - color_accum[ch] * r1ma) * gi[ch];
+                            color_accum[ch] += col[ch] * aw;
+                        }
+                        val[C + 0] = norm_prob * grad_alpha;
+                        // d alpha / d mh^2 = -alpha_unclamped / 2; t = rdet * grad_mh
+                        const T t = T(-0.5) * norm_prob * opa * grad_alpha * rdet;
+                        const T A = c * du - b * dv;
+                        const T B = a * dv - b * du;
+                        val[C + 1] = T(-2) * A * t;           // :216-217
+                        val[C + 2] = T(-2) * B * t;           // :218-219
+                        val[C + 3] = (dv * dv - c * mh) * t;  // :221-229 with cf = mh^2 * rdet
+                        val[C + 4] = (b * mh - du * dv) * t;
+                        val[C + 5] = (du * du - a * mh) * t;
                     }
-                    val[C + 0] = norm_prob * grad_alpha;
-                    const T grad_prob = opa * grad_alpha;
-                    const T grad_mh = T(-0.5) * norm_prob * grad_prob;
-                    val[C + 1] = -(-b * dv - b * dv + 2 * c * du) * rdet * grad_mh;
-                    val[C + 2] = -(2 * a * dv - b * du - b * du) * rdet * grad_mh;
-                    const T cf = (a * dv * dv - b * du * dv - b * du * dv + c * du * du) * rdet * rdet;
-                    val[C + 3] = (-c * cf + dv * dv * rdet) * grad_mh;
-                    val[C + 4] = (b * cf - du * dv * rdet) * grad_mh;
-                    val[C + 5] = (-a * cf + du * du * rdet) * grad_mh;
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) color_accum[ch] += col[ch] * alpha * weight;
                 }
             }
             if (__ballot(contrib) == 0) continue;   // every reaching lane skipped the splat
