@@ -243,7 +243,7 @@ def main():
     value = P / (ms_per_step * 1e-3) / 1e6
 
     # measured counts of the timed scene
-    S = int(stats.get("S", 0)) or int(_count_instances(g, T, cam, DEFAULTS, dev))
+    S = int(_count_instances(g, T, cam, DEFAULTS, dev)) if rank == 0 else 0
     V = int(stats["V"])
     n_coeff = (deg + 1) ** 2
     alg = algorithmic_bytes(N, V, S, P, n_coeff)

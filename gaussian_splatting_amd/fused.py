@@ -156,12 +156,14 @@ def supported(gaussians, camera_T_world, camera, use_sh_precompute):
 
 
 def rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_mask_padding, mh_dist,
-              use_sh_precompute, background_rgb, tile_rows=None, return_aux=False):
+              use_sh_precompute, background_rgb, tile_rows=None, return_aux=False, grad_sync=None):
+    """tile_rows=(row0, row1) restricts binning and rendering to those tile rows and grad_sync is
+    applied to (uv, conic, opacity, colour) between the two autograd nodes: the hooks
+    gaussian_splatting_amd.sharded uses; both default to the single-GPU behaviour."""
     if not supported(gaussians, camera_T_world, camera, use_sh_precompute):
-        if tile_rows is not None:
-            raise RuntimeError("tile_rows is only supported on the fused fp32 SH-precompute path")
         return _reference_shaped.rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh,
-                                           cull_mask_padding, mh_dist, use_sh_precompute, background_rgb)
+                                           cull_mask_padding, mh_dist, use_sh_precompute, background_rgb,
+                                           tile_rows=tile_rows, grad_sync=grad_sync)
     g = gaussians
     sh = g.sh.contiguous() if g.sh is not None else None
     out = _Preprocess.apply(
@@ -169,7 +171,9 @@ def rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_m
         g.rgb.contiguous(), sh, camera_T_world.contiguous(), camera.K.contiguous(), int(camera.width),
         int(camera.height), near_thresh, far_thresh, cull_mask_padding, mh_dist, tile_rows)
     uv, conic, opacity, rgb, packed, xyz_cam, culling_mask, ranges, sorted_g, vis_idx = out
-    image = _Render.apply(uv, conic, opacity, rgb, packed, ranges, sorted_g, background_rgb.contiguous(),
+    r_uv, r_conic, r_opacity, r_rgb = (uv, conic, opacity, rgb) if grad_sync is None else grad_sync(
+        uv, conic, opacity, rgb)
+    image = _Render.apply(r_uv, r_conic, r_opacity, r_rgb, packed, ranges, sorted_g, background_rgb.contiguous(),
                           int(camera.height), int(camera.width), tile_rows)
     if return_aux:
         return image, culling_mask, uv, dict(conic=conic, opacity=opacity, rgb=rgb, packed=packed,

@@ -111,14 +111,17 @@ def _hw(image_size):
 class RenderImage(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rgb, opacity, uvs, conic, rays, splat_start_end_idx_by_tile_idx,
-                sorted_gaussian_idx_by_splat_idx, image_size, background_rgb):
+                sorted_gaussian_idx_by_splat_idx, image_size, background_rgb, tile_rows=None):
+        """tile_rows (optional, beyond the reference signature): render only these tile rows."""
         H, W = _hw(image_size)
+        kw = {} if tile_rows is None else dict(tile_rows=tile_rows)
+        ctx.kw = kw
         rendered_image = torch.zeros(H, W, 3, dtype=rgb.dtype, device=rgb.device)
         num_splats_per_pixel = torch.zeros(H, W, dtype=torch.int, device=rgb.device)
         final_weight_per_pixel = torch.zeros(H, W, dtype=rgb.dtype, device=rgb.device)
         backend.get().render_tiles_cuda(
             uvs, opacity, rgb, conic, rays, splat_start_end_idx_by_tile_idx, sorted_gaussian_idx_by_splat_idx,
-            background_rgb, num_splats_per_pixel, final_weight_per_pixel, rendered_image)
+            background_rgb, num_splats_per_pixel, final_weight_per_pixel, rendered_image, **kw)
         ctx.save_for_backward(
             uvs, opacity, rgb, conic, rays, splat_start_end_idx_by_tile_idx, sorted_gaussian_idx_by_splat_idx,
             background_rgb, num_splats_per_pixel, final_weight_per_pixel)
@@ -135,5 +138,5 @@ class RenderImage(torch.autograd.Function):
         backend.get().render_tiles_backward_cuda(
             uvs, opacity, rgb, conic, rays, splat_start_end_idx_by_tile_idx, sorted_gaussian_idx_by_splat_idx,
             background_rgb, num_splats_per_pixel, final_weight_per_pixel, grad_rendered_image.contiguous(),
-            grad_rgb, grad_opacity, grad_uv, grad_conic)
-        return grad_rgb, grad_opacity, grad_uv, grad_conic, None, None, None, None, None
+            grad_rgb, grad_opacity, grad_uv, grad_conic, **ctx.kw)
+        return grad_rgb, grad_opacity, grad_uv, grad_conic, None, None, None, None, None, None

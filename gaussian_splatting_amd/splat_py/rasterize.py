@@ -29,9 +29,13 @@ def frustum_culling_mask(xyz_camera_frame, uv, camera, near_thresh, far_thresh, 
 
 
 def rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_mask_padding, mh_dist,
-              use_sh_precompute, background_rgb):
+              use_sh_precompute, background_rgb, tile_rows=None, grad_sync=None):
     """-> (image[H,W,3], culling_mask bool[N], uv[V,2]); uv is the post-cull autograd intermediate
-    whose .grad (if retained) is the render-backward grad_uv (trainer.py:360,379)."""
+    whose .grad (if retained) is the render-backward grad_uv (trainer.py:360,379).
+
+    tile_rows / grad_sync are the multi-GPU hooks of gaussian_splatting_amd.sharded (not part of the
+    reference signature): render only the tile rows [row0, row1) and pass the render inputs
+    through grad_sync so that their gradients can be summed across ranks."""
     xyz_camera_frame = transform_points_torch(gaussians.xyz, camera_T_world)
     uv = CameraPointProjection.apply(xyz_camera_frame, camera.K)
     culling_mask = frustum_culling_mask(xyz_camera_frame, uv, camera, near_thresh, far_thresh, cull_mask_padding)
@@ -69,7 +73,9 @@ def rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_m
     else:
         render_rgb = culled.rgb
 
+    r_rgb, r_opacity, r_uv, r_conic = (render_rgb, culled.opacity, uv, conic) if grad_sync is None else grad_sync(
+        render_rgb, culled.opacity, uv, conic)
     image = RenderImage.apply(
-        render_rgb, culled.opacity, uv, conic, rays, splat_start_end_idx_by_tile_idx,
-        sorted_gaussian_idx_by_splat_idx, (camera.height, camera.width), background_rgb)
+        r_rgb, r_opacity, r_uv, r_conic, rays, splat_start_end_idx_by_tile_idx,
+        sorted_gaussian_idx_by_splat_idx, (camera.height, camera.width), background_rgb, tile_rows)
     return image, culling_mask, uv

@@ -223,3 +223,58 @@ def test_fused_everything_culled_and_no_grad_paths():
     with torch.no_grad():
         img2, _, _ = fused.rasterize(g, T, cam, 0.3, 500.0, 100, 3.0, True, torch.zeros(3, device=DEV))
     assert img2.shape == (96, 128, 3)
+
+
+def test_fused_tile_row_bands_tile_the_frame():
+    """multi-GPU building block on one GPU: rendering the frame band by band (tile_rows) gives the
+    same image bit for bit and gradients that sum to the full-frame gradients"""
+    N, W, H, deg = 20000, 640, 472, 3
+    bg = torch.full((3,), 0.5, device=DEV)
+    gi = make_grad_image(W, H, seed=2, device=DEV)
+
+    def run(rows):
+        g, cam, T = make_scene(N, W, H, deg, seed=7, device=DEV)
+        for k in PARAMS:
+            getattr(g, k).requires_grad_(True)
+        img, mask, uv = fused.rasterize(g, T, cam, 0.3, 500.0, 100, 3.0, True, bg, tile_rows=rows)
+        img.backward(gi)
+        return img.detach(), {k: getattr(g, k).grad for k in PARAMS}
+
+    full_img, full_g = run(None)
+    nty = (H + 15) // 16
+    bands = [(0, 7), (7, 19), (19, nty)]
+    parts = [run(r) for r in bands]
+    assert torch.equal(sum(p[0] for p in parts), full_img)
+    for k in PARAMS:
+        s = sum(p[1][k] for p in parts)
+        assert scaled_err(s, full_g[k]) < 1e-5, k
+
+
+def test_sharded_rasterizer_single_rank_rccl():
+    """ShardedRasterizer over an RCCL ("nccl") process group of one rank == the plain fused path"""
+    import os
+    import torch.distributed as dist
+    from gaussian_splatting_amd.sharded import ShardedRasterizer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV, 0))
+    try:
+        bg = torch.zeros(3, device=DEV)
+        gi = make_grad_image(256, 192, seed=2, device=DEV)
+        outs = []
+        for sharded in (False, True):
+            g, cam, T = make_scene(3000, 256, 192, 3, seed=9, device=DEV)
+            for k in PARAMS:
+                getattr(g, k).requires_grad_(True)
+            fn = ShardedRasterizer(192, 1, 0).rasterize if sharded else fused.rasterize
+            img, mask, uv = fn(g, T, cam, 0.3, 500.0, 100, 3.0, True, bg)
+            img.backward(gi)
+            outs.append((img.detach(), {k: getattr(g, k).grad for k in PARAMS}))
+        assert torch.equal(outs[0][0], outs[1][0])
+        for k in PARAMS:
+            assert scaled_err(outs[1][1][k], outs[0][1][k]) < 1e-5, k
+    finally:
+        if created:
+            dist.destroy_process_group()
