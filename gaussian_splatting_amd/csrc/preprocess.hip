@@ -145,6 +145,21 @@ __global__ __launch_bounds__(PP_BLOCK) void k_preprocess(
     const float* __restrict__ M, const float* __restrict__ K, const float* __restrict__ center,
     int N, Frustum fr, const int* __restrict__ block_offsets, PreOut o) {
     __shared__ int s_cnt[PP_BLOCK / GS_WAVE];
+    // The workgroup's SH coefficients are one contiguous block of 256 * 3 * (N_SH-1) floats: fetch it
+    // with coalesced 16-byte loads into LDS (a per-thread walk over its own 180-byte row makes every
+    // load instruction touch 64 cache lines); rows are then read at an odd word stride (conflict-free).
+    constexpr int SHW = 3 * (N_SH - 1);
+    __shared__ alignas(16) float s_sh[N_SH > 1 ? PP_BLOCK * SHW : 4];
+    if constexpr (N_SH > 1) {
+        const int g0 = blockIdx.x * PP_BLOCK;
+        const int rows = min(PP_BLOCK, N - g0);
+        const int count = rows * SHW;
+        const float* src = sh + (size_t)g0 * SHW;   // 16-byte aligned: g0 is a multiple of 256
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        float4* dst4 = reinterpret_cast<float4*>(s_sh);
+        for (int i = threadIdx.x; i < (count >> 2); i += PP_BLOCK) dst4[i] = src4[i];
+        for (int i = (count & ~3) + threadIdx.x; i < count; i += PP_BLOCK) s_sh[i] = src[i];
+    }
     const int g = blockIdx.x * PP_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool vis = false;
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(PP_BLOCK) void k_preprocess(
         d[0] *= r; d[1] *= r; d[2] *= r;
         float Y[N_SH];
         sh_basis<float, N_SH>(d, Y);
-        const float* shg = sh + (size_t)g * 3 * (N_SH - 1);
+        const float* shg = s_sh + threadIdx.x * SHW;
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
             float t = 0;
@@ -240,11 +255,15 @@ __global__ __launch_bounds__(PP_BLOCK) void k_preprocess_bwd(
     const int* __restrict__ rank, const float* __restrict__ opacity_act,
     const float* __restrict__ g_uv, const float* __restrict__ g_conic,
     const float* __restrict__ g_opa, const float* __restrict__ g_rgb, int N, PreGrad o) {
+    constexpr int SHW = 3 * (N_SH - 1);
+    // SH gradients (180 B per Gaussian at degree 3) are staged in LDS and written back as one
+    // contiguous block with coalesced 16-byte stores
+    __shared__ alignas(16) float s_sh[N_SH > 1 ? PP_BLOCK * SHW : 4];
     const int g = blockIdx.x * PP_BLOCK + threadIdx.x;
-    if (g >= N) return;
-    const int v = rank[g];
+    const bool in_range = g < N;
+    const int v = in_range ? rank[g] : -1;
     float gx[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0}, gs[3] = {0, 0, 0}, go = 0, gc[3] = {0, 0, 0};
-    float* gsh = N_SH > 1 ? o.sh + (size_t)g * 3 * (N_SH - 1) : nullptr;
+    float* gsh = s_sh + threadIdx.x * SHW;
     if (v < 0) {
         if constexpr (N_SH > 1) {
 #pragma unroll
@@ -307,6 +326,17 @@ __global__ __launch_bounds__(PP_BLOCK) void k_preprocess_bwd(
         gx[1] = M[1] * gcam[0] + M[5] * gcam[1] + M[9] * gcam[2];
         gx[2] = M[2] * gcam[0] + M[6] * gcam[1] + M[10] * gcam[2];
     }
+    if constexpr (N_SH > 1) {
+        __syncthreads();
+        const int g0 = blockIdx.x * PP_BLOCK;
+        const int count = min(PP_BLOCK, N - g0) * SHW;
+        float* dst = o.sh + (size_t)g0 * SHW;
+        float4* dst4 = reinterpret_cast<float4*>(dst);
+        const float4* src4 = reinterpret_cast<const float4*>(s_sh);
+        for (int i = threadIdx.x; i < (count >> 2); i += PP_BLOCK) dst4[i] = src4[i];
+        for (int i = (count & ~3) + threadIdx.x; i < count; i += PP_BLOCK) dst[i] = s_sh[i];
+    }
+    if (!in_range) return;
     o.xyz[g * 3 + 0] = gx[0]; o.xyz[g * 3 + 1] = gx[1]; o.xyz[g * 3 + 2] = gx[2];
     o.quaternion[g * 4 + 0] = gq[0]; o.quaternion[g * 4 + 1] = gq[1];
     o.quaternion[g * 4 + 2] = gq[2]; o.quaternion[g * 4 + 3] = gq[3];

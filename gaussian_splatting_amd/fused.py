@@ -114,7 +114,8 @@ class _Preprocess(torch.autograd.Function):
 
 class _Render(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, uv, conic, opacity, rgb, packed, ranges, sorted_g, background_rgb, height, width, tile_rows):
+    def forward(ctx, uv, conic, opacity, rgb, packed, ranges, sorted_g, background_rgb, height, width, tile_rows,
+                slab_sync=None):
         dev = uv.device
         nty = (height + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
         row0, row1 = tile_rows if tile_rows is not None else (0, nty)
@@ -127,6 +128,7 @@ class _Render(torch.autograd.Function):
                   height, 1, row0, row1, _p(nsp), _p(fw), _p(image), _hip.GS_F32, _stream())
         ctx.save_for_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw)
         ctx.dims = (height, width, row0, row1, uv.shape[0])
+        ctx.slab_sync = slab_sync
         return image
 
     @staticmethod
@@ -144,7 +146,9 @@ class _Render(torch.autograd.Function):
         _hip.call("gs_render_tiles_backward", _p(packed), _p(rgb), None, _p(ranges), _p(sorted_g),
                   _p(background_rgb), _p(nsp), _p(fw), _p(grad_image), width, height, 1, row0, row1, _p(g_rgb),
                   _p(g_opa), _p(g_uv), _p(g_conic), _hip.GS_F32, _stream())
-        return g_uv, g_conic, g_opa, g_rgb, None, None, None, None, None, None, None
+        if ctx.slab_sync is not None:
+            ctx.slab_sync(slab)   # multi-GPU: sum the partial per-Gaussian gradients of all bands in place
+        return g_uv, g_conic, g_opa, g_rgb, None, None, None, None, None, None, None, None
 
 
 def supported(gaussians, camera_T_world, camera, use_sh_precompute):
@@ -156,10 +160,11 @@ def supported(gaussians, camera_T_world, camera, use_sh_precompute):
 
 
 def rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_mask_padding, mh_dist,
-              use_sh_precompute, background_rgb, tile_rows=None, return_aux=False, grad_sync=None):
-    """tile_rows=(row0, row1) restricts binning and rendering to those tile rows and grad_sync is
-    applied to (uv, conic, opacity, colour) between the two autograd nodes: the hooks
-    gaussian_splatting_amd.sharded uses; both default to the single-GPU behaviour."""
+              use_sh_precompute, background_rgb, tile_rows=None, return_aux=False, grad_sync=None, slab_sync=None):
+    """tile_rows=(row0, row1) restricts binning and rendering to those tile rows; slab_sync(flat) is
+    called on the flat [9 V] render-gradient slab in the backward (grad_sync is the generic
+    per-tensor form used by the reference-shaped path): the hooks gaussian_splatting_amd.sharded
+    uses; all default to the single-GPU behaviour."""
     if not supported(gaussians, camera_T_world, camera, use_sh_precompute):
         return _reference_shaped.rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh,
                                            cull_mask_padding, mh_dist, use_sh_precompute, background_rgb,
@@ -171,10 +176,8 @@ def rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_m
         g.rgb.contiguous(), sh, camera_T_world.contiguous(), camera.K.contiguous(), int(camera.width),
         int(camera.height), near_thresh, far_thresh, cull_mask_padding, mh_dist, tile_rows)
     uv, conic, opacity, rgb, packed, xyz_cam, culling_mask, ranges, sorted_g, vis_idx = out
-    r_uv, r_conic, r_opacity, r_rgb = (uv, conic, opacity, rgb) if grad_sync is None else grad_sync(
-        uv, conic, opacity, rgb)
-    image = _Render.apply(r_uv, r_conic, r_opacity, r_rgb, packed, ranges, sorted_g, background_rgb.contiguous(),
-                          int(camera.height), int(camera.width), tile_rows)
+    image = _Render.apply(uv, conic, opacity, rgb, packed, ranges, sorted_g, background_rgb.contiguous(),
+                          int(camera.height), int(camera.width), tile_rows, slab_sync)
     if return_aux:
         return image, culling_mask, uv, dict(conic=conic, opacity=opacity, rgb=rgb, packed=packed,
                                              xyz_camera_frame=xyz_cam, tile_ranges=ranges,

@@ -76,6 +76,9 @@ class ShardedRasterizer:
     def _grad_sync(self, *tensors):
         return _SumGradsAcrossRanks.apply(self.group, *tensors)
 
+    def _slab_sync(self, flat):
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+
     def rasterize(self, gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_mask_padding, mh_dist,
                   use_sh_precompute, background_rgb):
         """Same contract as splat_py.rasterize.rasterize; the returned image is the full frame on
@@ -87,6 +90,7 @@ class ShardedRasterizer:
             from .splat_py.rasterize import rasterize as impl
         image, culling_mask, uv = impl(
             gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_mask_padding, mh_dist,
-            use_sh_precompute, background_rgb, tile_rows=self.tile_rows, grad_sync=self._grad_sync)
+            use_sh_precompute, background_rgb, tile_rows=self.tile_rows, grad_sync=self._grad_sync,
+            **({"slab_sync": self._slab_sync} if self.fused else {}))
         image = _GatherImage.apply(image, self.group)
         return image, culling_mask, uv
