@@ -91,6 +91,49 @@ __device__ inline void stage_chunk(const T* __restrict__ packed, const T* __rest
     }
 }
 
+// moves a wave-uniform 64-bit value into scalar registers
+__device__ inline unsigned long long wave_uniform(unsigned long long m) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)m);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(m >> 32));
+    return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+}
+
+// Per-chunk wave-level touch masks.  Thread t tests the cutoff circle (centre u,v, radius^2 r2) of
+// staged splat t against the four 8x8 pixel patches of the tile; ballots turn that into one 64-bit
+// mask per (patch, 64 splats).  A wave then visits only the splats whose mask bit is set.  Exactly
+// result-preserving: the patch distance (dx, dy) is the per-pixel (du, dv) of the nearest pixel or
+// 0, float multiply/add are monotone, so dx*dx + dy*dy > r2 implies du*du + dv*dv > r2 for every
+// pixel of the patch, i.e. every lane would have taken the "alpha < 1/255" path.  NaNs compare
+// false and keep the splat.
+template <typename T, int CHUNK>
+__device__ inline void build_touch_masks(const T* s_geom, int cnt, int tid, int tile_x, int tile_y,
+                                         unsigned long long (*s_mask)[CHUNK / 64 > 0 ? CHUNK / 64 : 1]) {
+    if (tid < CHUNK) {   // CHUNK <= 256 == workgroup size
+        unsigned touch = 0;
+        if (tid < cnt) {
+            const T* rec = s_geom + tid * GS_PACKED_WIDTH;
+            const T u = rec[0], v = rec[1], r2 = rec[8];
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const T x0 = T(tile_x * 16 + ((p & 1) << 3)), y0 = T(tile_y * 16 + ((p >> 1) << 3));
+                const T x1 = x0 + T(7), y1 = y0 + T(7);
+                T dx = T(0), dy = T(0);
+                if (u < x0) dx = x0 - u;
+                if (u > x1) dx = x1 - u;
+                if (v < y0) dy = y0 - v;
+                if (v > y1) dy = y1 - v;
+                if (!(dx * dx + dy * dy > r2)) touch |= 1u << p;
+            }
+        }
+        const int w = tid >> 6;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const unsigned long long m = __ballot((touch >> p) & 1u);
+            if ((tid & 63) == 0) s_mask[p][w] = m;
+        }
+    }
+}
+
 // colour of splat i of the staged chunk at this pixel's view direction
 template <typename T, int N_SH>
 __device__ inline void splat_colour(const T* s_geom, const T* s_col, int i, const T* Y, T* col) {
@@ -143,44 +186,57 @@ __global__ __launch_bounds__(RB) void k_render_fwd(
 
     T acc = 0, fw = 0;
     T img[3] = {0, 0, 0};
-    int nsp = 0;
+    // num_splats_per_pixel == index of the first splat at whose turn the pixel is saturated
+    // (render.cu:106,146,162), or the list length: set when the pixel saturates
+    int nsp = n_tile;
     bool done = !valid;
     const T pu = T(px.u), pv = T(px.v);
+    const int wave = tid >> 6;
+    constexpr int NW = RCHUNK / 64 > 0 ? RCHUNK / 64 : 1;
+    __shared__ unsigned long long s_mask[4][NW];
 
     for (int base = 0; base < n_tile; base += RCHUNK) {
         const int cnt = min(RCHUNK, n_tile - base);
         stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, nullptr);
         __syncthreads();
-        for (int i = 0; i < cnt; i++) {
-            if (__ballot(!done) == 0) break;   // wave-uniform
-            if (!done) {
-                if (acc > Thr<T>::sat_gt()) {   // render.cu:106
-                    done = true;
-                } else {
+        build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
+        __syncthreads();
+        for (int word = 0; word < NW && word * 64 < cnt; word++) {
+            unsigned long long m = s_mask[wave][word];
+            m = wave_uniform(m);
+            while (m) {
+                if (__ballot(!done) == 0) break;   // wave-uniform: every pixel of the patch saturated
+                const int i = word * 64 + __builtin_ctzll(m);
+                m &= m - 1;
+                if (!done) {
                     const T* rec = s_geom + i * GS_PACKED_WIDTH;
                     const Vec4<T> g0 = *reinterpret_cast<const Vec4<T>*>(rec);
                     const T du = pu - g0.x, dv = pv - g0.y;
-                    nsp++;
                     // beyond the cutoff radius alpha < 1/255 is certain: same outcome as :145-148
-                    if (fast && du * du + dv * dv > rec[8]) continue;
-                    const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(rec + 4);
-                    const T a = g0.z, b = g0.w, c = g1.x, det = g1.y, opa = g1.w;
-                    const T mh = (c * du * du - (b + b) * du * dv + a * dv * dv) / det;
-                    T alpha = 0;
-                    if (mh > T(0)) alpha = opa * gexp<T>(T(-0.5) * mh);
-                    if (!(fast && alpha < Thr<T>::alpha_min())) {   // render.cu:145
-                        fw = 1.0 - acc;
-                        const T weight = alpha * (1.0 - acc);       // double, narrowed
-                        T col[3];
-                        splat_colour<T, N_SH>(s_geom, s_col, i, Y, col);
+                    if (!(fast && du * du + dv * dv > rec[8])) {
+                        const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(rec + 4);
+                        const T a = g0.z, b = g0.w, c = g1.x, det = g1.y, opa = g1.w;
+                        const T mh = (c * du * du - (b + b) * du * dv + a * dv * dv) / det;
+                        T alpha = 0;
+                        if (mh > T(0)) alpha = opa * gexp<T>(T(-0.5) * mh);
+                        if (!(fast && alpha < Thr<T>::alpha_min())) {   // render.cu:145
+                            fw = 1.0 - acc;
+                            const T weight = alpha * (1.0 - acc);       // double, narrowed
+                            T col[3];
+                            splat_colour<T, N_SH>(s_geom, s_col, i, Y, col);
 #pragma unroll
-                        for (int ch = 0; ch < 3; ch++) img[ch] += col[ch] * weight;
-                        acc += weight;
+                            for (int ch = 0; ch < 3; ch++) img[ch] += col[ch] * weight;
+                            acc += weight;
+                            if (acc > Thr<T>::sat_gt()) {   // saturated: the next splat's check fails
+                                done = true;
+                                nsp = min(n_tile, base + i + 1);
+                            }
+                        }
                     }
                 }
             }
         }
-        if (__syncthreads_and(done || acc > Thr<T>::sat_gt())) break;
+        if (__syncthreads_and(done)) break;
     }
 
     if (valid) {
@@ -252,6 +308,7 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
     __shared__ int s_idx[RCHUNK];
     __shared__ T s_acc[RCHUNK * NV];
     __shared__ int s_max[4];
+    __shared__ unsigned long long s_mask[4][RCHUNK / 64 > 0 ? RCHUNK / 64 : 1];
 
     const int t_local = tile_of_block(blockIdx.x, nt);
     if (t_local >= nt) return;
@@ -305,8 +362,16 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
         stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, s_idx);
         for (int k = tid; k < cnt * NV; k += RB) s_acc[k] = 0;
         __syncthreads();
+        build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
+        __syncthreads();
 
-        for (int i = cnt - 1; i >= 0; i--) {
+        for (int word = (cnt - 1) >> 6; word >= 0; word--) {
+          unsigned long long m = s_mask[wave][word];
+          m = wave_uniform(m);
+          while (m) {
+            const int bit = 63 - __builtin_clzll(m);
+            m &= ~(1ull << bit);
+            const int i = (word << 6) + bit;
             const int k = base + i;
             const bool reach = valid && k < nsp;
             if (__ballot(reach) == 0) continue;   // wave-uniform: no lane reaches this splat
@@ -378,6 +443,7 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
 #pragma unroll
                 for (int j = 0; j < NV; j++) lds_add(&s_acc[i * NV + j], val[j]);
             }
+          }
         }
         __syncthreads();
         // one global atomic per value per (splat, tile)
