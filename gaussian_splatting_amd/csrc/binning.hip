@@ -140,9 +140,23 @@ __device__ inline void for_each_tile(const float* __restrict__ uvs,
     const float b = conic[g * 3 + 1] / 2.0f;
     const float c = conic[g * 3 + 2] + 0.25f;
     const Obb o = compute_obb(u, v, a, b, c, mh);
-    const Window w = candidate_window(u, v, o.radius_tiles, ntx, nty, row0, row1);
+    Window w = candidate_window(u, v, o.radius_tiles, ntx, nty, row0, row1);
     if (w.sx >= w.ex || w.sy >= w.ey) return;
     const Sat s = sat_setup(o);
+    // The first two axes of the test (tile_culling.cu:14-25) are solved for the tile index instead
+    // of being evaluated per candidate: tile tx passes  mnx <= 16 (tx+1)  and  mxx >= 16 tx  iff
+    // ceil(mnx/16) - 1 <= tx <= floor(mxx/16)  (16 tx is exact in fp32, /16 is exact), likewise in y.
+    // The window shrinks from the reference's (2r)^2 square to the OBB's bounding box; the set of
+    // accepted tiles is unchanged.  Non-finite extents keep the full window (NaN compares pass).
+    if (s.mnx == s.mnx && s.mxx == s.mxx && s.mny == s.mny && s.mxy == s.mxy) {
+        // (clamped in float before the conversion: +-inf extents must not overflow the int math;
+        // tile indices are < 2^20, where float arithmetic on integers is exact)
+        const float big = 1.0e9f;
+        w.sx = max(w.sx, f2i(fminf(fmaxf(__builtin_ceilf(s.mnx / 16.0f) - 1.0f, -big), big)));
+        w.ex = min(w.ex, f2i(fminf(fmaxf(__builtin_floorf(s.mxx / 16.0f) + 1.0f, -big), big)));
+        w.sy = max(w.sy, f2i(fminf(fmaxf(__builtin_ceilf(s.mny / 16.0f) - 1.0f, -big), big)));
+        w.ey = min(w.ey, f2i(fminf(fmaxf(__builtin_floorf(s.mxy / 16.0f) + 1.0f, -big), big)));
+    }
     for (int tx = w.sx; tx < w.ex; tx++) {
         const float l = (float)tx * 16.0f, r = (float)(tx + 1) * 16.0f;
         for (int ty = w.sy; ty < w.ey; ty++) {

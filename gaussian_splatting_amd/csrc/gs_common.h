@@ -55,12 +55,14 @@ template <> struct Thr<double> {
 };
 
 // ---- deterministic exp (fp32): 2^f by a 6th-order polynomial, IEEE ops only -----------------------
+// Branch-free: the range cases are selects, so a render loop keeps one exec region per splat.
+// Same value as the CPU restatement for every input (the polynomial is evaluated on the clamped
+// argument, which equals the argument wherever the polynomial result is the one selected).
 __device__ inline float det_expf(float x) {
     const float t = x * 1.44269504088896341f;
-    if (!(t > -125.0f)) return (t != t) ? t : 0.0f;
-    if (t > 127.0f) return __builtin_inff();
-    const float n = __builtin_rintf(t);
-    const float f = t - n;
+    const float tc = fminf(fmaxf(t, -126.0f), 127.0f);
+    const float n = __builtin_rintf(tc);
+    const float f = tc - n;
     float p = 1.54035303933816e-4f;
     p = __builtin_fmaf(p, f, 1.33335581464284e-3f);
     p = __builtin_fmaf(p, f, 9.61812910762848e-3f);
@@ -68,7 +70,11 @@ __device__ inline float det_expf(float x) {
     p = __builtin_fmaf(p, f, 2.40226506959101e-1f);
     p = __builtin_fmaf(p, f, 6.93147180559945e-1f);
     p = __builtin_fmaf(p, f, 1.0f);
-    return __builtin_ldexpf(p, (int)n);
+    float r = __builtin_ldexpf(p, (int)n);
+    r = (t > 127.0f) ? __builtin_inff() : r;
+    r = (t > -125.0f) ? r : 0.0f;   // underflow -> 0
+    r = (t != t) ? t : r;           // NaN propagates
+    return r;
 }
 
 // exp() of the reference (projection.cu:91-93) and __expf/exp of the render kernels

@@ -135,9 +135,9 @@ __device__ inline void pack_record(T u, T v, const T* conic3, T opa, const T* co
     }
     const T det = a * c - b * b;
     const T rdet = 1.0 / det;
-    p[0] = u; p[1] = v; p[2] = a; p[3] = b;
-    p[4] = c; p[5] = det; p[6] = rdet; p[7] = opa;
-    p[8] = cutoff_r2_t<T>(a, b, c, det, opa);
+    p[0] = u; p[1] = v; p[2] = cutoff_r2_t<T>(a, b, c, det, opa); p[3] = opa;
+    p[4] = a; p[5] = b; p[6] = c; p[7] = det;
+    p[8] = rdet;
     p[9] = col3 ? col3[0] : T(0);
     p[10] = col3 ? col3[1] : T(0);
     p[11] = col3 ? col3[2] : T(0);

@@ -91,6 +91,37 @@ __device__ inline void stage_chunk(const T* __restrict__ packed, const T* __rest
     }
 }
 
+// Software prefetch of the next chunk (N_SH == 1: the record carries the colour): the gather
+// index -> 48-byte record is two dependent HBM/L2 round trips; issuing it before the current chunk
+// is composited hides that latency behind the VALU work.
+template <typename T> struct ChunkRegs {
+    Vec4<T> r0, r1, r2;
+    int g;
+};
+template <typename T>
+__device__ inline void fetch_chunk(const T* __restrict__ packed, const int* __restrict__ sorted,
+                                   int first, int count, int tid, ChunkRegs<T>& c) {
+    if (tid < count) {
+        c.g = sorted[first + tid];
+        const Vec4<T>* src = reinterpret_cast<const Vec4<T>*>(packed + (size_t)c.g * GS_PACKED_WIDTH);
+        c.r0 = src[0];
+        c.r1 = src[1];
+        c.r2 = src[2];
+    }
+}
+template <typename T>
+__device__ inline void commit_chunk(const ChunkRegs<T>& c, int count, int tid, T* s_geom, int* s_idx) {
+    if (tid < count) {
+        Vec4<T>* dst = reinterpret_cast<Vec4<T>*>(s_geom + tid * GS_PACKED_WIDTH);
+        dst[0] = c.r0;
+        dst[1] = c.r1;
+        dst[2] = c.r2;
+        if (s_idx) s_idx[tid] = c.g;
+    }
+}
+
+template <typename T> __device__ constexpr bool fast_mode() { return sizeof(T) == 4; }
+
 // moves a wave-uniform 64-bit value into scalar registers
 __device__ inline unsigned long long wave_uniform(unsigned long long m) {
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)m);
@@ -112,7 +143,19 @@ __device__ inline void build_touch_masks(const T* s_geom, int cnt, int tid, int 
         unsigned touch = 0;
         if (tid < cnt) {
             const T* rec = s_geom + tid * GS_PACKED_WIDTH;
-            const T u = rec[0], v = rec[1], r2 = rec[8];
+            const T u = rec[0], v = rec[1], r2 = rec[2];
+            // axis-aligned extent of the cutoff ellipse {d : d' S^-1 d <= tau}: |du| <= sqrt(tau a),
+            // |dv| <= sqrt(tau c) (S = [[a, b], [b, c]]).  With r2 >= tau * lmax: hx2 = r2 a / lmax
+            // >= tau a (the circle's margin carries over), so a patch entirely beyond hx or hy holds
+            // no pixel with alpha >= 1/255.  Tighter than the circle for elongated splats.
+            T hx2 = r2, hy2 = r2;
+            if (fast_mode<T>() && r2 > T(0) && r2 < T(1e30)) {
+                const T a = rec[4], b = rec[5], c = rec[6];
+                const T half = T(0.5) * (a + c);
+                const T lmax = half + gsqrt<T>(T(0.25) * (a - c) * (a - c) + b * b);
+                hx2 = r2 * (a / lmax) * T(1.0001);
+                hy2 = r2 * (c / lmax) * T(1.0001);
+            }
 #pragma unroll
             for (int p = 0; p < 4; p++) {
                 const T x0 = T(tile_x * 16 + ((p & 1) << 3)), y0 = T(tile_y * 16 + ((p >> 1) << 3));
@@ -122,7 +165,7 @@ __device__ inline void build_touch_masks(const T* s_geom, int cnt, int tid, int 
                 if (u > x1) dx = x1 - u;
                 if (v < y0) dy = y0 - v;
                 if (v > y1) dy = y1 - v;
-                if (!(dx * dx + dy * dy > r2)) touch |= 1u << p;
+                if (!(dx * dx + dy * dy > r2) && !(dx * dx > hx2) && !(dy * dy > hy2)) touch |= 1u << p;
             }
         }
         const int w = tid >> 6;
@@ -195,33 +238,39 @@ __global__ __launch_bounds__(RB) void k_render_fwd(
     constexpr int NW = RCHUNK / 64 > 0 ? RCHUNK / 64 : 1;
     __shared__ unsigned long long s_mask[4][NW];
 
+    ChunkRegs<T> pf;
+    if constexpr (N_SH == 1) fetch_chunk<T>(packed, sorted, s0, min(RCHUNK, n_tile), tid, pf);
     for (int base = 0; base < n_tile; base += RCHUNK) {
         const int cnt = min(RCHUNK, n_tile - base);
-        stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, nullptr);
+        if constexpr (N_SH == 1) commit_chunk<T>(pf, cnt, tid, s_geom, nullptr);
+        else stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, nullptr);
         __syncthreads();
         build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
         __syncthreads();
+        if constexpr (N_SH == 1) {
+            const int nb = base + RCHUNK;
+            if (nb < n_tile) fetch_chunk<T>(packed, sorted, s0 + nb, min(RCHUNK, n_tile - nb), tid, pf);
+        }
         for (int word = 0; word < NW && word * 64 < cnt; word++) {
-            unsigned long long m = s_mask[wave][word];
-            m = wave_uniform(m);
+            unsigned long long m = wave_uniform(s_mask[wave][word]);
             while (m) {
                 if (__ballot(!done) == 0) break;   // wave-uniform: every pixel of the patch saturated
                 const int i = word * 64 + __builtin_ctzll(m);
                 m &= m - 1;
                 if (!done) {
                     const T* rec = s_geom + i * GS_PACKED_WIDTH;
-                    const Vec4<T> g0 = *reinterpret_cast<const Vec4<T>*>(rec);
+                    const Vec4<T> g0 = *reinterpret_cast<const Vec4<T>*>(rec);   // u v r2 opacity
                     const T du = pu - g0.x, dv = pv - g0.y;
                     // beyond the cutoff radius alpha < 1/255 is certain: same outcome as :145-148
-                    if (!(fast && du * du + dv * dv > rec[8])) {
-                        const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(rec + 4);
-                        const T a = g0.z, b = g0.w, c = g1.x, det = g1.y, opa = g1.w;
+                    if (!(fast && du * du + dv * dv > g0.z)) {
+                        const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(rec + 4);   // a b c det
+                        const T a = g1.x, b = g1.y, c = g1.z, det = g1.w;
                         const T mh = (c * du * du - (b + b) * du * dv + a * dv * dv) / det;
-                        T alpha = 0;
-                        if (mh > T(0)) alpha = opa * gexp<T>(T(-0.5) * mh);
-                        if (!(fast && alpha < Thr<T>::alpha_min())) {   // render.cu:145
+                        T alpha = g0.w * gexp<T>(T(-0.5) * mh);
+                        alpha = (mh > T(0)) ? alpha : T(0);                 // render.cu:133
+                        if (!(fast && alpha < Thr<T>::alpha_min())) {       // render.cu:145
                             fw = 1.0 - acc;
-                            const T weight = alpha * (1.0 - acc);       // double, narrowed
+                            const T weight = alpha * (1.0 - acc);           // double, narrowed
                             T col[3];
                             splat_colour<T, N_SH>(s_geom, s_col, i, Y, col);
 #pragma unroll
@@ -229,7 +278,7 @@ __global__ __launch_bounds__(RB) void k_render_fwd(
                             acc += weight;
                             if (acc > Thr<T>::sat_gt()) {   // saturated: the next splat's check fails
                                 done = true;
-                                nsp = min(n_tile, base + i + 1);
+                                nsp = base + i + 1;
                             }
                         }
                     }
@@ -355,15 +404,22 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
     const T bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
     const int last_chunk = (n_used - 1) / RCHUNK;
+    ChunkRegs<T> pf;
+    if constexpr (N_SH == 1)
+        fetch_chunk<T>(packed, sorted, s0 + last_chunk * RCHUNK, n_used - last_chunk * RCHUNK, tid, pf);
     for (int chunk = last_chunk; chunk >= 0; chunk--) {
         const int base = chunk * RCHUNK;
         const int cnt = min(RCHUNK, n_used - base);
         __syncthreads();   // previous chunk fully flushed
-        stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, s_idx);
+        if constexpr (N_SH == 1) commit_chunk<T>(pf, cnt, tid, s_geom, s_idx);
+        else stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, s_idx);
         for (int k = tid; k < cnt * NV; k += RB) s_acc[k] = 0;
         __syncthreads();
         build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
         __syncthreads();
+        if constexpr (N_SH == 1) {
+            if (chunk > 0) fetch_chunk<T>(packed, sorted, s0 + base - RCHUNK, RCHUNK, tid, pf);
+        }
 
         for (int word = (cnt - 1) >> 6; word >= 0; word--) {
           unsigned long long m = s_mask[wave][word];
@@ -373,20 +429,20 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
             m &= ~(1ull << bit);
             const int i = (word << 6) + bit;
             const int k = base + i;
-            const bool reach = valid && k < nsp;
-            if (__ballot(reach) == 0) continue;   // wave-uniform: no lane reaches this splat
+            const bool reach = valid && k < nsp;   // render_backward.cu:131
+            if (__ballot(reach) == 0) continue;    // wave-uniform: no lane reaches this splat
             T val[NV];
 #pragma unroll
             for (int j = 0; j < NV; j++) val[j] = 0;
             bool contrib = false;
             if (reach) {
                 const T* rec = s_geom + i * GS_PACKED_WIDTH;
-                const Vec4<T> g0 = *reinterpret_cast<const Vec4<T>*>(rec);
-                const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(rec + 4);
+                const Vec4<T> g0 = *reinterpret_cast<const Vec4<T>*>(rec);       // u v r2 opacity
+                const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(rec + 4);   // a b c det
                 const T du = pu - g0.x, dv = pv - g0.y;
-                const T a = g0.z, b = g0.w, c = g1.x, rdet = g1.z, opa = g1.w;
+                const T a = g1.x, b = g1.y, c = g1.z, rdet = rec[8], opa = g0.w;
                 T norm_prob = 0, alpha = 0, mh = 0;
-                if (!(fast && du * du + dv * dv > rec[8])) {   // inside the cutoff radius
+                if (!(fast && du * du + dv * dv > g0.z)) {   // inside the cutoff radius
                     // render_backward.cu:153-165 (multiplies by 1/det; forward divides)
                     mh = (c * du * du - (b + b) * du * dv + a * dv * dv) * rdet;
                     if (mh > T(0)) norm_prob = gexp<T>(T(-0.5) * mh);
@@ -505,11 +561,11 @@ __global__ __launch_bounds__(RB) void k_render_depth(const float* __restrict__ p
             if (__ballot(!done) == 0) break;
             if (!done) {
                 const Vec4<float> g0 =
-                    *reinterpret_cast<const Vec4<float>*>(s_geom + i * GS_PACKED_WIDTH);
+                    *reinterpret_cast<const Vec4<float>*>(s_geom + i * GS_PACKED_WIDTH);       // u v r2 opa
                 const Vec4<float> g1 =
-                    *reinterpret_cast<const Vec4<float>*>(s_geom + i * GS_PACKED_WIDTH + 4);
+                    *reinterpret_cast<const Vec4<float>*>(s_geom + i * GS_PACKED_WIDTH + 4);   // a b c det
                 const float du = pu - g0.x, dv = pv - g0.y;
-                const float a = g0.z, b = g0.w, c = g1.x, det = g1.y, opa = g1.w;
+                const float a = g1.x, b = g1.y, c = g1.z, det = g1.w, opa = g0.w;
                 const float mh = (c * du * du - (b + b) * du * dv + a * dv * dv) / det;
                 float alpha = 0.0f;
                 if (mh > 0.0f) alpha = opa * det_expf(-0.5f * mh);

@@ -148,7 +148,7 @@ int gs_preprocess_backward(const void* xyz, const void* quaternion, const void* 
 
 /* ---- tile renderer ---------------------------------------------------------------------------- */
 /* Packs what the render kernels read per splat into one 48-byte (fp32) record per visible Gaussian:
- *   packed[V][12] = (u, v, a, b | c, det, 1/det, opacity | r2, col0, col1, col2)
+ *   packed[V][12] = (u, v, r2, opacity | a, b, c, det | 1/det, col0, col1, col2)
  * a/b/c as render.cu:117-128 forms them (+0.25 dilation for fp32, none for fp64); r2 is a
  * conservative squared cutoff radius: a pixel farther than sqrt(r2) from (u, v) provably has
  * alpha < 1/255 and is skipped exactly as render.cu:145-148 would skip it (+inf for fp64, which
