@@ -121,6 +121,8 @@ __device__ inline void commit_chunk(const ChunkRegs<T>& c, int count, int tid, T
 }
 
 template <typename T> __device__ constexpr bool fast_mode() { return sizeof(T) == 4; }
+template <typename T> __device__ inline T tmin(T a, T b) { return b < a ? b : a; }
+template <typename T> __device__ inline T tmax(T a, T b) { return b > a ? b : a; }
 
 // moves a wave-uniform 64-bit value into scalar registers
 __device__ inline unsigned long long wave_uniform(unsigned long long m) {
@@ -144,17 +146,20 @@ __device__ inline void build_touch_masks(const T* s_geom, int cnt, int tid, int 
         if (tid < cnt) {
             const T* rec = s_geom + tid * GS_PACKED_WIDTH;
             const T u = rec[0], v = rec[1], r2 = rec[2];
-            // axis-aligned extent of the cutoff ellipse {d : d' S^-1 d <= tau}: |du| <= sqrt(tau a),
-            // |dv| <= sqrt(tau c) (S = [[a, b], [b, c]]).  With r2 >= tau * lmax: hx2 = r2 a / lmax
-            // >= tau a (the circle's margin carries over), so a patch entirely beyond hx or hy holds
-            // no pixel with alpha >= 1/255.  Tighter than the circle for elongated splats.
-            T hx2 = r2, hy2 = r2;
+            // Exact test of the cutoff ellipse {d : d' S^-1 d <= tau_m} against each patch rectangle:
+            // the minimum of q(d) = (c dx^2 - 2 b dx dy + a dy^2) / det over the rectangle of pixel
+            // offsets is 0 if the centre lies inside, else it is attained on an edge, where q is a
+            // 1-D parabola.  tau_m = r2 / lmax >= 1.05 tau (r2 carries the margin of cutoff_r2), and
+            // the continuous minimum bounds every pixel's q from below, so q_min > tau_m means no
+            // pixel of the patch can reach alpha >= 1/255.  Cheaper bounds first (circle).
+            bool use_q = false;
+            T a = 0, b = 0, c = 0, rdet = 0, tau_m = 0;
             if (fast_mode<T>() && r2 > T(0) && r2 < T(1e30)) {
-                const T a = rec[4], b = rec[5], c = rec[6];
+                a = rec[4]; b = rec[5]; c = rec[6]; rdet = rec[8];
                 const T half = T(0.5) * (a + c);
                 const T lmax = half + gsqrt<T>(T(0.25) * (a - c) * (a - c) + b * b);
-                hx2 = r2 * (a / lmax) * T(1.0001);
-                hy2 = r2 * (c / lmax) * T(1.0001);
+                tau_m = (r2 / lmax) * T(1.001);
+                use_q = a > T(0) && c > T(0) && rdet > T(0);
             }
 #pragma unroll
             for (int p = 0; p < 4; p++) {
@@ -165,7 +170,25 @@ __device__ inline void build_touch_masks(const T* s_geom, int cnt, int tid, int 
                 if (u > x1) dx = x1 - u;
                 if (v < y0) dy = y0 - v;
                 if (v > y1) dy = y1 - v;
-                if (!(dx * dx + dy * dy > r2) && !(dx * dx > hx2) && !(dy * dy > hy2)) touch |= 1u << p;
+                bool hit = !(dx * dx + dy * dy > r2);
+                if (hit && use_q && (dx != T(0) || dy != T(0))) {
+                    // rectangle of offsets [X0, X1] x [Y0, Y1]; minimise q on its four edges
+                    const T X0 = x0 - u, X1 = x1 - u, Y0 = y0 - v, Y1 = y1 - v;
+                    T qmin = T(3.0e38);
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const T X = e ? X1 : X0;            // vertical edges: dy* = b X / a
+                        T yy = b * X / a;
+                        yy = tmin<T>(tmax<T>(yy, Y0), Y1);
+                        qmin = tmin<T>(qmin, (c * X * X - T(2) * b * X * yy + a * yy * yy) * rdet);
+                        const T Y = e ? Y1 : Y0;            // horizontal edges: dx* = b Y / c
+                        T xx = b * Y / c;
+                        xx = tmin<T>(tmax<T>(xx, X0), X1);
+                        qmin = tmin<T>(qmin, (c * xx * xx - T(2) * b * xx * Y + a * Y * Y) * rdet);
+                    }
+                    hit = !(qmin > tau_m);
+                }
+                if (hit) touch |= 1u << p;
             }
         }
         const int w = tid >> 6;
