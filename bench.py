@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--workload", default="D", choices=["A", "B", "C", "D"])
     ap.add_argument("--path", default="auto", choices=["auto", "fused", "reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the multi-GPU code path (ShardedRasterizer over RCCL) even with one rank")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
 
@@ -160,9 +162,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from gaussian_splatting_amd import _hip
     from gaussian_splatting_amd.synthetic import DEFAULTS, WORKLOADS, make_grad_image, make_scene
@@ -187,7 +191,7 @@ def main():
                 raise
         path = "fused" if fused_mod is not None else "reference"
 
-    if world > 1:
+    if world > 1 or args.force_sharded:
         from gaussian_splatting_amd.sharded import ShardedRasterizer
         rast = ShardedRasterizer(cam.height, world, rank, fused=(path == "fused"))
 
@@ -250,6 +254,12 @@ def main():
     per_entry = {k: (sum(v) / len(v), len(v) / args.steps) for k, v in timing.items() if v}
     # dominant entry point = largest GPU time per step
     dom = max(per_entry, key=lambda k: per_entry[k][0] * per_entry[k][1]) if per_entry else None
+    # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in their own
+    # rocprofv3 runs and corrected for gfx950: scripts/pmc_passes.sh, scripts/make_traffic_json.py)
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", f"r01_hbm_traffic_{args.workload}.json")
+    if world == 1 and path == "fused" and os.path.exists(tpath):
+        traffic = {k: v["hbm_bytes"] for k, v in json.load(open(tpath))["entries"].items()}
     roofline = None
     if dom is not None:
         dur_ms = per_entry[dom][0]
@@ -259,12 +269,17 @@ def main():
         ach = (a / (dur_ms * 1e-3) / 1e9) if a else None
         roofline = {
             "bound": "hbm", "kernel": dom, "achieved": round(ach, 2) if ach else None, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5) if ach else None, "traffic": None,
+            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5) if ach else None, "traffic": traffic.get(dom),
             "launch_ms": round(dur_ms, 4), "algorithmic_bytes": int(a) if a else None,
             "frame_algorithmic_bytes": int(alg["frame"]),
             "frame_frac": round(alg["frame"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             "entry_ms_per_step": {k: round(v[0] * v[1], 4) for k, v in sorted(per_entry.items())},
         }
+
+    # secondary measurement (not the headline): BASELINE.json configs[1], same step definition
+    other = {}
+    if world == 1 and not args.force_sharded and args.workload != "B" and path == "fused":
+        other["B"] = _time_workload("B", fused_mod, dev, steps=max(5, args.steps // 2), warmup=3)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -279,12 +294,40 @@ def main():
             "config": {"workload": f"{args.workload}: {N} Gaussians, {W}x{H}, SH degree {deg}, seed 0",
                        "N": N, "V": V, "S": S, "P": P, "path": path,
                        "parallelism": "single" if world == 1 else f"tile-rows x{world}"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "other_workloads": other,
         }
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def _time_workload(name, fused_mod, dev, steps, warmup):
+    from gaussian_splatting_amd.synthetic import DEFAULTS, WORKLOADS, make_grad_image, make_scene
+    N, W, H, deg = WORKLOADS[name]
+    g, cam, T = make_scene(N, W, H, deg, seed=0, device=dev)
+    params = [p for p in (g.xyz, g.rgb, g.opacity, g.scale, g.quaternion, g.sh) if p is not None]
+    for p in params:
+        p.requires_grad_(True)
+    gi = make_grad_image(W, H, seed=1, device=dev)
+    bg = torch.zeros(3, device=dev)
+
+    def step():
+        for p in params:
+            p.grad = None
+        image, _, _ = fused_mod.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, **DEFAULTS)
+        image.backward(gi)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"workload": f"{N} Gaussians, {W}x{H}, SH degree {deg}", "ms_per_step": round(ms, 4),
+            "value": round(W * H / (ms * 1e-3) / 1e6, 3), "unit": "Mpixels/s", "steps": steps}
 
 
 def _count_instances(g, T, cam, defaults, dev):

@@ -251,19 +251,38 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_count(const float* __restric
     for (int t = threadIdx.x; t < T; t += PRIV_BLOCK) row[t] = s_hist[t];
 }
 
-// hist[b][t] <- sum_{b' < b} hist[b'][t];  counts[t] <- column total
-__global__ __launch_bounds__(256) void k_bin_colscan(int* __restrict__ hist, int T,
-                                                     int* __restrict__ counts) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= T) return;
-    int run = 0;
+// hist[b][t] <- sum_{b' < b} hist[b'][t];  counts[t] <- column total.
+// 1024-thread workgroup = 64 tiles x 16 row segments of 32 rows: every thread sums its segment
+// (coalesced: a wave reads 64 consecutive tiles of one row), the 16 segment sums of a tile are
+// prefixed through LDS, then the thread re-walks its segment writing the exclusive offsets.
+constexpr int CS_TILES = 64;
+constexpr int CS_SEGS = 16;
+constexpr int CS_ROWS = PRIV_NB / CS_SEGS;
+__global__ __launch_bounds__(CS_TILES * CS_SEGS) void k_bin_colscan(int* __restrict__ hist, int T,
+                                                                   int* __restrict__ counts) {
+    __shared__ int s_seg[CS_SEGS][CS_TILES];
+    const int lt = threadIdx.x & (CS_TILES - 1);
+    const int seg = threadIdx.x / CS_TILES;
+    const int t = blockIdx.x * CS_TILES + lt;
+    int* col = hist + (size_t)seg * CS_ROWS * T + t;
+    int sum = 0;
+    if (t < T) {
 #pragma unroll 8
-    for (int b = 0; b < PRIV_NB; b++) {
-        const int h = hist[(size_t)b * T + t];
-        hist[(size_t)b * T + t] = run;
-        run += h;
+        for (int r = 0; r < CS_ROWS; r++) sum += col[(size_t)r * T];
     }
-    counts[t] = run;
+    s_seg[seg][lt] = sum;
+    __syncthreads();
+    int run = 0;
+    for (int s2 = 0; s2 < seg; s2++) run += s_seg[s2][lt];
+    if (t < T) {
+        if (seg == CS_SEGS - 1) counts[t] = run + sum;
+#pragma unroll 8
+        for (int r = 0; r < CS_ROWS; r++) {
+            const int h = col[(size_t)r * T];
+            col[(size_t)r * T] = run;
+            run += h;
+        }
+    }
 }
 
 __device__ inline uint32_t sortable_bits(float z) {   // monotone float -> uint map
@@ -551,7 +570,7 @@ int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visi
         k_bin_count<<<PRIV_NB, PRIV_BLOCK, sizeof(int) * (size_t)T, s>>>(
             (const float*)uvs, (const float*)conic, V, n_tiles_x, n_tiles_y, mh_dist, tile_row0,
             tile_row1, hist, visible_count);
-        k_bin_colscan<<<div_up(T, 256), 256, 0, s>>>(hist, T, counts);
+        k_bin_colscan<<<div_up(T, CS_TILES), CS_TILES * CS_SEGS, 0, s>>>(hist, T, counts);
     } else {
         if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)T, s) != hipSuccess) {
             gs::set_error("tile_count: memset failed");
