@@ -25,6 +25,7 @@
 // stand-alone kernels (pg_math.h), so given the same camera-frame coordinates the results are
 // bit-identical to them and to the CPU restatement.
 #include "pg_math.h"
+#include "tile_math.h"
 
 namespace gs {
 
@@ -138,19 +139,29 @@ struct PreOut {
     uint8_t* culled;  // [N]    culling mask (1 = culled), rasterize.py:33-49
 };
 
-template <int N_SH>
+// tile-row band of a multi-GPU rank and what is needed to evaluate the candidate window
+struct Band {
+    int row0, row1, ntx, nty;
+    float mh;
+};
+
+// BAND == true (multi-GPU): the SH colour -- 180 B of the 236 B a Gaussian reads at degree 3 -- is
+// evaluated only for Gaussians whose candidate tile window (tile_culling.cu:138-156) reaches the
+// rank's rows; the others cannot appear in any of the rank's tile lists.  SH rows are then read
+// directly (no LDS staging: most rows are skipped).
+template <int N_SH, bool BAND>
 __global__ __launch_bounds__(PP_BLOCK) void k_preprocess(
     const float* __restrict__ xyz, const float* __restrict__ quat, const float* __restrict__ scale,
     const float* __restrict__ opacity, const float* __restrict__ rgb, const float* __restrict__ sh,
     const float* __restrict__ M, const float* __restrict__ K, const float* __restrict__ center,
-    int N, Frustum fr, const int* __restrict__ block_offsets, PreOut o) {
+    int N, Frustum fr, const int* __restrict__ block_offsets, PreOut o, Band band) {
     __shared__ int s_cnt[PP_BLOCK / GS_WAVE];
     // The workgroup's SH coefficients are one contiguous block of 256 * 3 * (N_SH-1) floats: fetch it
     // with coalesced 16-byte loads into LDS (a per-thread walk over its own 180-byte row makes every
     // load instruction touch 64 cache lines); rows are then read at an odd word stride (conflict-free).
     constexpr int SHW = 3 * (N_SH - 1);
-    __shared__ alignas(16) float s_sh[N_SH > 1 ? PP_BLOCK * SHW : 4];
-    if constexpr (N_SH > 1) {
+    __shared__ alignas(16) float s_sh[(N_SH > 1 && !BAND) ? PP_BLOCK * SHW : 4];
+    if constexpr (N_SH > 1 && !BAND) {
         const int g0 = blockIdx.x * PP_BLOCK;
         const int rows = min(PP_BLOCK, N - g0);
         const int count = rows * SHW;
@@ -205,17 +216,25 @@ __global__ __launch_bounds__(PP_BLOCK) void k_preprocess(
     const float opa = sigmoid_det(opacity[g]);
     o.opacity[v] = opa;
 
-    float col[3];
+    float col[3] = {0, 0, 0};
+    bool in_band = true;
+    if constexpr (BAND) {
+        const float a = c3[0] + 0.25f, b = c3[1] / 2.0f, cc = c3[2] + 0.25f;   // tile_culling.cu:142-144
+        const Obb obb = compute_obb(uv[0], uv[1], a, b, cc, band.mh);
+        const Window w = candidate_window(uv[0], uv[1], obb.radius_tiles, band.ntx, band.nty, band.row0,
+                                          band.row1);
+        in_band = w.sx < w.ex && w.sy < w.ey;
+    }
     if constexpr (N_SH == 1) {
         col[0] = rgb[g * 3 + 0]; col[1] = rgb[g * 3 + 1]; col[2] = rgb[g * 3 + 2];
-    } else {
+    } else if (in_band) {
         // precompute_sh.cu:28-55 with coefficient 0 = rgb and 1.. = sh (rasterize.py:89)
         float d[3] = {p[0] - center[0], p[1] - center[1], p[2] - center[2]};
         const float r = 1.0f / __builtin_sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
         d[0] *= r; d[1] *= r; d[2] *= r;
         float Y[N_SH];
         sh_basis<float, N_SH>(d, Y);
-        const float* shg = s_sh + threadIdx.x * SHW;
+        const float* shg = BAND ? sh + (size_t)g * SHW : s_sh + threadIdx.x * SHW;
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
             float t = 0;
@@ -379,6 +398,7 @@ int gs_preprocess_forward(const void* xyz, const void* quaternion, const void* s
                           const void* opacity, const void* rgb, const void* sh, int n_sh,
                           const void* camera_T_world, const void* K, int N, int W, int H,
                           float near_thresh, float far_thresh, float cull_mask_padding,
+                          float mh_dist, int band_row0, int band_row1,
                           int32_t* workspace, void* camera_center, int32_t* visible_count,
                           uint8_t* culling_mask, int32_t* rank, int32_t* vis_idx, void* uv,
                           void* xyz_camera_frame, void* conic, void* opacity_act, void* rgb_render,
@@ -403,11 +423,27 @@ int gs_preprocess_forward(const void* xyz, const void* quaternion, const void* s
     o.vis_idx = vis_idx;
     o.rank = rank;
     o.culled = culling_mask;
-    DISPATCH_SH(n_sh, (k_preprocess<N_SH><<<nb, PP_BLOCK, 0, s>>>(
-                          (const float*)xyz, (const float*)quaternion, (const float*)scale,
-                          (const float*)opacity, (const float*)rgb, (const float*)sh,
-                          (const float*)camera_T_world, (const float*)K,
-                          (const float*)camera_center, N, fr, block_offsets, o)));
+    Band band;
+    band.ntx = (W + GS_TILE - 1) / GS_TILE;
+    band.nty = (H + GS_TILE - 1) / GS_TILE;
+    band.row0 = band_row0;
+    band.row1 = band_row1;
+    band.mh = mh_dist;
+    GS_REQUIRE(band_row0 >= 0 && band_row1 <= band.nty && band_row0 <= band_row1, "bad tile row band");
+    const bool banded = !(band_row0 == 0 && band_row1 == band.nty);
+    if (banded) {
+        DISPATCH_SH(n_sh, (k_preprocess<N_SH, true><<<nb, PP_BLOCK, 0, s>>>(
+                              (const float*)xyz, (const float*)quaternion, (const float*)scale,
+                              (const float*)opacity, (const float*)rgb, (const float*)sh,
+                              (const float*)camera_T_world, (const float*)K,
+                              (const float*)camera_center, N, fr, block_offsets, o, band)));
+    } else {
+        DISPATCH_SH(n_sh, (k_preprocess<N_SH, false><<<nb, PP_BLOCK, 0, s>>>(
+                              (const float*)xyz, (const float*)quaternion, (const float*)scale,
+                              (const float*)opacity, (const float*)rgb, (const float*)sh,
+                              (const float*)camera_T_world, (const float*)K,
+                              (const float*)camera_center, N, fr, block_offsets, o, band)));
+    }
     return check_launch("preprocess_forward");
 }
 

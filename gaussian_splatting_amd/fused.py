@@ -64,7 +64,7 @@ class _Preprocess(torch.autograd.Function):
         packed = torch.empty(N, 12, **f32)
         _hip.call("gs_preprocess_forward", _p(xyz), _p(quaternion), _p(scale), _p(opacity), _p(rgb), _p(sh), n_sh,
                   _p(camera_T_world), _p(K), N, width, height, _cf(near_thresh), _cf(far_thresh),
-                  _cf(cull_mask_padding), _p(ws), _p(center), _p(count), _p(culling_mask), _p(rank), _p(vis_idx), _p(uv),
+                  _cf(cull_mask_padding), _cf(mh_dist), row0, row1, _p(ws), _p(center), _p(count), _p(culling_mask), _p(rank), _p(vis_idx), _p(uv),
                   _p(xyz_cam), _p(conic), _p(opacity_act), _p(rgb_render), _p(packed), _stream())
 
         tile_counts = torch.empty(_hip.lib().gs_tile_workspace_ints(T), **i32)

@@ -118,6 +118,9 @@ int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void*
  * the visible index equals the reference's boolean-mask index.
  *   inputs   xyz[N,3] quaternion[N,4] scale[N,3] opacity[N,1] (logits) rgb[N,3]
  *            sh[N,3,n_sh-1] (NULL when n_sh == 1), camera_T_world[4,4], K[3,3]
+ *   mh_dist, band_row0, band_row1: a multi-GPU rank passes its tile-row band; rgb_render (and the
+ *            colour inside packed) is then evaluated only for Gaussians whose candidate tile window
+ *            reaches the band (0 elsewhere).  Pass 0 and n_tile_rows for the whole frame.
  *   workspace int32[gs_preprocess_workspace_ints(N)]
  *   outputs  camera_center[3]; visible_count[1] (= V, on the device); culling_mask uint8[N]
  *            (1 = culled); rank int32[N] (visible index or -1); and, with capacity N rows of which
@@ -128,6 +131,7 @@ int gs_preprocess_forward(const void* xyz, const void* quaternion, const void* s
                           const void* opacity, const void* rgb, const void* sh, int n_sh,
                           const void* camera_T_world, const void* K, int N, int W, int H,
                           float near_thresh, float far_thresh, float cull_mask_padding,
+                          float mh_dist, int band_row0, int band_row1,
                           int32_t* workspace, void* camera_center, int32_t* visible_count,
                           uint8_t* culling_mask, int32_t* rank, int32_t* vis_idx, void* uv,
                           void* xyz_camera_frame, void* conic, void* opacity_act, void* rgb_render,

@@ -1,0 +1,49 @@
+"""Per-rank compute of a G-way tile-row split measured on ONE GPU: renders only the band of rank
+`--rank` of `--world` (no collectives).  usage: python scripts/band_cost.py --world 8 --rank 3"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gaussian_splatting_amd import _hip, fused
+from gaussian_splatting_amd.sharded import band_of
+from gaussian_splatting_amd.synthetic import DEFAULTS, WORKLOADS, make_grad_image, make_scene
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--world", type=int, default=8)
+ap.add_argument("--rank", type=int, default=3)
+ap.add_argument("--workload", default="D")
+ap.add_argument("--steps", type=int, default=10)
+a = ap.parse_args()
+N, W, H, deg = WORKLOADS[a.workload]
+g, cam, T = make_scene(N, W, H, deg, seed=0, device="cuda")
+params = [p for p in (g.xyz, g.rgb, g.opacity, g.scale, g.quaternion, g.sh) if p is not None]
+for p in params:
+    p.requires_grad_(True)
+gi = make_grad_image(W, H, seed=1, device="cuda")
+bg = torch.zeros(3, device="cuda")
+rows = band_of((H + 15) // 16, a.world, a.rank)
+
+
+def step():
+    for p in params:
+        p.grad = None
+    img, _, _ = fused.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, tile_rows=rows, **DEFAULTS)
+    img.backward(gi)
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+_hip.enable_timing(True)
+t0 = time.perf_counter()
+for _ in range(a.steps):
+    step()
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / a.steps * 1e3
+t = _hip.collect_timing()
+print(f"world {a.world} rank {a.rank} rows {rows}: {ms:.3f} ms/step",
+      {k: round(sum(v) / len(v), 4) for k, v in sorted(t.items())})
