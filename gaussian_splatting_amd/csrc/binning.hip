@@ -239,13 +239,13 @@ __global__ __launch_bounds__(BIN_BLOCK) void k_tile_emit(
     const float* __restrict__ uvs, const float* __restrict__ xyz_cam,
     const float* __restrict__ conic, int V, int ntx, int nty, float mh, int row0, int row1,
     const int* __restrict__ ranges, int* __restrict__ cursor, uint64_t* __restrict__ keys,
-    const int* __restrict__ v_dev) {
+    const int* __restrict__ v_dev, int64_t cap) {
     const int g = blockIdx.x * BIN_BLOCK + threadIdx.x;
     if (g >= (v_dev ? *v_dev : V)) return;
     const uint64_t key = ((uint64_t)sortable_bits(xyz_cam[g * 3 + 2]) << 32) | (uint32_t)g;
     for_each_tile(uvs, conic, g, ntx, nty, mh, row0, row1, [&](int tile) {
         const int pos = ranges[tile] + atomicAdd(cursor + tile, 1);
-        keys[pos] = key;
+        if (pos < cap) keys[pos] = key;
     });
 }
 
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_emit(
     const float* __restrict__ uvs, const float* __restrict__ xyz_cam,
     const float* __restrict__ conic, int V, int ntx, int nty, float mh, int row0, int row1,
     const int* __restrict__ ranges, const int* __restrict__ hist, uint64_t* __restrict__ keys,
-    const int* __restrict__ v_dev) {
+    const int* __restrict__ v_dev, int64_t cap) {
     extern __shared__ int s_cursor[];
     const int T = ntx * nty;
     const int* row = hist + (size_t)blockIdx.x * T;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_emit(
         const uint64_t key = ((uint64_t)sortable_bits(xyz_cam[g * 3 + 2]) << 32) | (uint32_t)g;
         for_each_tile(uvs, conic, g, ntx, nty, mh, row0, row1, [&](int tile) {
             const int pos = atomicAdd(&s_cursor[tile], 1);
-            keys[pos] = key;
+            if (pos < cap) keys[pos] = key;
         });
     }
 }
@@ -390,12 +390,13 @@ __device__ inline void pair_step_lds(uint64_t* s, int n, int n_pad, int k, int j
 template <int CAP_LO, int CAP_HI>
 __global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_lds(const int* __restrict__ ranges,
                                                               const uint64_t* __restrict__ keys,
-                                                              int* __restrict__ sorted, int tile0) {
+                                                              int* __restrict__ sorted, int tile0,
+                                                              int64_t cap) {
     extern __shared__ uint64_t s_keys[];
     const int tile = tile0 + blockIdx.x;
     const int s0 = ranges[tile];
     const int n = ranges[tile + 1] - s0;
-    if (n <= CAP_LO || n > CAP_HI) return;
+    if (n <= CAP_LO || n > CAP_HI || (int64_t)s0 + n > cap) return;
     const int tid = threadIdx.x;
     if (n == 1) {
         if (tid == 0) sorted[s0] = (int)(uint32_t)keys[s0];
@@ -425,11 +426,11 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_lds(const int* __restr
 __global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_global(const int* __restrict__ ranges,
                                                                  uint64_t* __restrict__ keys,
                                                                  int* __restrict__ sorted,
-                                                                 int tile0) {
+                                                                 int tile0, int64_t cap) {
     const int tile = tile0 + blockIdx.x;
     const int s0 = ranges[tile];
     const int n = ranges[tile + 1] - s0;
-    if (n <= SORT_MAX_LDS_KEYS) return;
+    if (n <= SORT_MAX_LDS_KEYS || (int64_t)s0 + n > cap) return;
     const int tid = threadIdx.x;
     uint64_t* gk = keys + s0;
     int n_pad = 2;
@@ -472,14 +473,14 @@ static int launch_tile_sort(const int* ranges, uint64_t* keys, int* sorted, int 
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(8192));
         attr_set = true;
     }
-    k_tile_sort_lds<0, 1024><<<nt, SORT_BLOCK, lds_bytes(1024), s>>>(ranges, keys, sorted, tile0);
+    k_tile_sort_lds<0, 1024><<<nt, SORT_BLOCK, lds_bytes(1024), s>>>(ranges, keys, sorted, tile0, S);
     // larger classes can only be populated if the instance count allows it
     if (S > 1024)
-        k_tile_sort_lds<1024, 4096><<<nt, SORT_BLOCK, lds_bytes(4096), s>>>(ranges, keys, sorted, tile0);
+        k_tile_sort_lds<1024, 4096><<<nt, SORT_BLOCK, lds_bytes(4096), s>>>(ranges, keys, sorted, tile0, S);
     if (S > 4096)
-        k_tile_sort_lds<4096, 8192><<<nt, SORT_BLOCK, lds_bytes(8192), s>>>(ranges, keys, sorted, tile0);
+        k_tile_sort_lds<4096, 8192><<<nt, SORT_BLOCK, lds_bytes(8192), s>>>(ranges, keys, sorted, tile0, S);
     if (S > SORT_MAX_LDS_KEYS)
-        k_tile_sort_global<<<nt, SORT_BLOCK, 0, s>>>(ranges, keys, sorted, tile0);
+        k_tile_sort_global<<<nt, SORT_BLOCK, 0, s>>>(ranges, keys, sorted, tile0, S);
     return GS_OK;
 }
 
@@ -544,7 +545,7 @@ int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void*
         const int32_t* hist = workspace + T;
         k_bin_emit<<<PRIV_NB, PRIV_BLOCK, sizeof(int) * (size_t)T, s>>>(
             (const float*)uvs, (const float*)xyz_camera_frame, (const float*)conic, V, n_tiles_x,
-            n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, hist, keys, visible_count);
+            n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, hist, keys, visible_count, S);
     } else {
         int32_t* cursor = workspace;
         if (hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)T, s) != hipSuccess) {
@@ -553,7 +554,7 @@ int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void*
         }
         k_tile_emit<<<div_up(V, BIN_BLOCK), BIN_BLOCK, 0, s>>>(
             (const float*)uvs, (const float*)xyz_camera_frame, (const float*)conic, V, n_tiles_x,
-            n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, cursor, keys, visible_count);
+            n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, cursor, keys, visible_count, S);
     }
     const int t0 = tile_row0 * n_tiles_x;
     const int nt = (tile_row1 - tile_row0) * n_tiles_x;

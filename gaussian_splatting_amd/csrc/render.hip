@@ -94,35 +94,6 @@ __device__ inline void stage_chunk(const T* __restrict__ packed, const T* __rest
     }
 }
 
-// Software prefetch of the next chunk (N_SH == 1: the record carries the colour): the gather
-// index -> 48-byte record is two dependent HBM/L2 round trips; issuing it before the current chunk
-// is composited hides that latency behind the VALU work.
-template <typename T> struct ChunkRegs {
-    Vec4<T> r0, r1, r2;
-    int g;
-};
-template <typename T>
-__device__ inline void fetch_chunk(const T* __restrict__ packed, const int* __restrict__ sorted,
-                                   int first, int count, int tid, ChunkRegs<T>& c) {
-    if (tid < count) {
-        c.g = sorted[first + tid];
-        const Vec4<T>* src = reinterpret_cast<const Vec4<T>*>(packed + (size_t)c.g * GS_PACKED_WIDTH);
-        c.r0 = src[0];
-        c.r1 = src[1];
-        c.r2 = src[2];
-    }
-}
-template <typename T>
-__device__ inline void commit_chunk(const ChunkRegs<T>& c, int count, int tid, T* s_geom, int* s_idx) {
-    if (tid < count) {
-        Vec4<T>* dst = reinterpret_cast<Vec4<T>*>(s_geom + tid * GS_PACKED_WIDTH);
-        dst[0] = c.r0;
-        dst[1] = c.r1;
-        dst[2] = c.r2;
-        if (s_idx) s_idx[tid] = c.g;
-    }
-}
-
 template <typename T> __device__ constexpr bool fast_mode() { return sizeof(T) == 4; }
 template <typename T> __device__ inline T tmin(T a, T b) { return b < a ? b : a; }
 template <typename T> __device__ inline T tmax(T a, T b) { return b > a ? b : a; }
@@ -264,19 +235,12 @@ __global__ __launch_bounds__(RB) void k_render_fwd(
     constexpr int NW = RCHUNK / 64 > 0 ? RCHUNK / 64 : 1;
     __shared__ unsigned long long s_mask[4][NW];
 
-    ChunkRegs<T> pf;
-    if constexpr (N_SH == 1) fetch_chunk<T>(packed, sorted, s0, min(RCHUNK, n_tile), tid, pf);
     for (int base = 0; base < n_tile; base += RCHUNK) {
         const int cnt = min(RCHUNK, n_tile - base);
-        if constexpr (N_SH == 1) commit_chunk<T>(pf, cnt, tid, s_geom, nullptr);
-        else stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, nullptr);
+        stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, nullptr);
         __syncthreads();
         build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
         __syncthreads();
-        if constexpr (N_SH == 1) {
-            const int nb = base + RCHUNK;
-            if (nb < n_tile) fetch_chunk<T>(packed, sorted, s0 + nb, min(RCHUNK, n_tile - nb), tid, pf);
-        }
         for (int word = 0; word < NW && word * 64 < cnt; word++) {
             unsigned long long m = wave_uniform(s_mask[wave][word]);
             while (m) {
@@ -353,8 +317,11 @@ __device__ inline float row_sum(float v) {
     v += GS_DPP(v, 0x111, 0xf, true);
     v += GS_DPP(v, 0x112, 0xf, true);
     v += GS_DPP(v, 0x114, 0xf, true);
-#if GS_BWD_GROUP == 16
+#if GS_BWD_GROUP >= 16
     v += GS_DPP(v, 0x118, 0xf, true);
+#endif
+#if GS_BWD_GROUP >= 32
+    v += GS_DPP(v, 0x142, 0xa, false);   // row_bcast:15 into rows 1 and 3: lanes 31, 63 hold half sums
 #endif
     return v;
 }
@@ -448,22 +415,15 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
     const T bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
     const int last_chunk = (n_used - 1) / RCHUNK;
-    ChunkRegs<T> pf;
-    if constexpr (N_SH == 1)
-        fetch_chunk<T>(packed, sorted, s0 + last_chunk * RCHUNK, n_used - last_chunk * RCHUNK, tid, pf);
     for (int chunk = last_chunk; chunk >= 0; chunk--) {
         const int base = chunk * RCHUNK;
         const int cnt = min(RCHUNK, n_used - base);
         __syncthreads();   // previous chunk fully flushed
-        if constexpr (N_SH == 1) commit_chunk<T>(pf, cnt, tid, s_geom, s_idx);
-        else stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, s_idx);
+        stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, s_idx);
         for (int k = tid; k < cnt * NV; k += RB) s_acc[k] = 0;
         __syncthreads();
         build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
         __syncthreads();
-        if constexpr (N_SH == 1) {
-            if (chunk > 0) fetch_chunk<T>(packed, sorted, s0 + base - RCHUNK, RCHUNK, tid, pf);
-        }
 
         for (int word = (cnt - 1) >> 6; word >= 0; word--) {
           unsigned long long m = s_mask[wave][word];

@@ -100,7 +100,9 @@ int gs_precompute_rgb_from_sh_backward(const void* xyz, const void* matrix, cons
  *   one 8-byte read returns S and V.  Pass the same V and visible_count to both calls.
  * workspace: int32[gs_tile_workspace_ints(n_tiles)] scratch written by step 1 and read by step 2
  *   (per-workgroup tile histograms; keep it untouched between the two calls);
- * keys: uint64[S] scratch. */
+ * keys: uint64[S] scratch.  S may be an over-estimate (a capacity): instances beyond it are not
+ * written and tiles reaching beyond it are left unsorted, so a caller may launch step 2 before it
+ * has read the true count and repeat it with the exact S only if the count exceeded the capacity. */
 size_t gs_tile_workspace_ints(int n_tiles);
 int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visible_count,
                   int n_tiles_x, int n_tiles_y, float mh_dist, int tile_row0, int tile_row1,

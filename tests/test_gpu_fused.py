@@ -278,3 +278,26 @@ def test_sharded_rasterizer_single_rank_rccl():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_fused_speculative_capacity_overflow_is_repaired():
+    """the emit + sort are launched with a capacity guessed from the previous frame; a too small
+    guess must be detected and repaired, a too large one must not change anything"""
+    bg = torch.zeros(3, device=DEV)
+
+    def run():
+        g, cam, T = make_scene(20000, 640, 480, 0, seed=3, device=DEV)
+        img, _, _, aux = fused.rasterize(g, T, cam, 0.3, 500.0, 100, 3.0, True, bg, return_aux=True)
+        return img, aux["sorted_gaussians"].clone(), aux["tile_ranges"].clone()
+
+    fused._capacity_hint.clear()
+    ref = run()                                  # no hint: exact path
+    assert len(fused._capacity_hint) == 1
+    key = next(iter(fused._capacity_hint))
+    spec = run()                                 # hint present: speculative path
+    fused._capacity_hint[key] = 100              # far too small: overflow, repaired
+    small = run()
+    fused._capacity_hint[key] = 10 * ref[1].numel()
+    large = run()
+    for other in (spec, small, large):
+        assert torch.equal(other[0], ref[0]) and torch.equal(other[1], ref[1]) and torch.equal(other[2], ref[2])
