@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--workload", default="D", choices=["A", "B", "C", "D"])
     ap.add_argument("--path", default="auto", choices=["auto", "fused", "reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--also", default="", help="comma-separated extra workloads to time after the headline one "
+                    "(reported under other_workloads; off by default so that a profile of the default "
+                    "command contains one workload only)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (ShardedRasterizer over RCCL) even with one rank")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -278,8 +281,9 @@ def main():
 
     # secondary measurement (not the headline): BASELINE.json configs[1], same step definition
     other = {}
-    if world == 1 and not args.force_sharded and args.workload != "B" and path == "fused":
-        other["B"] = _time_workload("B", fused_mod, dev, steps=max(5, args.steps // 2), warmup=3)
+    if world == 1 and not args.force_sharded and path == "fused":
+        for name in [w for w in args.also.split(",") if w]:
+            other[name] = _time_workload(name, fused_mod, dev, steps=max(5, args.steps // 2), warmup=3)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
