@@ -88,3 +88,27 @@ def test_get_splats_nan_guard(oracle_backend):
     bad = torch.tensor([[0.0, float("nan"), 1.0]])
     with pytest.raises(FloatingPointError):
         get_splats(torch.zeros(1, 2), Tiles(32, 32, "cpu"), torch.ones(1, 3), bad, 3.0)
+
+
+def test_product_path_fails_loudly_without_hip_library(monkeypatch):
+    """no CPU fallback: a missing libgsplat_hip.so is an error, never a silent oracle/PyTorch path"""
+    from gaussian_splatting_amd import _hip
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip, "LIB_PATH", "/nonexistent/libgsplat_hip.so")
+    with pytest.raises(_hip.HipLibraryError, match="no CPU fallback"):
+        _hip.lib()
+    with pytest.raises(_hip.HipLibraryError):
+        _hip.call("gs_abi_version")
+
+
+def test_product_package_never_imports_the_oracle():
+    """static check: nothing under gaussian_splatting_amd/ refers to oracle/"""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gaussian_splatting_amd")
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "gs_oracle" not in src, f
