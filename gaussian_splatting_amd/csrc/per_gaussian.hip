@@ -3,7 +3,7 @@
 // workgroups, no LDS, no host synchronisation, launched on the caller's stream.
 //
 // Forward kernels keep the operation order and operand precisions of the reference so that their
-// fp32 outputs are bit-identical to the CPU restatement (oracle/gs_oracle.cpp); backward kernels
+// fp32 outputs are bit-identical to the CPU restatement used by the tests; backward kernels
 // compute in T and are compared with a tolerance.
 #include "pg_math.h"
 
