@@ -303,6 +303,7 @@ def main():
         print(json.dumps(line))
     if world > 1 or args.force_sharded:
         import torch.distributed as dist
+        dist.barrier()   # rank 0 does untimed extra work (instance count, JSON) before teardown
         dist.destroy_process_group()
 
 

@@ -242,9 +242,9 @@ __global__ __launch_bounds__(RB) void k_render_fwd(
         build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
         __syncthreads();
         for (int word = 0; word < NW && word * 64 < cnt; word++) {
+            if (__ballot(!done) == 0) break;   // wave-uniform: every pixel of the patch saturated
             unsigned long long m = wave_uniform(s_mask[wave][word]);
             while (m) {
-                if (__ballot(!done) == 0) break;   // wave-uniform: every pixel of the patch saturated
                 const int i = word * 64 + __builtin_ctzll(m);
                 m &= m - 1;
                 if (!done) {
@@ -496,7 +496,17 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
                     }
                 }
             }
-            if (__ballot(contrib) == 0) continue;   // every reaching lane skipped the splat
+            const unsigned long long cmask = __ballot(contrib);
+            if (cmask == 0) continue;   // every reaching lane skipped the splat
+            if (fast && __popcll(cmask) <= 4) {
+                // few contributors: they add their own values (<= 4 lanes per LDS atomic, the same
+                // conflict degree as the row-leader form) and the DPP reduction is skipped
+                if (contrib) {
+#pragma unroll
+                    for (int j = 0; j < NV; j++) lds_add(&s_acc[i * NV + j], val[j]);
+                }
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < NV; j++) val[j] = row_sum(val[j]);
             if (row_leader<T>(lane)) {
