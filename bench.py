@@ -286,8 +286,11 @@ def main():
             other[name] = _time_workload(name, fused_mod, dev, steps=max(5, args.steps // 2), warmup=3)
 
     cpu = None
+    parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload, args.cpu_seconds)
+        if path == "fused":
+            parity = parity_check(args.workload, fused_mod, dev)
 
     if rank == 0:
         line = {
@@ -298,13 +301,64 @@ def main():
             "config": {"workload": f"{args.workload}: {N} Gaussians, {W}x{H}, SH degree {deg}, seed 0",
                        "N": N, "V": V, "S": S, "P": P, "path": path,
                        "parallelism": "single" if world == 1 else f"tile-rows x{world}"},
-            "roofline": roofline, "cpu_baseline": cpu, "other_workloads": other,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "other_workloads": other,
         }
         print(json.dumps(line))
     if world > 1 or args.force_sharded:
         import torch.distributed as dist
         dist.barrier()   # rank 0 does untimed extra work (instance count, JSON) before teardown
         dist.destroy_process_group()
+
+
+def parity_check(workload, fused_mod, dev, n_rows=2):
+    """Second half of the metric ("grad max-rel-err vs ref"): the CPU oracle, as the checker, renders a
+    band of tile rows of the timed workload forward + backward from the GPU's own per-splat inputs
+    (uv, conic, opacity, colour, tile lists); the GPU renders the same band.  Image: max abs difference
+    (0 == bit-identical).  Gradients w.r.t. those inputs: max |g - ref| / max(|ref|, 1 % of max|ref|)."""
+    from gaussian_splatting_amd.synthetic import DEFAULTS, WORKLOADS, make_grad_image, make_scene
+    from oracle import gs_oracle as orc
+
+    orc.set_modes(0, 0)
+    N, W, H, deg = WORKLOADS[workload]
+    nty = (H + 15) // 16
+    rows = (nty // 2, min(nty, nty // 2 + n_rows))
+    g, cam, T = make_scene(N, W, H, deg, seed=0, device=dev)
+    bg = torch.zeros(3, device=dev)
+    for name in ("xyz", "rgb", "opacity", "scale", "quaternion", "sh"):
+        p = getattr(g, name)
+        if p is not None:
+            p.requires_grad_(True)
+    img, mask, uv, aux = fused_mod.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, tile_rows=rows,
+                                             return_aux=True, **DEFAULTS)
+    for k in ("conic", "opacity", "rgb"):
+        aux[k].retain_grad()
+    uv.retain_grad()
+    gi = make_grad_image(W, H, seed=1, device=dev)
+    img.backward(gi)
+    c = lambda t: t.detach().cpu().contiguous()
+    uvc, conic, opa, rgb = c(uv), c(aux["conic"]), c(aux["opacity"]), c(aux["rgb"])
+    ranges, sorted_g = c(aux["tile_ranges"]), c(aux["sorted_gaussians"])
+    ref_img = torch.zeros(H, W, 3)
+    nsp = torch.zeros(H, W, dtype=torch.int32)
+    fw = torch.zeros(H, W)
+    rays = torch.zeros(1, 1, 1)
+    orc.render_tiles_cuda(uvc, opa, rgb, conic, rays, ranges, sorted_g, bg.cpu(), nsp, fw, ref_img, tile_rows=rows)
+    V = uvc.shape[0]
+    ref = [torch.zeros(V, 3), torch.zeros(V, 1), torch.zeros(V, 2), torch.zeros(V, 3)]
+    orc.render_tiles_backward_cuda(uvc, opa, rgb, conic, rays, ranges, sorted_g, bg.cpu(), nsp, fw, gi.cpu(), *ref,
+                                   tile_rows=rows)
+    got = [aux["rgb"].grad, aux["opacity"].grad, uv.grad, aux["conic"].grad]
+    worst = 0.0
+    for a, b in zip(got, ref):
+        a, b = a.detach().cpu().double(), b.double()
+        floor = 1e-2 * b.abs().max().item()
+        if floor > 0:
+            worst = max(worst, ((a - b).abs() / torch.clamp(b.abs(), min=floor)).max().item())
+    y0, y1 = rows[0] * 16, min(H, rows[1] * 16)
+    return {"image_max_abs_err": float((img.detach().cpu()[y0:y1] - ref_img[y0:y1]).abs().max()),
+            "grad_max_rel_err": worst, "target": 1e-4,
+            "sample": f"workload {workload}, tile rows [{rows[0]},{rows[1]}) rendered by GPU and by the CPU oracle "
+                      "from the same per-splat inputs and tile lists"}
 
 
 def _time_workload(name, fused_mod, dev, steps, warmup):
