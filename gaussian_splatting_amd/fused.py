@@ -115,6 +115,8 @@ class _Preprocess(torch.autograd.Function):
         sorted_g = sorted_buf[:S]
 
         ctx.save_for_backward(xyz, quaternion, scale, camera_T_world, K, center, rank, opacity_act)
+        ctx.set_materialize_grads(False)   # no zero tensors for the auxiliary outputs in backward
+        ctx.V = V
         ctx.n_sh = n_sh
         ctx.sh_shape = None if sh is None else tuple(sh.shape)
         uv_v, conic_v, opa_v, rgb_v = uv[:V], conic[:V], opacity_act[:V], rgb_render[:V]
@@ -126,10 +128,10 @@ class _Preprocess(torch.autograd.Function):
     def backward(ctx, g_uv, g_conic, g_opa, g_rgb, *unused):
         xyz, quaternion, scale, camera_T_world, K, center, rank, opacity_act = ctx.saved_tensors
         N = xyz.shape[0]
-        V = int(g_uv.shape[0]) if g_uv is not None else 0
+        V = ctx.V
         dev = xyz.device
 
-        def dense(g, width):
+        def dense(g, width):   # an output nobody consumed has no gradient: zeros
             if g is None:
                 return torch.zeros(max(V, 1), width, dtype=torch.float32, device=dev)
             return g.contiguous()
@@ -163,6 +165,7 @@ class _Render(torch.autograd.Function):
         _hip.call("gs_render_tiles", _p(packed), _p(rgb), None, _p(ranges), _p(sorted_g), _p(background_rgb), width,
                   height, 1, row0, row1, _p(nsp), _p(fw), _p(image), _hip.GS_F32, _stream())
         ctx.save_for_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw)
+        ctx.set_materialize_grads(False)
         ctx.dims = (height, width, row0, row1, uv.shape[0])
         ctx.slab_sync = slab_sync
         return image
@@ -172,6 +175,8 @@ class _Render(torch.autograd.Function):
         packed, rgb, ranges, sorted_g, background_rgb, nsp, fw = ctx.saved_tensors
         height, width, row0, row1, V = ctx.dims
         dev = packed.device
+        if grad_image is None:
+            return (None,) * 12
         grad_image = grad_image.contiguous()
         # one zero-filled slab [V, 9]: rgb 3 | opacity 1 | uv 2 | conic 3 (atomicAdd targets)
         slab = torch.zeros(9 * V, dtype=torch.float32, device=dev)
