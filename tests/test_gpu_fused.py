@@ -301,3 +301,28 @@ def test_fused_speculative_capacity_overflow_is_repaired():
     large = run()
     for other in (spec, small, large):
         assert torch.equal(other[0], ref[0]) and torch.equal(other[1], ref[1]) and torch.equal(other[2], ref[2])
+
+
+def test_kernels_run_on_the_current_stream():
+    """launches go to torch's current HIP stream, with no hidden device sync the
+    caller could be relying on -- a frame issued on a side stream equals one on the default stream"""
+    bg = torch.zeros(3, device=DEV)
+    gi = make_grad_image(320, 240, seed=4, device=DEV)
+
+    def run():
+        g, cam, T = make_scene(8000, 320, 240, 3, seed=21, device=DEV)
+        for k in PARAMS:
+            getattr(g, k).requires_grad_(True)
+        img, _, _ = fused.rasterize(g, T, cam, 0.3, 500.0, 100, 3.0, True, bg)
+        img.backward(gi)
+        return img.detach(), g.xyz.grad
+
+    ref_img, ref_grad = run()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        img, grad = run()
+    side.synchronize()
+    assert torch.equal(img, ref_img)
+    assert scaled_err(grad, ref_grad) < 1e-5
