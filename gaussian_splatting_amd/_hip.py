@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libgsplat_hip.so")
 
 GS_F32 = 0
 GS_F64 = 1
+GS_SORT_PREFIX = 1024
 
 # every entry point include/gsplat_hip.h declares
 EXPORTS = [
@@ -21,9 +22,9 @@ EXPORTS = [
     "gs_compute_projection_jacobian", "gs_compute_projection_jacobian_backward",
     "gs_compute_conic", "gs_compute_conic_backward",
     "gs_precompute_rgb_from_sh", "gs_precompute_rgb_from_sh_backward",
-    "gs_tile_workspace_ints", "gs_tile_count", "gs_tile_emit_sort",
+    "gs_tile_workspace_ints", "gs_tile_count", "gs_tile_emit_sort", "gs_tile_sort_flagged",
     "gs_preprocess_workspace_ints", "gs_preprocess_forward", "gs_preprocess_backward",
-    "gs_pack_splats", "gs_render_tiles", "gs_render_tiles_backward", "gs_render_depth",
+    "gs_pack_splats", "gs_render_tiles", "gs_render_tiles_prefix", "gs_render_tiles_backward", "gs_render_depth",
 ]
 
 _lib = None

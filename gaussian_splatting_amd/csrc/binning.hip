@@ -289,7 +289,7 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_emit(
 //   n <= 1024: 8.5 KiB    n <= 4096: 34 KiB    n <= 8192: 68 KiB    larger: pair-wise on global memory.
 constexpr int SORT_BLOCK = 256;
 constexpr int SORT_R = 16;
-constexpr int SORT_MAX_LDS_KEYS = 8192;
+static_assert(SORT_BLOCK == 256, "the radix-select histogram has one bin per thread");
 
 __device__ inline int slot(int i) { return i + (i >> 4); }
 
@@ -387,25 +387,10 @@ __device__ inline void pair_step_lds(uint64_t* s, int n, int n_pad, int k, int j
     }
 }
 
-template <int CAP_LO, int CAP_HI>
-__global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_lds(const int* __restrict__ ranges,
-                                                              const uint64_t* __restrict__ keys,
-                                                              int* __restrict__ sorted, int tile0,
-                                                              int64_t cap) {
-    extern __shared__ uint64_t s_keys[];
-    const int tile = tile0 + blockIdx.x;
-    const int s0 = ranges[tile];
-    const int n = ranges[tile + 1] - s0;
-    if (n <= CAP_LO || n > CAP_HI || (int64_t)s0 + n > cap) return;
-    const int tid = threadIdx.x;
-    if (n == 1) {
-        if (tid == 0) sorted[s0] = (int)(uint32_t)keys[s0];
-        return;
-    }
+// sorts s[slot(0..n)) ascending; every thread of the workgroup calls it, keys already in LDS
+__device__ inline void lds_bitonic_sort(uint64_t* s_keys, int n, int tid) {
     int n_pad = SORT_R;
     while (n_pad < n) n_pad <<= 1;
-    for (int i = tid; i < n; i += SORT_BLOCK) s_keys[slot(i)] = keys[s0 + i];
-    __syncthreads();
     register_pass<true>(s_keys, n, n_pad, tid);
     __syncthreads();
     for (int k = 2 * SORT_R; k <= n_pad; k <<= 1) {
@@ -418,11 +403,234 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_lds(const int* __restr
         register_pass<false>(s_keys, n, n_pad, tid);
         __syncthreads();
     }
+}
+
+// flags != nullptr: only tiles whose flag is set (the repair pass of the prefix mode)
+template <int CAP_LO, int CAP_HI>
+__global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_lds(const int* __restrict__ ranges,
+                                                              const uint64_t* __restrict__ keys,
+                                                              int* __restrict__ sorted, int tile0,
+                                                              int64_t cap,
+                                                              const int* __restrict__ flags) {
+    extern __shared__ uint64_t s_keys[];
+    const int tile = tile0 + blockIdx.x;
+    if (flags != nullptr && flags[tile] == 0) return;
+    const int s0 = ranges[tile];
+    const int n = ranges[tile + 1] - s0;
+    if (n <= CAP_LO || n > CAP_HI || (int64_t)s0 + n > cap) return;
+    const int tid = threadIdx.x;
+    if (n == 1) {
+        if (tid == 0) sorted[s0] = (int)(uint32_t)keys[s0];
+        return;
+    }
+    for (int i = tid; i < n; i += SORT_BLOCK) s_keys[slot(i)] = keys[s0 + i];
+    __syncthreads();
+    lds_bitonic_sort(s_keys, n, tid);
     for (int i = tid; i < n; i += SORT_BLOCK) sorted[s0 + i] = (int)(uint32_t)s_keys[slot(i)];
 }
 
-// oversize tile: the pair-wise network directly on the tile's global segment (one workgroup, so
-// workgroup-scope ordering suffices)
+// ---- sort of exactly 1024 unique keys by 4 waves ---------------------------------------------------
+// The register-blocked network above keeps only n/16 threads busy in its register passes, which
+// for 1024 keys is one wave out of four.  With the count fixed and no padding the work splits
+// evenly instead:
+//   A. each wave sorts a run of 256 keys held 4 per lane (element e = 4*lane + r): classic bitonic
+//      network, strides 1 and 2 in registers, strides 4..128 as lane-xor exchanges (no LDS
+//      storage, no workgroup barrier)
+//   B. the four sorted runs go to LDS; every key finds its rank in the three other runs by a
+//      branch-free binary search (12 independent searches per thread, 9 dependent LDS reads each)
+//      and lands at own index + ranks -- a 4-way merge without a sequential merge loop.
+// s_run: 1024 keys (linear), s_out: 1024 ints; keys must be unique (they carry the Gaussian index).
+__device__ inline void ce_dir(uint64_t& a, uint64_t& b, bool asc) {
+    const bool sw = (a > b) == asc;
+    const uint64_t lo = sw ? b : a, hi = sw ? a : b;
+    a = lo;
+    b = hi;
+}
+
+__device__ inline void wave_sort256(uint64_t (&v)[4], int lane) {
+#pragma unroll
+    for (int k = 2; k <= 256; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            if (j >= 4) {
+                const int lx = j >> 2;
+                const bool lower = (lane & lx) == 0;
+                const bool asc = k == 256 || (lane & (k >> 2)) == 0;
+                const bool keep_min = lower == asc;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint64_t o = __shfl_xor(v[r], lx);
+                    const bool take = keep_min ? (o < v[r]) : (o > v[r]);
+                    v[r] = take ? o : v[r];
+                }
+            } else {
+                // partner r ^ j inside the lane; direction from bit k of e = 4*lane + r
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if ((r & j) != 0) continue;
+                    const bool asc = k == 256 || (k >= 4 ? (lane & (k >> 2)) == 0 : (r & k) == 0);
+                    ce_dir(v[r], v[r | j], asc);
+                }
+            }
+        }
+    }
+}
+
+__device__ inline void sort1024_4waves(uint64_t* s_run, int* s_out, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    uint64_t v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = s_run[4 * tid + r];
+    wave_sort256(v, lane);
+    __syncthreads();   // every wave has read its unsorted run
+#pragma unroll
+    for (int r = 0; r < 4; r++) s_run[4 * tid + r] = v[r];
+    __syncthreads();
+    int pos[4][3];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int o = 0; o < 3; o++) pos[r][o] = 0;
+#pragma unroll
+    for (int step = 128; step >= 1; step >>= 1) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int o = 0; o < 3; o++) {
+                const int run = (wave + 1 + o) & 3;
+                if (s_run[run * 256 + pos[r][o] + step - 1] < v[r]) pos[r][o] += step;
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        int at = 4 * lane + r;
+#pragma unroll
+        for (int o = 0; o < 3; o++) {
+            const int run = (wave + 1 + o) & 3;
+            at += pos[r][o] + (s_run[run * 256 + pos[r][o]] < v[r] ? 1 : 0);   // reaches 256
+        }
+        s_out[at] = (int)(uint32_t)v[r];
+    }
+    __syncthreads();
+}
+
+// ---- prefix sort -----------------------------------------------------------------------------------
+// The render consumes a tile's list front to back and stops when every pixel of the tile is
+// saturated; on dense scenes that is a small part of the list (2.86 M Gaussians at 1297x840: lists
+// of ~2800, deepest pixel of any tile at 743).  In prefix mode a tile with more than
+// GS_SORT_PREFIX = 1024 entries gets only its 1024 smallest keys ordered:
+//   1. the workgroup holds the tile's keys in registers (CAP_HI / 256 per thread)
+//   2. MSB-first radix select of the 1024th smallest key: 8-bit digits starting at the highest bit
+//      in which the tile's keys differ (so the first histogram already spreads), LDS histogram +
+//      one-wave scan per digit, until the pivot's bucket is needed in full
+//   3. ballot-compaction of the keys <= pivot into LDS (exactly 1024: the keys are unique)
+//   4. sort1024_4waves on those 1024
+// The result is exact, not approximate: k_render_fwd raises a per-tile flag if it reaches the end
+// of the prefix with an unsaturated pixel, and the repair pass (gs_tile_sort_flagged + a
+// flagged-only render) redoes such a tile from its full list, all enqueued without a host read.
+template <int CAP_LO, int CAP_HI>
+__global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_prefix(const int* __restrict__ ranges,
+                                                                 const uint64_t* __restrict__ keys,
+                                                                 int* __restrict__ sorted,
+                                                                 int tile0, int64_t cap) {
+    constexpr int K = GS_SORT_PREFIX;
+    constexpr int KPT = CAP_HI / SORT_BLOCK;
+    static_assert(K == 1024, "sort1024_4waves");
+    __shared__ uint64_t s_sel[K];
+    __shared__ int s_out[K];
+    __shared__ int s_hist[256];
+    __shared__ unsigned long long s_diff;
+    __shared__ int s_state[3];
+    __shared__ int s_cnt;
+    const int tile = tile0 + blockIdx.x;
+    const int s0 = ranges[tile];
+    const int n = ranges[tile + 1] - s0;
+    if (n <= CAP_LO || n > CAP_HI || !prefix_sorted_tile(n, K) || (int64_t)s0 + n > cap) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+
+    uint64_t k[KPT];
+    const uint64_t key0 = keys[s0];
+    uint64_t diff = 0;
+#pragma unroll
+    for (int e = 0; e < KPT; e++) {
+        const int i = e * SORT_BLOCK + tid;
+        k[e] = i < n ? keys[s0 + i] : key0;   // the filler never counts: every use is guarded by i < n
+        diff |= k[e] ^ key0;
+    }
+    if (tid == 0) {
+        s_diff = 0;
+        s_cnt = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) diff |= __shfl_xor(diff, d);
+    if (lane == 0) atomicOr(&s_diff, (unsigned long long)diff);
+    __syncthreads();
+    int hi = 64 - __builtin_clzll(s_diff);   // bits [hi, 64) are common to all keys; n >= 2 unique keys: hi >= 1
+    uint64_t prefix = hi < 64 ? ((key0 >> hi) << hi) : 0ull;
+    int r = K;
+    while (true) {
+        const int w = hi < 8 ? hi : 8;
+        const int shift = hi - w;
+        s_hist[tid] = 0;   // SORT_BLOCK == 256 bins
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < KPT; e++) {
+            const int i = e * SORT_BLOCK + tid;
+            if (i < n && (((k[e] ^ prefix) >> shift) >> w) == 0)
+                atomicAdd(&s_hist[(int)((k[e] >> shift) & ((1u << w) - 1))], 1);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int h0 = s_hist[4 * lane], h1 = s_hist[4 * lane + 1], h2 = s_hist[4 * lane + 2],
+                      h3 = s_hist[4 * lane + 3];
+            const int t = h0 + h1 + h2 + h3;
+            int incl = t;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(incl, d);
+                if (lane >= d) incl += up;
+            }
+            int below = incl - t;
+            if (below < r && r <= incl) {   // exactly one lane: the candidates number at least r
+                int d = 4 * lane, cd = h0;
+                if (r > below + h0) {
+                    below += h0; d++; cd = h1;
+                    if (r > below + h1) {
+                        below += h1; d++; cd = h2;
+                        if (r > below + h2) { below += h2; d++; cd = h3; }
+                    }
+                }
+                s_state[0] = d;
+                s_state[1] = r - below;
+                s_state[2] = cd;
+            }
+        }
+        __syncthreads();
+        const int d = s_state[0], cd = s_state[2];
+        r = s_state[1];
+        prefix |= (uint64_t)d << shift;
+        hi = shift;
+        if (cd == r || hi == 0) break;   // the whole bucket belongs to the prefix (at hi == 0: one key)
+    }
+    const uint64_t pivot_hi = prefix >> hi;
+#pragma unroll
+    for (int e = 0; e < KPT; e++) {
+        const int i = e * SORT_BLOCK + tid;
+        const bool sel = i < n && (k[e] >> hi) <= pivot_hi;
+        const unsigned long long m = __ballot(sel);
+        if (m == 0) continue;
+        int base = 0;
+        if (lane == __builtin_ctzll(m)) base = atomicAdd(&s_cnt, __builtin_popcountll(m));
+        base = __shfl(base, __builtin_ctzll(m));
+        if (sel) s_sel[base + __builtin_popcountll(m & ((1ull << lane) - 1))] = k[e];
+    }
+    __syncthreads();
+    sort1024_4waves(s_sel, s_out, tid);
+    for (int i = tid; i < K; i += SORT_BLOCK) sorted[s0 + i] = s_out[i];
+}
+
 __global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_global(const int* __restrict__ ranges,
                                                                  uint64_t* __restrict__ keys,
                                                                  int* __restrict__ sorted,
@@ -463,22 +671,38 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_global(const int* __re
     for (int i = tid; i < n; i += SORT_BLOCK) sorted[s0 + i] = (int)(uint32_t)gk[i];
 }
 
-static int launch_tile_sort(const int* ranges, uint64_t* keys, int* sorted, int tile0, int nt,
-                            int64_t S, hipStream_t s) {
-    if (nt <= 0) return GS_OK;
-    auto lds_bytes = [](int cap) { return (size_t)(cap + cap / SORT_R) * sizeof(uint64_t); };
+static size_t sort_lds_bytes(int cap) { return (size_t)(cap + cap / SORT_R) * sizeof(uint64_t); }
+
+static void sort_attr_once() {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_tile_sort_lds<4096, 8192>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(8192));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)sort_lds_bytes(8192));
         attr_set = true;
     }
-    k_tile_sort_lds<0, 1024><<<nt, SORT_BLOCK, lds_bytes(1024), s>>>(ranges, keys, sorted, tile0, S);
+}
+
+static int launch_tile_sort(const int* ranges, uint64_t* keys, int* sorted, int tile0, int nt,
+                            int64_t S, int sort_prefix, hipStream_t s) {
+    if (nt <= 0) return GS_OK;
+    sort_attr_once();
+    k_tile_sort_lds<0, 1024><<<nt, SORT_BLOCK, sort_lds_bytes(1024), s>>>(ranges, keys, sorted,
+                                                                          tile0, S, nullptr);
     // larger classes can only be populated if the instance count allows it
-    if (S > 1024)
-        k_tile_sort_lds<1024, 4096><<<nt, SORT_BLOCK, lds_bytes(4096), s>>>(ranges, keys, sorted, tile0, S);
-    if (S > 4096)
-        k_tile_sort_lds<4096, 8192><<<nt, SORT_BLOCK, lds_bytes(8192), s>>>(ranges, keys, sorted, tile0, S);
+    if (sort_prefix > 0) {
+        if (S > 1024)
+            k_tile_sort_prefix<1024, 4096><<<nt, SORT_BLOCK, 0, s>>>(ranges, keys, sorted, tile0, S);
+        if (S > 4096)
+            k_tile_sort_prefix<4096, 8192><<<nt, SORT_BLOCK, 0, s>>>(ranges, keys, sorted, tile0, S);
+    } else {
+        if (S > 1024)
+            k_tile_sort_lds<1024, 4096><<<nt, SORT_BLOCK, sort_lds_bytes(4096), s>>>(
+                ranges, keys, sorted, tile0, S, nullptr);
+        if (S > 4096)
+            k_tile_sort_lds<4096, 8192><<<nt, SORT_BLOCK, sort_lds_bytes(8192), s>>>(
+                ranges, keys, sorted, tile0, S, nullptr);
+    }
     if (S > SORT_MAX_LDS_KEYS)
         k_tile_sort_global<<<nt, SORT_BLOCK, 0, s>>>(ranges, keys, sorted, tile0, S);
     return GS_OK;
@@ -535,9 +759,12 @@ int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visi
 int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void* conic, int V,
                       const int32_t* visible_count, int n_tiles_x, int n_tiles_y, float mh_dist,
                       int tile_row0, int tile_row1, const int32_t* tile_ranges, int32_t* workspace,
-                      uint64_t* keys, int64_t S, int32_t* sorted_gaussians, void* stream) {
+                      uint64_t* keys, int64_t S, int32_t* sorted_gaussians, int sort_prefix,
+                      void* stream) {
     GS_REQUIRE(tile_row0 >= 0 && tile_row1 <= n_tiles_y && tile_row0 <= tile_row1,
                "bad tile row range");
+    GS_REQUIRE(sort_prefix == 0 || sort_prefix == GS_SORT_PREFIX,
+               "sort_prefix must be 0 or GS_SORT_PREFIX (%d)", GS_SORT_PREFIX);
     hipStream_t s = (hipStream_t)stream;
     const int T = n_tiles_x * n_tiles_y;
     if (S <= 0 || V <= 0) return GS_OK;
@@ -558,8 +785,26 @@ int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void*
     }
     const int t0 = tile_row0 * n_tiles_x;
     const int nt = (tile_row1 - tile_row0) * n_tiles_x;
-    launch_tile_sort(tile_ranges, keys, sorted_gaussians, t0, nt, S, s);
+    launch_tile_sort(tile_ranges, keys, sorted_gaussians, t0, nt, S, sort_prefix, s);
     return check_launch("tile_emit_sort");
+}
+
+int gs_tile_sort_flagged(const int32_t* tile_ranges, const uint64_t* keys, int64_t S,
+                         const int32_t* tile_flags, int n_tiles_x, int tile_row0, int tile_row1,
+                         int32_t* sorted_gaussians, void* stream) {
+    GS_REQUIRE(tile_flags != nullptr, "tile_flags must not be null");
+    GS_REQUIRE(tile_row0 >= 0 && tile_row0 <= tile_row1, "bad tile row range");
+    hipStream_t s = (hipStream_t)stream;
+    const int t0 = tile_row0 * n_tiles_x;
+    const int nt = (tile_row1 - tile_row0) * n_tiles_x;
+    if (nt <= 0 || S <= GS_SORT_PREFIX) return GS_OK;   // no tile can have been prefix-sorted
+    sort_attr_once();
+    k_tile_sort_lds<1024, 4096><<<nt, SORT_BLOCK, sort_lds_bytes(4096), s>>>(
+        tile_ranges, keys, sorted_gaussians, t0, S, tile_flags);
+    if (S > 4096)
+        k_tile_sort_lds<4096, 8192><<<nt, SORT_BLOCK, sort_lds_bytes(8192), s>>>(
+            tile_ranges, keys, sorted_gaussians, t0, S, tile_flags);
+    return check_launch("tile_sort_flagged");
 }
 
 }  // extern "C"

@@ -170,6 +170,15 @@ __device__ inline void sh_to_rgb(const T* coeff, const T* Y, T* rgb) {
     }
 }
 
+// ---- prefix-sorted tile lists (binning.hip "prefix sort") --------------------------------------------
+// Largest tile list the LDS sort kernels take; longer ones are sorted in full in global memory.
+constexpr int SORT_MAX_LDS_KEYS = 8192;
+// In prefix mode only the first sort_prefix entries of such a tile's segment are ordered (and
+// valid).  The sort and the forward render kernel share this predicate.
+__host__ __device__ inline bool prefix_sorted_tile(int n, int sort_prefix) {
+    return sort_prefix > 0 && n > sort_prefix && n <= SORT_MAX_LDS_KEYS;
+}
+
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace gs

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(RB) void k_render_fwd(
     const T* __restrict__ packed, const T* __restrict__ rgb, const T* __restrict__ view_dir,
     const int* __restrict__ ranges, const int* __restrict__ sorted, const T* __restrict__ bg,
     int W, int H, int ntx, int tile0, int nt, int* __restrict__ nsp_out, T* __restrict__ fw_out,
-    T* __restrict__ image) {
+    T* __restrict__ image, int sort_prefix, int* __restrict__ tile_flags, int flagged_only) {
     constexpr bool fast = sizeof(T) == 4;
     constexpr int CW = ColW<N_SH>::value;
     constexpr int RCHUNK = Chunk<T, N_SH>::value;
@@ -207,10 +207,14 @@ __global__ __launch_bounds__(RB) void k_render_fwd(
     if (t_local >= nt) return;
     const int tile = tile0 + t_local;
     const int tid = threadIdx.x;
+    if (flagged_only && tile_flags[tile] == 0) return;
     const PixelMap px = pixel_of_thread(tile % ntx, tile / ntx, tid);
     const bool valid = px.u < W && px.v < H;
     const int s0 = ranges[tile];
     const int n_tile = ranges[tile + 1] - s0;
+    // prefix mode (binning.hip "prefix sort"): only the first sort_prefix entries are there
+    const bool prefix_only = !flagged_only && prefix_sorted_tile(n_tile, sort_prefix);
+    const int n_list = prefix_only ? sort_prefix : n_tile;
 
     T Y[N_SH];
     if constexpr (N_SH > 1) {
@@ -235,8 +239,9 @@ __global__ __launch_bounds__(RB) void k_render_fwd(
     constexpr int NW = RCHUNK / 64 > 0 ? RCHUNK / 64 : 1;
     __shared__ unsigned long long s_mask[4][NW];
 
-    for (int base = 0; base < n_tile; base += RCHUNK) {
-        const int cnt = min(RCHUNK, n_tile - base);
+    bool all_done = false;
+    for (int base = 0; base < n_list; base += RCHUNK) {
+        const int cnt = min(RCHUNK, n_list - base);
         stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, nullptr);
         __syncthreads();
         build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
@@ -275,8 +280,11 @@ __global__ __launch_bounds__(RB) void k_render_fwd(
                 }
             }
         }
-        if (__syncthreads_and(done)) break;
+        all_done = __syncthreads_and(done);
+        if (all_done) break;
     }
+    // an unsaturated pixel at the end of the prefix: the tile is redone from its full list
+    if (tile_flags != nullptr && !flagged_only && tid == 0) tile_flags[tile] = prefix_only && !all_done;
 
     if (valid) {
         if (acc < Thr<T>::bg_lt()) {   // render.cu:169
@@ -653,8 +661,31 @@ int gs_render_tiles(const void* packed, const void* rgb, const void* view_dir_by
                                             (const T*)view_dir_by_pixel, tile_ranges,
                                             sorted_gaussians, (const T*)background_rgb, W, H, ntx,
                                             tile_row0 * ntx, nt, num_splats_per_pixel,
-                                            (T*)final_weight_per_pixel, (T*)image))));
+                                            (T*)final_weight_per_pixel, (T*)image, 0, nullptr,
+                                            0))));
     return check_launch("render_tiles");
+}
+
+int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* tile_ranges,
+                           const int32_t* sorted_gaussians, const void* background_rgb, int W,
+                           int H, int tile_row0, int tile_row1, int sort_prefix,
+                           int32_t* tile_flags, int flagged_only, int32_t* num_splats_per_pixel,
+                           void* final_weight_per_pixel, void* image, void* stream) {
+    GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
+    GS_REQUIRE(sort_prefix == GS_SORT_PREFIX, "sort_prefix must be GS_SORT_PREFIX (%d)",
+               GS_SORT_PREFIX);
+    GS_REQUIRE(tile_flags != nullptr, "tile_flags must not be null");
+    if (int e = check_rows(H, tile_row0, tile_row1)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    const int ntx = (W + 15) / 16;
+    const int nt = (tile_row1 - tile_row0) * ntx;
+    if (nt == 0) return GS_OK;
+    const int grid = ((nt + 7) / 8) * 8;
+    k_render_fwd<float, 1><<<grid, RB, 0, s>>>(
+        (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
+        (const float*)background_rgb, W, H, ntx, tile_row0 * ntx, nt, num_splats_per_pixel,
+        (float*)final_weight_per_pixel, (float*)image, sort_prefix, tile_flags, flagged_only);
+    return check_launch("render_tiles_prefix");
 }
 
 int gs_render_tiles_backward(const void* packed, const void* rgb, const void* view_dir_by_pixel,

@@ -36,6 +36,13 @@ def _cf(x):
     return ctypes.c_float(float(x))
 
 
+# Prefix mode of the per-tile sort (include/gsplat_hip.h: gs_tile_emit_sort): order only the 1024
+# nearest entries of long tile lists and repair, on the device, the tiles that needed more.  Exact;
+# off only for callers that want the complete sorted lists back (return_aux=True).
+SORT_PREFIX = True
+
+last_tile_flags = None   # int32[T] of the latest prefix-mode frame: 1 = the tile was repaired (for tests/tools)
+
 _capacity_hint = {}   # (device, N, tiles, band) -> instance capacity guessed from the previous frame
 _pinned = {}
 
@@ -51,7 +58,7 @@ def _pinned_pair(dev):
 class _Preprocess(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, quaternion, scale, opacity, rgb, sh, camera_T_world, K, width, height, near_thresh,
-                far_thresh, cull_mask_padding, mh_dist, tile_rows):
+                far_thresh, cull_mask_padding, mh_dist, tile_rows, sort_prefix=0):
         dev = xyz.device
         N = xyz.shape[0]
         n_sh = 1 if sh is None else sh.shape[2] + 1
@@ -85,12 +92,12 @@ class _Preprocess(torch.autograd.Function):
                   _p(tile_counts), _p(ranges), _stream())
         def emit_sort(capacity):
             sorted_buf = torch.empty(capacity, **i32)
+            keys = torch.empty(capacity, dtype=torch.int64, device=dev)
             if capacity > 0:
-                keys = torch.empty(capacity, dtype=torch.int64, device=dev)
                 _hip.call("gs_tile_emit_sort", _p(uv), _p(xyz_cam), _p(conic), N, _p(count), ntx, nty, _cf(mh_dist),
                           row0, row1, _p(ranges), _p(tile_counts), _p(keys), ctypes.c_int64(capacity),
-                          _p(sorted_buf), _stream())
-            return sorted_buf
+                          _p(sorted_buf), sort_prefix, _stream())
+            return sorted_buf, keys
 
         # The frame's only device->host read: (S, V), 8 bytes, to size the outputs.  If a previous
         # frame of the same shape is known, the emit + sort are enqueued first with a capacity guessed
@@ -103,16 +110,17 @@ class _Preprocess(torch.autograd.Function):
             host.copy_(ranges[T:T + 2], non_blocking=True)
             ready = torch.cuda.Event()
             ready.record()
-            sorted_buf = emit_sort(guess)
+            sorted_buf, keys = emit_sort(guess)
             ready.synchronize()
             S, V = int(host[0]), int(host[1])
             if S > guess:
-                sorted_buf = emit_sort(S)
+                sorted_buf, keys = emit_sort(S)
         else:
             S, V = ranges[T:T + 2].tolist()
-            sorted_buf = emit_sort(S)
+            sorted_buf, keys = emit_sort(S)
         _capacity_hint[key] = int(S * 1.25) + 4096
         sorted_g = sorted_buf[:S]
+        keys = keys[:S]   # prefix mode: the repair pass of _Render sorts flagged tiles from these
 
         ctx.save_for_backward(xyz, quaternion, scale, camera_T_world, K, center, rank, opacity_act)
         ctx.set_materialize_grads(False)   # no zero tensors for the auxiliary outputs in backward
@@ -120,7 +128,7 @@ class _Preprocess(torch.autograd.Function):
         ctx.n_sh = n_sh
         ctx.sh_shape = None if sh is None else tuple(sh.shape)
         uv_v, conic_v, opa_v, rgb_v = uv[:V], conic[:V], opacity_act[:V], rgb_render[:V]
-        aux = (packed, xyz_cam[:V], culling_mask, ranges[:T + 1], sorted_g, vis_idx[:V])
+        aux = (packed, xyz_cam[:V], culling_mask, ranges[:T + 1], sorted_g, vis_idx[:V], keys)
         ctx.mark_non_differentiable(*aux)
         return (uv_v, conic_v, opa_v, rgb_v) + aux
 
@@ -147,14 +155,15 @@ class _Preprocess(torch.autograd.Function):
         _hip.call("gs_preprocess_backward", _p(xyz), _p(quaternion), _p(scale), ctx.n_sh, _p(camera_T_world), _p(K),
                   _p(center), _p(rank), _p(opacity_act), _p(g_uv), _p(g_conic), _p(g_opa), _p(g_rgb), N,
                   _p(grad_xyz), _p(grad_q), _p(grad_scale), _p(grad_opacity), _p(grad_rgb), _p(grad_sh), _stream())
-        return (grad_xyz, grad_q, grad_scale, grad_opacity, grad_rgb, grad_sh) + (None,) * 9
+        return (grad_xyz, grad_q, grad_scale, grad_opacity, grad_rgb, grad_sh) + (None,) * 10
 
 
 class _Render(torch.autograd.Function):
     @staticmethod
     def forward(ctx, uv, conic, opacity, rgb, packed, ranges, sorted_g, background_rgb, height, width, tile_rows,
-                slab_sync=None):
+                slab_sync=None, keys=None, sort_prefix=0):
         dev = uv.device
+        ntx = (width + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
         nty = (height + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
         row0, row1 = tile_rows if tile_rows is not None else (0, nty)
         # rows outside [row0, row1) are not written by the kernel: zero-fill only when sharded
@@ -162,8 +171,23 @@ class _Render(torch.autograd.Function):
         image = alloc(height, width, 3, dtype=torch.float32, device=dev)
         nsp = alloc(height, width, dtype=torch.int32, device=dev)
         fw = alloc(height, width, dtype=torch.float32, device=dev)
-        _hip.call("gs_render_tiles", _p(packed), _p(rgb), None, _p(ranges), _p(sorted_g), _p(background_rgb), width,
-                  height, 1, row0, row1, _p(nsp), _p(fw), _p(image), _hip.GS_F32, _stream())
+        if sort_prefix and sorted_g.shape[0] > sort_prefix:
+            # provisional render from the ordered prefixes; tiles that ran out of prefix are flagged,
+            # sorted in full and rendered again -- three enqueues, the host never looks at the flags
+            flags = torch.empty(ntx * nty, dtype=torch.int32, device=dev)
+            S = ctypes.c_int64(sorted_g.shape[0])
+            args = (_p(packed), _p(rgb), _p(ranges), _p(sorted_g), _p(background_rgb), width, height, row0, row1,
+                    sort_prefix, _p(flags))
+            outs = (_p(nsp), _p(fw), _p(image), _stream())
+            _hip.call("gs_render_tiles_prefix", *args, 0, *outs)
+            _hip.call("gs_tile_sort_flagged", _p(ranges), _p(keys), S, _p(flags), ntx, row0, row1, _p(sorted_g),
+                      _stream())
+            _hip.call("gs_render_tiles_prefix", *args, 1, *outs)
+            global last_tile_flags
+            last_tile_flags = flags
+        else:
+            _hip.call("gs_render_tiles", _p(packed), _p(rgb), None, _p(ranges), _p(sorted_g), _p(background_rgb),
+                      width, height, 1, row0, row1, _p(nsp), _p(fw), _p(image), _hip.GS_F32, _stream())
         ctx.save_for_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw)
         ctx.set_materialize_grads(False)
         ctx.dims = (height, width, row0, row1, uv.shape[0])
@@ -176,7 +200,7 @@ class _Render(torch.autograd.Function):
         height, width, row0, row1, V = ctx.dims
         dev = packed.device
         if grad_image is None:
-            return (None,) * 12
+            return (None,) * 14
         grad_image = grad_image.contiguous()
         # one zero-filled slab [V, 9]: rgb 3 | opacity 1 | uv 2 | conic 3 (atomicAdd targets)
         slab = torch.zeros(9 * V, dtype=torch.float32, device=dev)
@@ -189,7 +213,7 @@ class _Render(torch.autograd.Function):
                   _p(g_opa), _p(g_uv), _p(g_conic), _hip.GS_F32, _stream())
         if ctx.slab_sync is not None:
             ctx.slab_sync(slab)   # multi-GPU: sum the partial per-Gaussian gradients of all bands in place
-        return g_uv, g_conic, g_opa, g_rgb, None, None, None, None, None, None, None, None
+        return (g_uv, g_conic, g_opa, g_rgb) + (None,) * 10
 
 
 def supported(gaussians, camera_T_world, camera, use_sh_precompute):
@@ -212,13 +236,14 @@ def rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_m
                                            tile_rows=tile_rows, grad_sync=grad_sync)
     g = gaussians
     sh = g.sh.contiguous() if g.sh is not None else None
+    sort_prefix = _hip.GS_SORT_PREFIX if (SORT_PREFIX and not return_aux) else 0
     out = _Preprocess.apply(
         g.xyz.contiguous(), g.quaternion.contiguous(), g.scale.contiguous(), g.opacity.contiguous(),
         g.rgb.contiguous(), sh, camera_T_world.contiguous(), camera.K.contiguous(), int(camera.width),
-        int(camera.height), near_thresh, far_thresh, cull_mask_padding, mh_dist, tile_rows)
-    uv, conic, opacity, rgb, packed, xyz_cam, culling_mask, ranges, sorted_g, vis_idx = out
+        int(camera.height), near_thresh, far_thresh, cull_mask_padding, mh_dist, tile_rows, sort_prefix)
+    uv, conic, opacity, rgb, packed, xyz_cam, culling_mask, ranges, sorted_g, vis_idx, keys = out
     image = _Render.apply(uv, conic, opacity, rgb, packed, ranges, sorted_g, background_rgb.contiguous(),
-                          int(camera.height), int(camera.width), tile_rows, slab_sync)
+                          int(camera.height), int(camera.width), tile_rows, slab_sync, keys, sort_prefix)
     if return_aux:
         return image, culling_mask, uv, dict(conic=conic, opacity=opacity, rgb=rgb, packed=packed,
                                              xyz_camera_frame=xyz_cam, tile_ranges=ranges,

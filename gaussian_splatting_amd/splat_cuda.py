@@ -220,7 +220,7 @@ def get_sorted_gaussian_list(max_tiles_per_gaussian, uvs, xyz_camera_frame, coni
         keys = torch.empty(S, dtype=torch.int64, device=dev)
         _hip.call("gs_tile_emit_sort", _p(uvs), _p(xyz_camera_frame), _p(conic), V, None, int(n_tiles_x), int(n_tiles_y), mh,
                                   row0, row1, _p(ranges), _p(counts), _p(keys), ctypes.c_int64(S), _p(sorted_g),
-                                  _stream())
+                                  0, _stream())
     return sorted_g, ranges
 
 

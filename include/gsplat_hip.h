@@ -33,6 +33,7 @@ extern "C" {
 
 #define GS_TILE 16       /* tile edge in pixels (splat_py/structs.py:4) */
 #define GS_PACKED_WIDTH 12 /* scalars per packed splat record, see gs_pack_splats */
+#define GS_SORT_PREFIX 1024 /* entries ordered per long tile list in prefix mode, see gs_tile_emit_sort */
 
 const char* gs_last_error(void);
 int gs_abi_version(void);
@@ -102,7 +103,17 @@ int gs_precompute_rgb_from_sh_backward(const void* xyz, const void* matrix, cons
  *   (per-workgroup tile histograms; keep it untouched between the two calls);
  * keys: uint64[S] scratch.  S may be an over-estimate (a capacity): instances beyond it are not
  * written and tiles reaching beyond it are left unsorted, so a caller may launch step 2 before it
- * has read the true count and repeat it with the exact S only if the count exceeded the capacity. */
+ * has read the true count and repeat it with the exact S only if the count exceeded the capacity.
+ *
+ * sort_prefix: 0 = every segment is sorted in full (what get_sorted_gaussian_list returns).
+ *   GS_SORT_PREFIX = prefix mode for the fused renderer: the forward pass stops reading a tile's
+ *   list once all its pixels are saturated (render.cu:106,162), on dense scenes after a small part
+ *   of it, so for a tile with GS_SORT_PREFIX < n <= 8192 entries only the GS_SORT_PREFIX nearest are
+ *   selected and ordered into sorted_gaussians[start .. start+GS_SORT_PREFIX); the rest of that
+ *   segment is undefined.  Results stay exact: gs_render_tiles_prefix raises tile_flags[t] when a
+ *   tile ran out of prefix with an unsaturated pixel; gs_tile_sort_flagged then sorts those tiles
+ *   in full from the untouched `keys`, and a second gs_render_tiles_prefix call with
+ *   flagged_only = 1 re-renders them.  All three are plain enqueues, no host read. */
 size_t gs_tile_workspace_ints(int n_tiles);
 int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visible_count,
                   int n_tiles_x, int n_tiles_y, float mh_dist, int tile_row0, int tile_row1,
@@ -110,7 +121,13 @@ int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visi
 int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void* conic, int V,
                       const int32_t* visible_count, int n_tiles_x, int n_tiles_y, float mh_dist,
                       int tile_row0, int tile_row1, const int32_t* tile_ranges, int32_t* workspace,
-                      uint64_t* keys, int64_t S, int32_t* sorted_gaussians /*[S]*/, void* stream);
+                      uint64_t* keys, int64_t S, int32_t* sorted_gaussians /*[S]*/, int sort_prefix,
+                      void* stream);
+/* Full sort of the tiles t in the row band with tile_flags[t] != 0 (keys as left by
+ * gs_tile_emit_sort(..., GS_SORT_PREFIX, ...), same S). */
+int gs_tile_sort_flagged(const int32_t* tile_ranges, const uint64_t* keys, int64_t S,
+                         const int32_t* tile_flags, int n_tiles_x, int tile_row0, int tile_row1,
+                         int32_t* sorted_gaussians, void* stream);
 
 /* ---- fused per-Gaussian stage (fp32) ----------------------------------------------------------------
  * One pass replacing the PyTorch glue and per-Gaussian kernels of rasterize()
@@ -171,6 +188,18 @@ int gs_render_tiles(const void* packed, const void* rgb, const void* view_dir_by
                     const void* background_rgb, int W, int H, int n_sh, int tile_row0,
                     int tile_row1, int32_t* num_splats_per_pixel, void* final_weight_per_pixel,
                     void* image, int dtype, void* stream);
+/* The same kernel over lists produced with sort_prefix = GS_SORT_PREFIX (fp32, n_sh == 1).
+ * flagged_only == 0: renders every tile of the band, reading at most the ordered prefix of a
+ *   prefix-sorted tile, and writes tile_flags[t] = 1 if tile t needs its full list (0 otherwise;
+ *   the outputs of such a tile are then provisional).
+ * flagged_only == 1: renders only tiles with tile_flags[t] != 0, from their full lists (after
+ *   gs_tile_sort_flagged).  tile_flags: int32[n_tiles].
+ * After both calls every output equals what gs_render_tiles gives on fully sorted lists. */
+int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* tile_ranges,
+                           const int32_t* sorted_gaussians, const void* background_rgb, int W,
+                           int H, int tile_row0, int tile_row1, int sort_prefix,
+                           int32_t* tile_flags, int flagged_only, int32_t* num_splats_per_pixel,
+                           void* final_weight_per_pixel, void* image, void* stream);
 /* render_tiles_backward_cuda (bindings.cpp:120; render_backward.cu:12-595).
  * grad_rgb[V,3,n_sh], grad_opacity[V,1], grad_uv[V,2], grad_conic[V,3] are accumulated.
  * Bug-compatible with render_backward.cu:185. */

@@ -154,3 +154,116 @@ def test_lds_sort_size_classes():
     counts = (ref[1][1:] - ref[1][:-1]).tolist()
     assert 500 < counts[0] <= 1024 < counts[1] <= 4096 < counts[2] <= 8192, counts
     assert torch.equal(got[1].cpu(), ref[1]) and torch.equal(got[0].cpu(), ref[0])
+
+
+def test_prefix_sort_selects_the_nearest_entries():
+    """gs_tile_emit_sort(sort_prefix=1024): tiles of 1024 < n <= 8192 entries get exactly the first
+    1024 entries of the full order (radix select + sort), shorter and longer tiles the full order"""
+    import ctypes
+    from gaussian_splatting_amd import _hip
+    orc = oracle()
+    gen = torch.Generator().manual_seed(12)
+    chunks, sizes = [], (700, 1025, 3000, 4097, 8192, 9000)
+    for tile_x, n in enumerate(sizes):
+        uvs = torch.rand(n, 2, generator=gen) * 10 + 3
+        uvs[:, 0] += 16 * tile_x
+        chunks.append(uvs)
+    uv = torch.cat(chunks).contiguous()
+    V = uv.shape[0]
+    conic = torch.tensor([[0.5, 0.0, 0.5]]).repeat(V, 1).contiguous()
+    # depths: a wide range in one tile, a narrow one (keys differ in low bits only) in another, many ties
+    z = 1 + 10 * torch.rand(V, 1, generator=gen)
+    z[700:1725] = 5.0 + 1e-6 * torch.rand(1025, 1, generator=gen)
+    z[::7] = 3.0
+    xyz_c = torch.cat([torch.zeros(V, 2), z], dim=1).contiguous()
+    ntx = len(sizes)
+    ref_sorted, ref_ranges = orc.get_sorted_gaussian_list(1024, uv, xyz_c, conic, ntx, 1, 3.0)
+    assert (ref_ranges[1:] - ref_ranges[:-1]).tolist() == list(sizes)
+
+    p = lambda x: ctypes.c_void_p(x.data_ptr())
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    uv_d, xyz_d, conic_d = uv.to(DEV), xyz_c.to(DEV), conic.to(DEV)
+    ws = torch.empty(_hip.lib().gs_tile_workspace_ints(ntx), dtype=torch.int32, device=DEV)
+    ranges = torch.empty(ntx + 1, dtype=torch.int32, device=DEV)
+    _hip.call("gs_tile_count", p(uv_d), p(conic_d), V, None, ntx, 1, ctypes.c_float(3.0), 0, 1, p(ws), p(ranges),
+              stream)
+    assert torch.equal(ranges.cpu(), ref_ranges)
+    S = int(ranges[-1])
+    keys = torch.empty(S, dtype=torch.int64, device=DEV)
+    got = torch.full((S,), -1, dtype=torch.int32, device=DEV)
+    _hip.call("gs_tile_emit_sort", p(uv_d), p(xyz_d), p(conic_d), V, None, ntx, 1, ctypes.c_float(3.0), 0, 1,
+              p(ranges), p(ws), p(keys), ctypes.c_int64(S), p(got), _hip.GS_SORT_PREFIX, stream)
+    got = got.cpu()
+    for t, n in enumerate(sizes):
+        s0 = int(ref_ranges[t])
+        m = 1024 if 1024 < n <= 8192 else n
+        assert torch.equal(got[s0:s0 + m], ref_sorted[s0:s0 + m]), (t, n)
+    # repair pass: flag two of the prefix tiles, they come back fully sorted, the others untouched
+    flags = torch.tensor([0, 1, 0, 0, 1, 0], dtype=torch.int32, device=DEV)
+    before = got.clone()
+    got_d = got.to(DEV)
+    _hip.call("gs_tile_sort_flagged", p(ranges), p(keys), ctypes.c_int64(S), p(flags), ntx, 0, 1, p(got_d), stream)
+    got = got_d.cpu()
+    for t, n in enumerate(sizes):
+        s0 = int(ref_ranges[t])
+        if flags[t]:
+            assert torch.equal(got[s0:s0 + n], ref_sorted[s0:s0 + n]), (t, n)
+        else:
+            assert torch.equal(got[s0:s0 + n], before[s0:s0 + n]), (t, n)
+
+
+def run_both_sort_modes(make, grad_image):
+    out = {}
+    for mode in (False, True):
+        g, cam, T, kw = make()
+        for k in PARAMS:
+            if getattr(g, k) is not None:
+                getattr(g, k).requires_grad_(True)
+        fused.SORT_PREFIX = mode
+        try:
+            img, mask, uv = fused.rasterize(g, T, cam, use_sh_precompute=True,
+                                            background_rgb=torch.full((3,), 0.5, device=DEV), **kw)
+        finally:
+            fused.SORT_PREFIX = True
+        uv.retain_grad()
+        img.backward(grad_image)
+        out[mode] = (img.detach(), {k: getattr(g, k).grad for k in PARAMS if getattr(g, k) is not None}, uv.grad)
+    return out
+
+
+def test_prefix_sort_mode_is_exact_on_config_D():
+    """dense scene: every tile saturates inside its 1024-entry prefix; image identical, gradients
+    equal up to summation order"""
+    N, W, H, deg = WORKLOADS["D"]
+    fused.last_tile_flags = None
+    out = run_both_sort_modes(lambda: make_scene(N, W, H, deg, seed=0, device=DEV) + (DEFAULTS,),
+                              make_grad_image(W, H, seed=1, device=DEV))
+    assert fused.last_tile_flags is not None and int(fused.last_tile_flags.sum()) == 0
+    assert torch.equal(out[True][0], out[False][0])
+    for k in out[False][1]:
+        assert scaled_err(out[True][1][k], out[False][1][k]) < 1e-5, k
+    assert scaled_err(out[True][2], out[False][2]) < 1e-5
+
+
+def test_prefix_sort_mode_repairs_tiles_that_need_more():
+    """faint Gaussians: pixels need thousands of splats, so prefix tiles run out and are redone"""
+    W = H = 128
+
+    def make():
+        g, cam, T = make_scene(120000, W, H, 0, seed=5, device=DEV)
+        g.opacity.fill_(-5.0)
+        return g, cam, T, DEFAULTS
+
+    fused.last_tile_flags = None
+    out = run_both_sort_modes(make, make_grad_image(W, H, seed=2, device=DEV))
+    flags = fused.last_tile_flags
+    assert flags is not None and 0 < int(flags.sum())
+    g, cam, T, kw = make()
+    _, _, _, aux = fused.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=torch.zeros(3, device=DEV),
+                                   return_aux=True, **kw)
+    counts = (aux["tile_ranges"][1:] - aux["tile_ranges"][:-1])
+    in_prefix_class = (counts > 1024) & (counts <= 8192)
+    assert int(in_prefix_class.sum()) > 0 and bool((flags.bool() <= in_prefix_class).all())
+    assert torch.equal(out[True][0], out[False][0])
+    for k in out[False][1]:
+        assert scaled_err(out[True][1][k], out[False][1][k]) < 1e-5, k
