@@ -45,6 +45,10 @@ def algorithmic_bytes(N, V, S, P, n_coeff):
     return per
 
 
+# C-ABI entry points of the fused path that are variants of a SURVEY.md 8(d) row
+ENTRY_ALIAS = {"gs_render_tiles_backward_slab": "gs_render_tiles_backward", "gs_render_tiles_prefix": "gs_render_tiles"}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,13 +270,14 @@ def main():
     roofline = None
     if dom is not None:
         dur_ms = per_entry[dom][0]
-        a = alg.get(dom)
+        a = alg.get(ENTRY_ALIAS.get(dom, dom))
         if a is not None and world > 1:
             a = a / world   # each rank's launch covers its share of the tiles
         ach = (a / (dur_ms * 1e-3) / 1e9) if a else None
         roofline = {
             "bound": "hbm", "kernel": dom, "achieved": round(ach, 2) if ach else None, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5) if ach else None, "traffic": traffic.get(dom),
+            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5) if ach else None,
+            "traffic": traffic.get(dom, traffic.get(ENTRY_ALIAS.get(dom, dom))),
             "launch_ms": round(dur_ms, 4), "algorithmic_bytes": int(a) if a else None,
             "frame_algorithmic_bytes": int(alg["frame"]),
             "frame_frac": round(alg["frame"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),

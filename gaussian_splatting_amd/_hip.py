@@ -24,7 +24,8 @@ EXPORTS = [
     "gs_precompute_rgb_from_sh", "gs_precompute_rgb_from_sh_backward",
     "gs_tile_workspace_ints", "gs_tile_count", "gs_tile_emit_sort", "gs_tile_sort_flagged",
     "gs_preprocess_workspace_ints", "gs_preprocess_forward", "gs_preprocess_backward",
-    "gs_pack_splats", "gs_render_tiles", "gs_render_tiles_prefix", "gs_render_tiles_backward", "gs_render_depth",
+    "gs_pack_splats", "gs_render_tiles", "gs_render_tiles_prefix", "gs_render_tiles_backward", "gs_render_tiles_backward_slab",
+    "gs_render_depth", "gs_halo_workspace_ints", "gs_halo_plan", "gs_halo_gather_sum",
 ]
 
 _lib = None
@@ -45,6 +46,7 @@ def lib():
         _lib.gs_last_error.restype = ctypes.c_char_p
         _lib.gs_preprocess_workspace_ints.restype = ctypes.c_size_t
         _lib.gs_tile_workspace_ints.restype = ctypes.c_size_t
+        _lib.gs_halo_workspace_ints.restype = ctypes.c_size_t
     return _lib
 
 

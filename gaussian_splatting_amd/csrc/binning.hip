@@ -336,7 +336,7 @@ __device__ inline void reg_sort16(uint64_t (&v)[SORT_R]) {
 }
 
 template <bool FULL_SORT>
-__device__ inline void register_pass(uint64_t* s, int n, int n_pad, int tid) {
+__device__ __forceinline__ void register_pass(uint64_t* s, int n, int n_pad, int tid) {
     for (int blk = tid; blk < (n_pad >> 4); blk += SORT_BLOCK) {
         const int base = blk << 4;
         if (base >= n) continue;   // an all-padding block is already in order
@@ -353,7 +353,7 @@ __device__ inline void register_pass(uint64_t* s, int n, int n_pad, int tid) {
 }
 
 // one pair-wise step on LDS (flip when j == 0), four pairs in flight per thread
-__device__ inline void pair_step_lds(uint64_t* s, int n, int n_pad, int k, int j, int tid) {
+__device__ __forceinline__ void pair_step_lds(uint64_t* s, int n, int n_pad, int k, int j, int tid) {
     const int pairs = n_pad >> 1;
     for (int p0 = tid; p0 < pairs; p0 += 4 * SORT_BLOCK) {
         int lo[4], hi[4];
@@ -388,7 +388,7 @@ __device__ inline void pair_step_lds(uint64_t* s, int n, int n_pad, int k, int j
 }
 
 // sorts s[slot(0..n)) ascending; every thread of the workgroup calls it, keys already in LDS
-__device__ inline void lds_bitonic_sort(uint64_t* s_keys, int n, int tid) {
+__device__ __forceinline__ void lds_bitonic_sort(uint64_t* s_keys, int n, int tid) {
     int n_pad = SORT_R;
     while (n_pad < n) n_pad <<= 1;
     register_pass<true>(s_keys, n, n_pad, tid);
@@ -405,16 +405,13 @@ __device__ inline void lds_bitonic_sort(uint64_t* s_keys, int n, int tid) {
     }
 }
 
-// flags != nullptr: only tiles whose flag is set (the repair pass of the prefix mode)
 template <int CAP_LO, int CAP_HI>
 __global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_lds(const int* __restrict__ ranges,
                                                               const uint64_t* __restrict__ keys,
                                                               int* __restrict__ sorted, int tile0,
-                                                              int64_t cap,
-                                                              const int* __restrict__ flags) {
+                                                              int64_t cap) {
     extern __shared__ uint64_t s_keys[];
     const int tile = tile0 + blockIdx.x;
-    if (flags != nullptr && flags[tile] == 0) return;
     const int s0 = ranges[tile];
     const int n = ranges[tile + 1] - s0;
     if (n <= CAP_LO || n > CAP_HI || (int64_t)s0 + n > cap) return;
@@ -429,46 +426,50 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_lds(const int* __restr
     for (int i = tid; i < n; i += SORT_BLOCK) sorted[s0 + i] = (int)(uint32_t)s_keys[slot(i)];
 }
 
-// ---- sort of exactly 1024 unique keys by 4 waves ---------------------------------------------------
-// The register-blocked network above keeps only n/16 threads busy in its register passes, which
-// for 1024 keys is one wave out of four.  With the count fixed and no padding the work splits
-// evenly instead:
-//   A. each wave sorts a run of 256 keys held 4 per lane (element e = 4*lane + r): classic bitonic
-//      network, strides 1 and 2 in registers, strides 4..128 as lane-xor exchanges (no LDS
-//      storage, no workgroup barrier)
-//   B. the four sorted runs go to LDS; every key finds its rank in the three other runs by a
-//      branch-free binary search (12 independent searches per thread, 9 dependent LDS reads each)
-//      and lands at own index + ranks -- a 4-way merge without a sequential merge loop.
-// s_run: 1024 keys (linear), s_out: 1024 ints; keys must be unique (they carry the Gaussian index).
-__device__ inline void ce_dir(uint64_t& a, uint64_t& b, bool asc) {
+// ---- wave-level sorts (lists of up to 1024 entries) ------------------------------------------------
+// The register-blocked network above keeps only n/16 threads busy in its register passes: one
+// wave out of four for 1024 keys, four lanes for the ~50-entry lists of a sparse scene.  Short
+// lists therefore use waves as the unit:
+//   wave_sort<R>      one wave sorts 64*R keys held R per lane (element e = R*lane + r): classic
+//                     bitonic network with alternating directions, strides < R in registers, the
+//                     others as lane-xor exchanges.  No LDS storage, no workgroup barrier.
+//   sort1024_4waves   each of the 4 waves sorts a run of 256 (wave_sort<4>); the sorted runs go to
+//                     LDS and every key finds its rank in the three other runs by a branch-free
+//                     binary search (12 independent searches per thread, 9 dependent LDS reads
+//                     each) and lands at own index + ranks: a 4-way merge without a merge loop.
+// Padding is explicit here (~0 keys, larger than any real key); real keys are unique (they carry
+// the Gaussian index), so ranks are unambiguous and padding lands at positions >= n.
+__device__ __forceinline__ void ce_dir(uint64_t& a, uint64_t& b, bool asc) {
     const bool sw = (a > b) == asc;
     const uint64_t lo = sw ? b : a, hi = sw ? a : b;
     a = lo;
     b = hi;
 }
 
-__device__ inline void wave_sort256(uint64_t (&v)[4], int lane) {
+template <int R>
+__device__ __forceinline__ void wave_sort(uint64_t (&v)[R], int lane) {
+    constexpr int NK = 64 * R;
 #pragma unroll
-    for (int k = 2; k <= 256; k <<= 1) {
+    for (int k = 2; k <= NK; k <<= 1) {
 #pragma unroll
         for (int j = k >> 1; j >= 1; j >>= 1) {
-            if (j >= 4) {
-                const int lx = j >> 2;
+            if (j >= R) {
+                const int lx = j / R;
                 const bool lower = (lane & lx) == 0;
-                const bool asc = k == 256 || (lane & (k >> 2)) == 0;
+                const bool asc = k == NK || (lane & (k / R)) == 0;   // k > j >= R
                 const bool keep_min = lower == asc;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
+                for (int r = 0; r < R; r++) {
                     const uint64_t o = __shfl_xor(v[r], lx);
                     const bool take = keep_min ? (o < v[r]) : (o > v[r]);
                     v[r] = take ? o : v[r];
                 }
             } else {
-                // partner r ^ j inside the lane; direction from bit k of e = 4*lane + r
+                // partner r ^ j inside the lane; direction from bit k of e = R*lane + r
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
+                for (int r = 0; r < R; r++) {
                     if ((r & j) != 0) continue;
-                    const bool asc = k == 256 || (k >= 4 ? (lane & (k >> 2)) == 0 : (r & k) == 0);
+                    const bool asc = k == NK || (k >= R ? (lane & (k / R)) == 0 : (r & k) == 0);
                     ce_dir(v[r], v[r | j], asc);
                 }
             }
@@ -476,12 +477,26 @@ __device__ inline void wave_sort256(uint64_t (&v)[4], int lane) {
     }
 }
 
-__device__ inline void sort1024_4waves(uint64_t* s_run, int* s_out, int tid) {
+// one wave, n <= 64 * R keys straight from / to global memory
+template <int R>
+__device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ keys, int* __restrict__ sorted,
+                                      int n, int lane) {
+    uint64_t v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) v[r] = (R * lane + r < n) ? keys[R * lane + r] : ~0ull;
+    wave_sort<R>(v, lane);
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        if (R * lane + r < n) sorted[R * lane + r] = (int)(uint32_t)v[r];
+}
+
+// s_run: 1024 keys (linear, padded with ~0 beyond the list); s_out: 1024 ints
+__device__ __forceinline__ void sort1024_4waves(uint64_t* s_run, int* s_out, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     uint64_t v[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) v[r] = s_run[4 * tid + r];
-    wave_sort256(v, lane);
+    wave_sort<4>(v, lane);
     __syncthreads();   // every wave has read its unsorted run
 #pragma unroll
     for (int r = 0; r < 4; r++) s_run[4 * tid + r] = v[r];
@@ -509,7 +524,7 @@ __device__ inline void sort1024_4waves(uint64_t* s_run, int* s_out, int tid) {
             const int run = (wave + 1 + o) & 3;
             at += pos[r][o] + (s_run[run * 256 + pos[r][o]] < v[r] ? 1 : 0);   // reaches 256
         }
-        s_out[at] = (int)(uint32_t)v[r];
+        s_out[at] = (int)(uint32_t)v[r];   // padding lands in [n, 1024), possibly on top of other padding
     }
     __syncthreads();
 }
@@ -519,72 +534,65 @@ __device__ inline void sort1024_4waves(uint64_t* s_run, int* s_out, int tid) {
 // saturated; on dense scenes that is a small part of the list (2.86 M Gaussians at 1297x840: lists
 // of ~2800, deepest pixel of any tile at 743).  In prefix mode a tile with more than
 // GS_SORT_PREFIX = 1024 entries gets only its 1024 smallest keys ordered:
-//   1. the workgroup holds the tile's keys in registers (CAP_HI / 256 per thread)
+//   1. the workgroup holds the tile's keys in registers (KPT per thread)
 //   2. MSB-first radix select of the 1024th smallest key: 8-bit digits starting at the highest bit
 //      in which the tile's keys differ (so the first histogram already spreads), LDS histogram +
 //      one-wave scan per digit, until the pivot's bucket is needed in full
 //   3. ballot-compaction of the keys <= pivot into LDS (exactly 1024: the keys are unique)
 //   4. sort1024_4waves on those 1024
 // The result is exact, not approximate: k_render_fwd raises a per-tile flag if it reaches the end
-// of the prefix with an unsaturated pixel, and the repair pass (gs_tile_sort_flagged + a
+// of the prefix with an unsaturated pixel, and the repair pass (k_tile_sort_flagged + a
 // flagged-only render) redoes such a tile from its full list, all enqueued without a host read.
-template <int CAP_LO, int CAP_HI>
-__global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_prefix(const int* __restrict__ ranges,
-                                                                 const uint64_t* __restrict__ keys,
-                                                                 int* __restrict__ sorted,
-                                                                 int tile0, int64_t cap) {
-    constexpr int K = GS_SORT_PREFIX;
-    constexpr int KPT = CAP_HI / SORT_BLOCK;
-    static_assert(K == 1024, "sort1024_4waves");
-    __shared__ uint64_t s_sel[K];
-    __shared__ int s_out[K];
-    __shared__ int s_hist[256];
-    __shared__ unsigned long long s_diff;
-    __shared__ int s_state[3];
-    __shared__ int s_cnt;
-    const int tile = tile0 + blockIdx.x;
-    const int s0 = ranges[tile];
-    const int n = ranges[tile + 1] - s0;
-    if (n <= CAP_LO || n > CAP_HI || !prefix_sorted_tile(n, K) || (int64_t)s0 + n > cap) return;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
+struct SortLds {
+    uint64_t sel[GS_SORT_PREFIX];
+    int out[GS_SORT_PREFIX];
+    int hist[256];
+    unsigned long long diff;
+    int state[3];
+    int cnt;
+};
 
+template <int KPT>
+__device__ __forceinline__ void prefix_sort_tile(const uint64_t* __restrict__ keys, int* __restrict__ sorted,
+                                        int n, int tid, SortLds& L) {
+    constexpr int K = GS_SORT_PREFIX;
+    const int lane = tid & 63;
     uint64_t k[KPT];
-    const uint64_t key0 = keys[s0];
+    const uint64_t key0 = keys[0];
     uint64_t diff = 0;
 #pragma unroll
     for (int e = 0; e < KPT; e++) {
         const int i = e * SORT_BLOCK + tid;
-        k[e] = i < n ? keys[s0 + i] : key0;   // the filler never counts: every use is guarded by i < n
+        k[e] = i < n ? keys[i] : key0;   // the filler never counts: every use is guarded by i < n
         diff |= k[e] ^ key0;
     }
     if (tid == 0) {
-        s_diff = 0;
-        s_cnt = 0;
+        L.diff = 0;
+        L.cnt = 0;
     }
     __syncthreads();
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) diff |= __shfl_xor(diff, d);
-    if (lane == 0) atomicOr(&s_diff, (unsigned long long)diff);
+    if (lane == 0) atomicOr(&L.diff, (unsigned long long)diff);
     __syncthreads();
-    int hi = 64 - __builtin_clzll(s_diff);   // bits [hi, 64) are common to all keys; n >= 2 unique keys: hi >= 1
+    int hi = 64 - __builtin_clzll(L.diff);   // bits [hi, 64) are common to all keys; unique keys: hi >= 1
     uint64_t prefix = hi < 64 ? ((key0 >> hi) << hi) : 0ull;
     int r = K;
     while (true) {
         const int w = hi < 8 ? hi : 8;
         const int shift = hi - w;
-        s_hist[tid] = 0;   // SORT_BLOCK == 256 bins
+        L.hist[tid] = 0;   // SORT_BLOCK == 256 bins
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < KPT; e++) {
             const int i = e * SORT_BLOCK + tid;
             if (i < n && (((k[e] ^ prefix) >> shift) >> w) == 0)
-                atomicAdd(&s_hist[(int)((k[e] >> shift) & ((1u << w) - 1))], 1);
+                atomicAdd(&L.hist[(int)((k[e] >> shift) & ((1u << w) - 1))], 1);
         }
         __syncthreads();
         if (tid < 64) {
-            const int h0 = s_hist[4 * lane], h1 = s_hist[4 * lane + 1], h2 = s_hist[4 * lane + 2],
-                      h3 = s_hist[4 * lane + 3];
+            const int h0 = L.hist[4 * lane], h1 = L.hist[4 * lane + 1], h2 = L.hist[4 * lane + 2],
+                      h3 = L.hist[4 * lane + 3];
             const int t = h0 + h1 + h2 + h3;
             int incl = t;
 #pragma unroll
@@ -602,14 +610,14 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_prefix(const int* __re
                         if (r > below + h2) { below += h2; d++; cd = h3; }
                     }
                 }
-                s_state[0] = d;
-                s_state[1] = r - below;
-                s_state[2] = cd;
+                L.state[0] = d;
+                L.state[1] = r - below;
+                L.state[2] = cd;
             }
         }
         __syncthreads();
-        const int d = s_state[0], cd = s_state[2];
-        r = s_state[1];
+        const int d = L.state[0], cd = L.state[2];
+        r = L.state[1];
         prefix |= (uint64_t)d << shift;
         hi = shift;
         if (cd == r || hi == 0) break;   // the whole bucket belongs to the prefix (at hi == 0: one key)
@@ -622,25 +630,17 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_prefix(const int* __re
         const unsigned long long m = __ballot(sel);
         if (m == 0) continue;
         int base = 0;
-        if (lane == __builtin_ctzll(m)) base = atomicAdd(&s_cnt, __builtin_popcountll(m));
+        if (lane == __builtin_ctzll(m)) base = atomicAdd(&L.cnt, __builtin_popcountll(m));
         base = __shfl(base, __builtin_ctzll(m));
-        if (sel) s_sel[base + __builtin_popcountll(m & ((1ull << lane) - 1))] = k[e];
+        if (sel) L.sel[base + __builtin_popcountll(m & ((1ull << lane) - 1))] = k[e];
     }
     __syncthreads();
-    sort1024_4waves(s_sel, s_out, tid);
-    for (int i = tid; i < K; i += SORT_BLOCK) sorted[s0 + i] = s_out[i];
+    sort1024_4waves(L.sel, L.out, tid);
+    for (int i = tid; i < K; i += SORT_BLOCK) sorted[i] = L.out[i];
 }
 
-__global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_global(const int* __restrict__ ranges,
-                                                                 uint64_t* __restrict__ keys,
-                                                                 int* __restrict__ sorted,
-                                                                 int tile0, int64_t cap) {
-    const int tile = tile0 + blockIdx.x;
-    const int s0 = ranges[tile];
-    const int n = ranges[tile + 1] - s0;
-    if (n <= SORT_MAX_LDS_KEYS || (int64_t)s0 + n > cap) return;
-    const int tid = threadIdx.x;
-    uint64_t* gk = keys + s0;
+// pair-wise bitonic network on global memory, in place (lists beyond the LDS classes)
+__device__ __forceinline__ void global_sort_tile(uint64_t* gk, int* __restrict__ sorted, int n, int tid) {
     int n_pad = 2;
     while (n_pad < n) n_pad <<= 1;
     for (int k = 2; k <= n_pad; k <<= 1) {
@@ -668,7 +668,89 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_global(const int* __re
             j = (j == 0) ? (k >> 2) : (j >> 1);
         }
     }
-    for (int i = tid; i < n; i += SORT_BLOCK) sorted[s0 + i] = (int)(uint32_t)gk[i];
+    for (int i = tid; i < n; i += SORT_BLOCK) sorted[i] = (int)(uint32_t)gk[i];
+}
+
+// One workgroup per tile of the band.  By list length n:
+//   n <= 64, <= 256   wave 0 alone (wave_sort<1>, <4>)
+//   n <= 1024         sort1024_4waves on the padded list
+//   n <= 4096         prefix mode: radix select + sort of the nearest 1024; full mode: left to
+//                     k_tile_sort_lds
+//   larger            k_tile_sort_big
+template <bool PREFIX>
+__global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort(
+    const int* __restrict__ ranges,
+                                                          const uint64_t* __restrict__ keys,
+                                                          int* __restrict__ sorted, int tile0,
+                                                          int64_t cap) {
+    __shared__ SortLds L;
+    const int tile = tile0 + blockIdx.x;
+    const int s0 = ranges[tile];
+    const int n = ranges[tile + 1] - s0;
+    if (n <= 0 || n > 4096 || (int64_t)s0 + n > cap) return;
+    const int tid = threadIdx.x;
+    if (n <= 256) {
+        if (tid >= 64) return;
+        if (n <= 64) wave_sort_tile<1>(keys + s0, sorted + s0, n, tid);
+        else wave_sort_tile<4>(keys + s0, sorted + s0, n, tid);
+    } else if (n <= 1024) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = r * SORT_BLOCK + tid;
+            L.sel[i] = i < n ? keys[s0 + i] : ~0ull;
+        }
+        __syncthreads();
+        sort1024_4waves(L.sel, L.out, tid);
+        for (int i = tid; i < n; i += SORT_BLOCK) sorted[s0 + i] = L.out[i];
+    } else if (PREFIX) {
+        prefix_sort_tile<4096 / SORT_BLOCK>(keys + s0, sorted + s0, n, tid, L);
+    }
+}
+
+// The rare long lists: a small grid walks the tiles.  4096 < n <= 8192: prefix mode only (full mode:
+// k_tile_sort_lds); n > 8192: full sort in global memory in both modes.
+template <bool PREFIX>
+__global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_big(const int* __restrict__ ranges,
+                                                              uint64_t* __restrict__ keys,
+                                                              int* __restrict__ sorted, int tile0,
+                                                              int nt, int64_t cap) {
+    __shared__ SortLds L;
+    const int tid = threadIdx.x;
+    for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+        const int s0 = ranges[tile0 + t];
+        const int n = ranges[tile0 + t + 1] - s0;
+        if (n <= 4096 || (int64_t)s0 + n > cap) continue;
+        if (n <= SORT_MAX_LDS_KEYS) {
+            if (!PREFIX) continue;
+            prefix_sort_tile<SORT_MAX_LDS_KEYS / SORT_BLOCK>(keys + s0, sorted + s0, n, tid, L);
+        } else {
+            global_sort_tile(keys + s0, sorted + s0, n, tid);
+        }
+        __syncthreads();
+    }
+}
+
+// full sort of the flagged tiles (repair pass of the prefix mode): a small grid walks the flags
+template <int CAP_HI>
+__global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_flagged(const int* __restrict__ ranges,
+                                                                  const uint64_t* __restrict__ keys,
+                                                                  int* __restrict__ sorted, int tile0,
+                                                                  int nt, int64_t cap,
+                                                                  const int* __restrict__ flags) {
+    extern __shared__ uint64_t s_keys[];
+    const int tid = threadIdx.x;
+    for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+        const int tile = tile0 + t;
+        if (flags[tile] == 0) continue;
+        const int s0 = ranges[tile];
+        const int n = ranges[tile + 1] - s0;
+        if (!prefix_sorted_tile(n, GS_SORT_PREFIX) || n > CAP_HI || (int64_t)s0 + n > cap) continue;
+        for (int i = tid; i < n; i += SORT_BLOCK) s_keys[slot(i)] = keys[s0 + i];
+        __syncthreads();
+        lds_bitonic_sort(s_keys, n, tid);
+        for (int i = tid; i < n; i += SORT_BLOCK) sorted[s0 + i] = (int)(uint32_t)s_keys[slot(i)];
+        __syncthreads();
+    }
 }
 
 static size_t sort_lds_bytes(int cap) { return (size_t)(cap + cap / SORT_R) * sizeof(uint64_t); }
@@ -679,33 +761,56 @@ static void sort_attr_once() {
         (void)hipFuncSetAttribute((const void*)k_tile_sort_lds<4096, 8192>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)sort_lds_bytes(8192));
+        (void)hipFuncSetAttribute((const void*)k_tile_sort_flagged<SORT_MAX_LDS_KEYS>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)sort_lds_bytes(SORT_MAX_LDS_KEYS));
         attr_set = true;
     }
 }
 
+constexpr int WALK_GRID = 512;   // kernels whose work is rare walk the tiles with this many workgroups
+
 static int launch_tile_sort(const int* ranges, uint64_t* keys, int* sorted, int tile0, int nt,
                             int64_t S, int sort_prefix, hipStream_t s) {
     if (nt <= 0) return GS_OK;
-    sort_attr_once();
-    k_tile_sort_lds<0, 1024><<<nt, SORT_BLOCK, sort_lds_bytes(1024), s>>>(ranges, keys, sorted,
-                                                                          tile0, S, nullptr);
+    const int walk = nt < WALK_GRID ? nt : WALK_GRID;
     // larger classes can only be populated if the instance count allows it
     if (sort_prefix > 0) {
-        if (S > 1024)
-            k_tile_sort_prefix<1024, 4096><<<nt, SORT_BLOCK, 0, s>>>(ranges, keys, sorted, tile0, S);
-        if (S > 4096)
-            k_tile_sort_prefix<4096, 8192><<<nt, SORT_BLOCK, 0, s>>>(ranges, keys, sorted, tile0, S);
-    } else {
-        if (S > 1024)
-            k_tile_sort_lds<1024, 4096><<<nt, SORT_BLOCK, sort_lds_bytes(4096), s>>>(
-                ranges, keys, sorted, tile0, S, nullptr);
-        if (S > 4096)
-            k_tile_sort_lds<4096, 8192><<<nt, SORT_BLOCK, sort_lds_bytes(8192), s>>>(
-                ranges, keys, sorted, tile0, S, nullptr);
+        k_tile_sort<true><<<nt, SORT_BLOCK, 0, s>>>(ranges, keys, sorted, tile0, S);
+        if (S > 4096) k_tile_sort_big<true><<<walk, SORT_BLOCK, 0, s>>>(ranges, keys, sorted, tile0, nt, S);
+        return GS_OK;
     }
+    sort_attr_once();
+    k_tile_sort<false><<<nt, SORT_BLOCK, 0, s>>>(ranges, keys, sorted, tile0, S);
+    if (S > 1024)
+        k_tile_sort_lds<1024, 4096><<<nt, SORT_BLOCK, sort_lds_bytes(4096), s>>>(ranges, keys, sorted,
+                                                                             tile0, S);
+    if (S > 4096)
+        k_tile_sort_lds<4096, 8192><<<nt, SORT_BLOCK, sort_lds_bytes(8192), s>>>(ranges, keys, sorted,
+                                                                             tile0, S);
     if (S > SORT_MAX_LDS_KEYS)
-        k_tile_sort_global<<<nt, SORT_BLOCK, 0, s>>>(ranges, keys, sorted, tile0, S);
+        k_tile_sort_big<false><<<walk, SORT_BLOCK, 0, s>>>(ranges, keys, sorted, tile0, nt, S);
     return GS_OK;
+}
+
+// repair pass: tiles of the (1024, 4096] class get the smaller LDS allocation
+static int launch_sort_flagged(const int* ranges, const uint64_t* keys, int* sorted, int tile0,
+                               int nt, int64_t S, const int* flags, hipStream_t s) {
+    if (nt <= 0 || S <= GS_SORT_PREFIX) return GS_OK;   // no tile can have been prefix-sorted
+    sort_attr_once();
+    const int grid = nt < WALK_GRID ? nt : WALK_GRID;
+    if (S <= 4096)
+        k_tile_sort_flagged<4096><<<grid, SORT_BLOCK, sort_lds_bytes(4096), s>>>(
+            ranges, keys, sorted, tile0, nt, S, flags);
+    else
+        k_tile_sort_flagged<SORT_MAX_LDS_KEYS><<<grid, SORT_BLOCK, sort_lds_bytes(SORT_MAX_LDS_KEYS), s>>>(
+            ranges, keys, sorted, tile0, nt, S, flags);
+    return GS_OK;
+}
+
+int sort_flagged_tiles(const int* ranges, const uint64_t* keys, int* sorted, int tile0, int nt,
+                       int64_t S, const int* flags, hipStream_t s) {
+    return launch_sort_flagged(ranges, keys, sorted, tile0, nt, S, flags, s);
 }
 
 }  // namespace gs
@@ -794,16 +899,8 @@ int gs_tile_sort_flagged(const int32_t* tile_ranges, const uint64_t* keys, int64
                          int32_t* sorted_gaussians, void* stream) {
     GS_REQUIRE(tile_flags != nullptr, "tile_flags must not be null");
     GS_REQUIRE(tile_row0 >= 0 && tile_row0 <= tile_row1, "bad tile row range");
-    hipStream_t s = (hipStream_t)stream;
-    const int t0 = tile_row0 * n_tiles_x;
-    const int nt = (tile_row1 - tile_row0) * n_tiles_x;
-    if (nt <= 0 || S <= GS_SORT_PREFIX) return GS_OK;   // no tile can have been prefix-sorted
-    sort_attr_once();
-    k_tile_sort_lds<1024, 4096><<<nt, SORT_BLOCK, sort_lds_bytes(4096), s>>>(
-        tile_ranges, keys, sorted_gaussians, t0, S, tile_flags);
-    if (S > 4096)
-        k_tile_sort_lds<4096, 8192><<<nt, SORT_BLOCK, sort_lds_bytes(8192), s>>>(
-            tile_ranges, keys, sorted_gaussians, t0, S, tile_flags);
+    launch_sort_flagged(tile_ranges, keys, sorted_gaussians, tile_row0 * n_tiles_x,
+                        (tile_row1 - tile_row0) * n_tiles_x, S, tile_flags, (hipStream_t)stream);
     return check_launch("tile_sort_flagged");
 }
 

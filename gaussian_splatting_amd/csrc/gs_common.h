@@ -179,6 +179,10 @@ __host__ __device__ inline bool prefix_sorted_tile(int n, int sort_prefix) {
     return sort_prefix > 0 && n > sort_prefix && n <= SORT_MAX_LDS_KEYS;
 }
 
+// binning.hip: full sort of the tiles with flags[t] != 0 (repair pass of the prefix mode)
+int sort_flagged_tiles(const int* ranges, const uint64_t* keys, int* sorted, int tile0, int nt,
+                       int64_t S, const int* flags, hipStream_t s);
+
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace gs

@@ -272,8 +272,7 @@ __global__ __launch_bounds__(PP_BLOCK) void k_preprocess_bwd(
     const float* __restrict__ xyz, const float* __restrict__ quat, const float* __restrict__ scale,
     const float* __restrict__ M, const float* __restrict__ K, const float* __restrict__ center,
     const int* __restrict__ rank, const float* __restrict__ opacity_act,
-    const float* __restrict__ g_uv, const float* __restrict__ g_conic,
-    const float* __restrict__ g_opa, const float* __restrict__ g_rgb, int N, PreGrad o) {
+    const float* __restrict__ g_slab, int v_base, int N, PreGrad o) {
     constexpr int SHW = 3 * (N_SH - 1);
     // SH gradients (180 B per Gaussian at degree 3) are staged in LDS and written back as one
     // contiguous block with coalesced 16-byte stores
@@ -293,7 +292,10 @@ __global__ __launch_bounds__(PP_BLOCK) void k_preprocess_bwd(
         float c[3];
         to_camera(M, p[0], p[1], p[2], c);
         // colour: precompute_sh.cu:61-111, then the split of cat(rgb, sh) (rasterize.py:89)
-        const float gr[3] = {g_rgb[v * 3 + 0], g_rgb[v * 3 + 1], g_rgb[v * 3 + 2]};
+        // render gradients of visible Gaussian v: row v - v_base of the [*, 9] slab
+        // (rgb 3 | opacity 1 | uv 2 | conic 3)
+        const float* gsl = g_slab + (size_t)(v - v_base) * 9;
+        const float gr[3] = {gsl[0], gsl[1], gsl[2]};
         if constexpr (N_SH == 1) {
             gc[0] = gr[0]; gc[1] = gr[1]; gc[2] = gr[2];
         } else {
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(PP_BLOCK) void k_preprocess_bwd(
         }
         // opacity: d sigmoid = y (1 - y)
         const float y = opacity_act[v];
-        go = g_opa[v] * (1.0f - y) * y;
+        go = gsl[3] * (1.0f - y) * y;
         // conic -> Sigma_world, J (projection_backward.cu:385-471)
         const float q4[4] = {quat[g * 4 + 0], quat[g * 4 + 1], quat[g * 4 + 2], quat[g * 4 + 3]};
         const float s3[3] = {scale[g * 3 + 0], scale[g * 3 + 1], scale[g * 3 + 2]};
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(PP_BLOCK) void k_preprocess_bwd(
         const float fx = K[0], fy = K[4];
         J6[0] = fx / z; J6[1] = 0; J6[2] = -fx * c[0] / z2;
         J6[3] = 0; J6[4] = fy / z; J6[5] = -fy * c[1] / z2;
-        const float gc3[3] = {g_conic[v * 3 + 0], g_conic[v * 3 + 1], g_conic[v * 3 + 2]};
+        const float gc3[3] = {gsl[6], gsl[7], gsl[8]};
         conic_bwd_of(J6, W, S9, gc3, gS9, gJ6);
         // Sigma_world -> quaternion, scale (projection_backward.cu:174-315)
         sigma_world_bwd_of(q4, s3, gS9, gq, gs);
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(PP_BLOCK) void k_preprocess_bwd(
                   gJ6[5] * 2 * c[1] * fy / z3;
         // uv -> camera-frame xyz (projection_backward.cu:9-36; nothing when z <= 0, Q10)
         if (z > 0.0f) {
-            const float gu = g_uv[v * 2 + 0], gv = g_uv[v * 2 + 1];
+            const float gu = gsl[4], gv = gsl[5];
             gcam[0] += gu * (fx / z);
             gcam[1] += gv * (fy / z);
             gcam[2] += gu * (-fx * c[0] / z2) + gv * (-fy * c[1] / z2);
@@ -449,9 +451,8 @@ int gs_preprocess_forward(const void* xyz, const void* quaternion, const void* s
 
 int gs_preprocess_backward(const void* xyz, const void* quaternion, const void* scale, int n_sh,
                            const void* camera_T_world, const void* K, const void* camera_center,
-                           const int32_t* rank, const void* opacity_act, const void* grad_uv,
-                           const void* grad_conic, const void* grad_opacity, const void* grad_rgb,
-                           int N, void* grad_xyz, void* grad_quaternion, void* grad_scale,
+                           const int32_t* rank, const void* opacity_act, const void* grad_slab,
+                           int v_base, int N, void* grad_xyz, void* grad_quaternion, void* grad_scale,
                            void* grad_opacity_logit, void* grad_rgb_param, void* grad_sh,
                            void* stream) {
     GS_REQUIRE(n_sh == 1 || grad_sh != nullptr, "grad_sh must be given when n_sh > 1");
@@ -468,8 +469,7 @@ int gs_preprocess_backward(const void* xyz, const void* quaternion, const void* 
                           (const float*)xyz, (const float*)quaternion, (const float*)scale,
                           (const float*)camera_T_world, (const float*)K,
                           (const float*)camera_center, rank, (const float*)opacity_act,
-                          (const float*)grad_uv, (const float*)grad_conic,
-                          (const float*)grad_opacity, (const float*)grad_rgb, N, o)));
+                          (const float*)grad_slab, v_base, N, o)));
     return check_launch("preprocess_backward");
 }
 

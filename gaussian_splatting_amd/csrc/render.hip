@@ -191,23 +191,23 @@ __device__ inline void splat_colour(const T* s_geom, const T* s_col, int i, cons
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
+// One tile by one workgroup.  sort_prefix > 0: prefix mode (binning.hip "prefix sort"), only the
+// first sort_prefix entries of a prefix-sorted tile's segment are there; tile_flags[tile] is set to
+// whether the tile ran out of them.  flagged_only: the repair call, full list, flags untouched.
 template <typename T, int N_SH>
-__global__ __launch_bounds__(RB) void k_render_fwd(
-    const T* __restrict__ packed, const T* __restrict__ rgb, const T* __restrict__ view_dir,
-    const int* __restrict__ ranges, const int* __restrict__ sorted, const T* __restrict__ bg,
-    int W, int H, int ntx, int tile0, int nt, int* __restrict__ nsp_out, T* __restrict__ fw_out,
-    T* __restrict__ image, int sort_prefix, int* __restrict__ tile_flags, int flagged_only) {
+__device__ __forceinline__ void render_tile_fwd(
+    const int tile, const T* __restrict__ packed, const T* __restrict__ rgb,
+    const T* __restrict__ view_dir, const int* __restrict__ ranges, const int* __restrict__ sorted,
+    const T* __restrict__ bg, int W, int H, int ntx, int* __restrict__ nsp_out,
+    T* __restrict__ fw_out, T* __restrict__ image, int sort_prefix, int* __restrict__ tile_flags,
+    bool flagged_only) {
     constexpr bool fast = sizeof(T) == 4;
     constexpr int CW = ColW<N_SH>::value;
     constexpr int RCHUNK = Chunk<T, N_SH>::value;
     __shared__ alignas(16) T s_geom[RCHUNK * GS_PACKED_WIDTH];
     __shared__ alignas(16) T s_col[N_SH > 1 ? RCHUNK * CW : 4];
 
-    const int t_local = tile_of_block(blockIdx.x, nt);
-    if (t_local >= nt) return;
-    const int tile = tile0 + t_local;
     const int tid = threadIdx.x;
-    if (flagged_only && tile_flags[tile] == 0) return;
     const PixelMap px = pixel_of_thread(tile % ntx, tile / ntx, tid);
     const bool valid = px.u < W && px.v < H;
     const int s0 = ranges[tile];
@@ -300,6 +300,33 @@ __global__ __launch_bounds__(RB) void k_render_fwd(
     }
 }
 
+template <typename T, int N_SH>
+__global__ __launch_bounds__(RB) void k_render_fwd(
+    const T* __restrict__ packed, const T* __restrict__ rgb, const T* __restrict__ view_dir,
+    const int* __restrict__ ranges, const int* __restrict__ sorted, const T* __restrict__ bg,
+    int W, int H, int ntx, int tile0, int nt, int* __restrict__ nsp_out, T* __restrict__ fw_out,
+    T* __restrict__ image, int sort_prefix, int* __restrict__ tile_flags) {
+    const int t_local = tile_of_block(blockIdx.x, nt);
+    if (t_local >= nt) return;
+    render_tile_fwd<T, N_SH>(tile0 + t_local, packed, rgb, view_dir, ranges, sorted, bg, W, H, ntx,
+                             nsp_out, fw_out, image, sort_prefix, tile_flags, false);
+}
+
+// repair pass of the prefix mode: a small grid walks the flags and renders the flagged tiles again,
+// now from their fully sorted lists
+__global__ __launch_bounds__(RB) void k_render_fwd_flagged(
+    const float* __restrict__ packed, const float* __restrict__ rgb, const int* __restrict__ ranges,
+    const int* __restrict__ sorted, const float* __restrict__ bg, int W, int H, int ntx, int tile0,
+    int nt, int* __restrict__ nsp_out, float* __restrict__ fw_out, float* __restrict__ image,
+    int* __restrict__ tile_flags) {
+    for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+        if (tile_flags[tile0 + t] == 0) continue;
+        render_tile_fwd<float, 1>(tile0 + t, packed, rgb, nullptr, ranges, sorted, bg, W, H, ntx,
+                                  nsp_out, fw_out, image, 0, tile_flags, true);
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // wave reductions
 // ---------------------------------------------------------------------------------------------------
@@ -364,7 +391,7 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
     const int* __restrict__ ranges, const int* __restrict__ sorted, const T* __restrict__ bg,
     const int* __restrict__ nsp_in, const T* __restrict__ fw_in, const T* __restrict__ grad_image,
     int W, int H, int ntx, int tile0, int nt, T* __restrict__ g_rgb, T* __restrict__ g_opa,
-    T* __restrict__ g_uv, T* __restrict__ g_conic) {
+    T* __restrict__ g_uv, T* __restrict__ g_conic, int slab) {
     constexpr bool fast = sizeof(T) == 4;
     constexpr int CW = ColW<N_SH>::value;
     constexpr int C = 3 * N_SH;
@@ -531,7 +558,11 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
             bool any = false;
 #pragma unroll
             for (int j = 0; j < NV; j++) any |= (a[j] != T(0));
-            if (any) {
+            if (any && slab) {
+                // one [V, 9] row per Gaussian (rgb 3 | opacity 1 | uv 2 | conic 3): the order of a[]
+#pragma unroll
+                for (int j = 0; j < NV; j++) global_add(g_rgb + (size_t)g * NV + j, a[j]);
+            } else if (any) {
 #pragma unroll
                 for (int j = 0; j < C; j++) global_add(g_rgb + (size_t)g * C + j, a[j]);
                 global_add(g_opa + g, a[C + 0]);
@@ -661,19 +692,17 @@ int gs_render_tiles(const void* packed, const void* rgb, const void* view_dir_by
                                             (const T*)view_dir_by_pixel, tile_ranges,
                                             sorted_gaussians, (const T*)background_rgb, W, H, ntx,
                                             tile_row0 * ntx, nt, num_splats_per_pixel,
-                                            (T*)final_weight_per_pixel, (T*)image, 0, nullptr,
-                                            0))));
+                                            (T*)final_weight_per_pixel, (T*)image, 0,
+                                            nullptr))));
     return check_launch("render_tiles");
 }
 
 int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* tile_ranges,
-                           const int32_t* sorted_gaussians, const void* background_rgb, int W,
-                           int H, int tile_row0, int tile_row1, int sort_prefix,
-                           int32_t* tile_flags, int flagged_only, int32_t* num_splats_per_pixel,
+                           int32_t* sorted_gaussians, const uint64_t* keys, int64_t S,
+                           const void* background_rgb, int W, int H, int tile_row0, int tile_row1,
+                           int32_t* tile_flags, int32_t* num_splats_per_pixel,
                            void* final_weight_per_pixel, void* image, void* stream) {
     GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
-    GS_REQUIRE(sort_prefix == GS_SORT_PREFIX, "sort_prefix must be GS_SORT_PREFIX (%d)",
-               GS_SORT_PREFIX);
     GS_REQUIRE(tile_flags != nullptr, "tile_flags must not be null");
     if (int e = check_rows(H, tile_row0, tile_row1)) return e;
     hipStream_t s = (hipStream_t)stream;
@@ -681,10 +710,20 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
     const int nt = (tile_row1 - tile_row0) * ntx;
     if (nt == 0) return GS_OK;
     const int grid = ((nt + 7) / 8) * 8;
+    const int t0 = tile_row0 * ntx;
+    // 1. provisional pass over the ordered prefixes; raises the flags
     k_render_fwd<float, 1><<<grid, RB, 0, s>>>(
         (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
-        (const float*)background_rgb, W, H, ntx, tile_row0 * ntx, nt, num_splats_per_pixel,
-        (float*)final_weight_per_pixel, (float*)image, sort_prefix, tile_flags, flagged_only);
+        (const float*)background_rgb, W, H, ntx, t0, nt, num_splats_per_pixel,
+        (float*)final_weight_per_pixel, (float*)image, GS_SORT_PREFIX, tile_flags);
+    if (S > GS_SORT_PREFIX) {
+        // 2. + 3. flagged tiles: full sort, render again (no-ops on a dense scene)
+        sort_flagged_tiles(tile_ranges, keys, sorted_gaussians, t0, nt, S, tile_flags, s);
+        k_render_fwd_flagged<<<nt < 512 ? nt : 512, RB, 0, s>>>(
+            (const float*)packed, (const float*)rgb, tile_ranges, sorted_gaussians,
+            (const float*)background_rgb, W, H, ntx, t0, nt, num_splats_per_pixel,
+            (float*)final_weight_per_pixel, (float*)image, tile_flags);
+    }
     return check_launch("render_tiles_prefix");
 }
 
@@ -709,8 +748,29 @@ int gs_render_tiles_backward(const void* packed, const void* rgb, const void* vi
                                      num_splats_per_pixel, (const T*)final_weight_per_pixel,
                                      (const T*)grad_image, W, H, ntx, tile_row0 * ntx, nt,
                                      (T*)grad_rgb, (T*)grad_opacity, (T*)grad_uv,
-                                     (T*)grad_conic))));
+                                     (T*)grad_conic, 0))));
     return check_launch("render_tiles_backward");
+}
+
+int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int32_t* tile_ranges,
+                                  const int32_t* sorted_gaussians, const void* background_rgb,
+                                  const int32_t* num_splats_per_pixel,
+                                  const void* final_weight_per_pixel, const void* grad_image, int W,
+                                  int H, int tile_row0, int tile_row1, void* grad_slab,
+                                  void* stream) {
+    GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
+    if (int e = check_rows(H, tile_row0, tile_row1)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    const int ntx = (W + 15) / 16;
+    const int nt = (tile_row1 - tile_row0) * ntx;
+    if (nt == 0) return GS_OK;
+    const int grid = ((nt + 7) / 8) * 8;
+    k_render_bwd<float, 1><<<grid, RB, 0, s>>>(
+        (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
+        (const float*)background_rgb, num_splats_per_pixel, (const float*)final_weight_per_pixel,
+        (const float*)grad_image, W, H, ntx, tile_row0 * ntx, nt, (float*)grad_slab, nullptr,
+        nullptr, nullptr, 1);
+    return check_launch("render_tiles_backward_slab");
 }
 
 int gs_render_depth(const void* packed, const void* xyz_camera_frame, const int32_t* tile_ranges,

@@ -7,15 +7,19 @@ Two autograd nodes instead of six-plus-glue:
 
     _Preprocess   gs_preprocess_forward + tile binning + per-tile sort   (parameters -> uv, conic,
                   opacity, colour; non-differentiable: packed records, tile lists, culling mask)
-    _Render       gs_render_tiles / gs_render_tiles_backward
+    _Render       gs_render_tiles(_prefix) / gs_render_tiles_backward_slab
 
 so `uv` is still an autograd intermediate between two nodes: `uv.retain_grad()` followed by
 `uv.grad` gives the render-backward grad_uv exactly as the trainer expects (trainer.py:360,379).
-One 8-byte device->host read per frame (V and S, to size the outputs); the reference has ~25
+One small device->host read per frame (V and S, to size the outputs); the reference has ~25
 synchronisation points.  fp32, SH-precompute colour mode; anything else is routed
 to the reference-shaped path in splat_py.rasterize (still HIP kernels, never a CPU fallback).
+
+The four stages are plain functions (preprocess_forward, render_forward, render_backward,
+preprocess_backward) that gaussian_splatting_amd.sharded composes differently for multi-GPU frames.
 """
 import ctypes
+from types import SimpleNamespace
 
 import torch
 
@@ -46,174 +50,224 @@ last_tile_flags = None   # int32[T] of the latest prefix-mode frame: 1 = the til
 _capacity_hint = {}   # (device, N, tiles, band) -> instance capacity guessed from the previous frame
 _pinned = {}
 
+SLAB_WIDTH = 9   # render gradients per visible Gaussian: rgb 3 | opacity 1 | uv 2 | conic 3
+SLAB_RGB, SLAB_OPACITY, SLAB_UV, SLAB_CONIC = slice(0, 3), slice(3, 4), slice(4, 6), slice(6, 9)
 
-def _pinned_pair(dev):
-    buf = _pinned.get(dev.index)
+
+def _pinned_ints(dev, n):
+    buf = _pinned.get((dev.index, n))
     if buf is None:
-        buf = torch.empty(2, dtype=torch.int32, pin_memory=True)
-        _pinned[dev.index] = buf
+        buf = torch.empty(n, dtype=torch.int32, pin_memory=True)
+        _pinned[(dev.index, n)] = buf
     return buf
 
 
+# ---------------------------------------------------------------------------------------------------
+# stages
+# ---------------------------------------------------------------------------------------------------
+def preprocess_forward(xyz, quaternion, scale, opacity, rgb, sh, camera_T_world, K, width, height, near_thresh,
+                       far_thresh, cull_mask_padding, mh_dist, tile_rows, sort_prefix, plan=None):
+    """Per-Gaussian stage, binning and per-tile sort of one frame.  `plan`, if given, is called as
+    plan(f) after the tile count is enqueued and returns a device int32 tensor whose first two
+    entries are (S, V); it is read back instead of the plain (S, V) pair and the host copy is left
+    in f.host (multi-GPU: the split sizes of the gradient exchange ride along)."""
+    dev = xyz.device
+    N = xyz.shape[0]
+    n_sh = 1 if sh is None else sh.shape[2] + 1
+    f32 = dict(dtype=torch.float32, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    ntx = (width + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
+    nty = (height + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
+    T = ntx * nty
+    row0, row1 = tile_rows if tile_rows is not None else (0, nty)
+    f = SimpleNamespace(N=N, n_sh=n_sh, ntx=ntx, nty=nty, T=T, row0=row0, row1=row1, width=width, height=height,
+                        mh_dist=mh_dist, sort_prefix=sort_prefix)
+
+    f.ws = torch.empty(_hip.lib().gs_preprocess_workspace_ints(N), **i32)
+    f.center = torch.empty(3, **f32)
+    f.count = torch.empty(1, **i32)
+    f.culling_mask = torch.empty(N, dtype=torch.bool, device=dev)   # kernel writes 0/1 bytes
+    f.rank = torch.empty(N, **i32)
+    f.vis_idx = torch.empty(N, **i32)
+    f.uv = torch.empty(N, 2, **f32)
+    f.xyz_cam = torch.empty(N, 3, **f32)
+    f.conic = torch.empty(N, 3, **f32)
+    f.opacity_act = torch.empty(N, 1, **f32)
+    f.rgb_render = torch.empty(N, 3, **f32)
+    f.packed = torch.empty(N, 12, **f32)
+    _hip.call("gs_preprocess_forward", _p(xyz), _p(quaternion), _p(scale), _p(opacity), _p(rgb), _p(sh), n_sh,
+              _p(camera_T_world), _p(K), N, width, height, _cf(near_thresh), _cf(far_thresh),
+              _cf(cull_mask_padding), _cf(mh_dist), row0, row1, _p(f.ws), _p(f.center), _p(f.count),
+              _p(f.culling_mask), _p(f.rank), _p(f.vis_idx), _p(f.uv), _p(f.xyz_cam), _p(f.conic),
+              _p(f.opacity_act), _p(f.rgb_render), _p(f.packed), _stream())
+
+    f.tile_counts = torch.empty(_hip.lib().gs_tile_workspace_ints(T), **i32)
+    f.ranges_buf = torch.empty(T + 2, **i32)
+    _hip.call("gs_tile_count", _p(f.uv), _p(f.conic), N, _p(f.count), ntx, nty, _cf(mh_dist), row0, row1,
+              _p(f.tile_counts), _p(f.ranges_buf), _stream())
+    record = plan(f) if plan is not None else f.ranges_buf[T:T + 2]
+
+    def emit_sort(capacity):
+        sorted_buf = torch.empty(capacity, **i32)
+        keys = torch.empty(capacity, dtype=torch.int64, device=dev)
+        if capacity > 0:
+            _hip.call("gs_tile_emit_sort", _p(f.uv), _p(f.xyz_cam), _p(f.conic), N, _p(f.count), ntx, nty,
+                      _cf(mh_dist), row0, row1, _p(f.ranges_buf), _p(f.tile_counts), _p(keys),
+                      ctypes.c_int64(capacity), _p(sorted_buf), sort_prefix, _stream())
+        return sorted_buf, keys
+
+    # The frame's only device->host read: (S, V) [+ the plan's record], to size the outputs.  If a
+    # previous frame of the same shape is known, the emit + sort are enqueued first with a capacity
+    # guessed from it, so the GPU keeps working while the host waits for the integers; the kernels
+    # never write beyond the capacity and the step is repeated only if S turned out larger.
+    key = (dev.index, N, T, row0, row1)
+    guess = _capacity_hint.get(key)
+    host = _pinned_ints(dev, record.numel())
+    if guess is not None:
+        host.copy_(record, non_blocking=True)
+        ready = torch.cuda.Event()
+        ready.record()
+        sorted_buf, keys = emit_sort(guess)
+        ready.synchronize()
+        S, V = int(host[0]), int(host[1])
+        if S > guess:
+            sorted_buf, keys = emit_sort(S)
+    else:
+        host.copy_(record)
+        S, V = int(host[0]), int(host[1])
+        sorted_buf, keys = emit_sort(S)
+    _capacity_hint[key] = int(S * 1.25) + 4096
+    f.host = host.tolist()
+    f.S, f.V = S, V
+    f.sorted_g = sorted_buf[:S]
+    f.keys = keys[:S]   # prefix mode: the repair pass of the render sorts flagged tiles from these
+    f.ranges = f.ranges_buf[:T + 1]
+    return f
+
+
+def preprocess_backward(xyz, quaternion, scale, camera_T_world, K, f, slab, v_base=0, i0=0, i1=None):
+    """Dense parameter gradients of the Gaussians [i0, i1) from the render-gradient slab
+    (row of visible Gaussian v at slab[v - v_base]).  xyz, quaternion, scale: the full tensors."""
+    i1 = f.N if i1 is None else i1
+    n = i1 - i0
+    dev = xyz.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    grad_xyz = torch.empty(n, 3, **f32)
+    grad_q = torch.empty(n, 4, **f32)
+    grad_scale = torch.empty(n, 3, **f32)
+    grad_opacity = torch.empty(n, 1, **f32)
+    grad_rgb = torch.empty(n, 3, **f32)
+    grad_sh = torch.empty(n, 3, f.n_sh - 1, **f32) if f.n_sh > 1 else None
+    if n > 0:
+        _hip.call("gs_preprocess_backward", _p(xyz[i0:i1]), _p(quaternion[i0:i1]), _p(scale[i0:i1]), f.n_sh,
+                  _p(camera_T_world), _p(K), _p(f.center), _p(f.rank[i0:i1]), _p(f.opacity_act), _p(slab),
+                  int(v_base), n, _p(grad_xyz), _p(grad_q), _p(grad_scale), _p(grad_opacity), _p(grad_rgb),
+                  _p(grad_sh), _stream())
+    return grad_xyz, grad_q, grad_scale, grad_opacity, grad_rgb, grad_sh
+
+
+def render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, width, tile_rows, sort_prefix):
+    dev = packed.device
+    ntx = (width + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
+    nty = (height + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
+    row0, row1 = tile_rows if tile_rows is not None else (0, nty)
+    # rows outside [row0, row1) are not written by the kernel: zero-fill only when sharded
+    alloc = torch.empty if tile_rows is None else torch.zeros
+    image = alloc(height, width, 3, dtype=torch.float32, device=dev)
+    nsp = alloc(height, width, dtype=torch.int32, device=dev)
+    fw = alloc(height, width, dtype=torch.float32, device=dev)
+    if sort_prefix and sorted_g.shape[0] > sort_prefix:
+        # provisional render from the ordered prefixes; tiles that ran out of prefix are flagged,
+        # sorted in full and rendered again -- one call, the host never looks at the flags
+        flags = torch.empty(ntx * nty, dtype=torch.int32, device=dev)
+        _hip.call("gs_render_tiles_prefix", _p(packed), _p(rgb), _p(ranges), _p(sorted_g), _p(keys),
+                  ctypes.c_int64(sorted_g.shape[0]), _p(background_rgb), width, height, row0, row1, _p(flags),
+                  _p(nsp), _p(fw), _p(image), _stream())
+        global last_tile_flags
+        last_tile_flags = flags
+    else:
+        _hip.call("gs_render_tiles", _p(packed), _p(rgb), None, _p(ranges), _p(sorted_g), _p(background_rgb),
+                  width, height, 1, row0, row1, _p(nsp), _p(fw), _p(image), _hip.GS_F32, _stream())
+    return image, nsp, fw
+
+
+def render_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, grad_image, height, width, tile_rows,
+                    V):
+    """-> the slab [V, 9] of accumulated render gradients (rgb 3 | opacity 1 | uv 2 | conic 3)"""
+    nty = (height + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
+    row0, row1 = tile_rows if tile_rows is not None else (0, nty)
+    slab = torch.zeros(max(V, 1), SLAB_WIDTH, dtype=torch.float32, device=packed.device)
+    _hip.call("gs_render_tiles_backward_slab", _p(packed), _p(rgb), _p(ranges), _p(sorted_g), _p(background_rgb),
+              _p(nsp), _p(fw), _p(grad_image), width, height, row0, row1, _p(slab), _stream())
+    return slab[:V]
+
+
+def _as_slab(g_uv, g_conic, g_opa, g_rgb, V, dev):
+    """the four render gradients as one [V, 9] slab: the slab they are views of when they come
+    straight from _Render.backward, a packed copy otherwise (outputs nobody consumed count as 0)"""
+    parts = ((g_rgb, SLAB_RGB), (g_opa, SLAB_OPACITY), (g_uv, SLAB_UV), (g_conic, SLAB_CONIC))
+    base = g_rgb._base if g_rgb is not None else None
+    if (base is not None and base.dim() == 2 and base.shape[1] == SLAB_WIDTH and base.is_contiguous()
+            and all(g is not None and g._base is base and g.shape[0] == V and g.stride() == (SLAB_WIDTH, 1)
+                    and g.storage_offset() == base.storage_offset() + sl.start for g, sl in parts)):
+        return base
+    slab = torch.zeros(max(V, 1), SLAB_WIDTH, dtype=torch.float32, device=dev)
+    for g, sl in parts:
+        if g is not None:
+            slab[:V, sl] = g
+    return slab
+
+
+# ---------------------------------------------------------------------------------------------------
+# autograd nodes
+# ---------------------------------------------------------------------------------------------------
 class _Preprocess(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, quaternion, scale, opacity, rgb, sh, camera_T_world, K, width, height, near_thresh,
                 far_thresh, cull_mask_padding, mh_dist, tile_rows, sort_prefix=0):
-        dev = xyz.device
-        N = xyz.shape[0]
-        n_sh = 1 if sh is None else sh.shape[2] + 1
-        f32 = dict(dtype=torch.float32, device=dev)
-        i32 = dict(dtype=torch.int32, device=dev)
-        ntx = (width + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
-        nty = (height + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
-        T = ntx * nty
-        row0, row1 = tile_rows if tile_rows is not None else (0, nty)
-
-        ws = torch.empty(_hip.lib().gs_preprocess_workspace_ints(N), **i32)
-        center = torch.empty(3, **f32)
-        count = torch.empty(1, **i32)
-        culling_mask = torch.empty(N, dtype=torch.bool, device=dev)   # kernel writes 0/1 bytes
-        rank = torch.empty(N, **i32)
-        vis_idx = torch.empty(N, **i32)
-        uv = torch.empty(N, 2, **f32)
-        xyz_cam = torch.empty(N, 3, **f32)
-        conic = torch.empty(N, 3, **f32)
-        opacity_act = torch.empty(N, 1, **f32)
-        rgb_render = torch.empty(N, 3, **f32)
-        packed = torch.empty(N, 12, **f32)
-        _hip.call("gs_preprocess_forward", _p(xyz), _p(quaternion), _p(scale), _p(opacity), _p(rgb), _p(sh), n_sh,
-                  _p(camera_T_world), _p(K), N, width, height, _cf(near_thresh), _cf(far_thresh),
-                  _cf(cull_mask_padding), _cf(mh_dist), row0, row1, _p(ws), _p(center), _p(count), _p(culling_mask), _p(rank), _p(vis_idx), _p(uv),
-                  _p(xyz_cam), _p(conic), _p(opacity_act), _p(rgb_render), _p(packed), _stream())
-
-        tile_counts = torch.empty(_hip.lib().gs_tile_workspace_ints(T), **i32)
-        ranges = torch.empty(T + 2, **i32)
-        _hip.call("gs_tile_count", _p(uv), _p(conic), N, _p(count), ntx, nty, _cf(mh_dist), row0, row1,
-                  _p(tile_counts), _p(ranges), _stream())
-        def emit_sort(capacity):
-            sorted_buf = torch.empty(capacity, **i32)
-            keys = torch.empty(capacity, dtype=torch.int64, device=dev)
-            if capacity > 0:
-                _hip.call("gs_tile_emit_sort", _p(uv), _p(xyz_cam), _p(conic), N, _p(count), ntx, nty, _cf(mh_dist),
-                          row0, row1, _p(ranges), _p(tile_counts), _p(keys), ctypes.c_int64(capacity),
-                          _p(sorted_buf), sort_prefix, _stream())
-            return sorted_buf, keys
-
-        # The frame's only device->host read: (S, V), 8 bytes, to size the outputs.  If a previous
-        # frame of the same shape is known, the emit + sort are enqueued first with a capacity guessed
-        # from it, so the GPU keeps working while the host waits for the two integers; the kernels
-        # never write beyond the capacity and the step is repeated only if S turned out larger.
-        key = (dev.index, N, T, row0, row1)
-        guess = _capacity_hint.get(key)
-        if guess is not None:
-            host = _pinned_pair(dev)
-            host.copy_(ranges[T:T + 2], non_blocking=True)
-            ready = torch.cuda.Event()
-            ready.record()
-            sorted_buf, keys = emit_sort(guess)
-            ready.synchronize()
-            S, V = int(host[0]), int(host[1])
-            if S > guess:
-                sorted_buf, keys = emit_sort(S)
-        else:
-            S, V = ranges[T:T + 2].tolist()
-            sorted_buf, keys = emit_sort(S)
-        _capacity_hint[key] = int(S * 1.25) + 4096
-        sorted_g = sorted_buf[:S]
-        keys = keys[:S]   # prefix mode: the repair pass of _Render sorts flagged tiles from these
-
-        ctx.save_for_backward(xyz, quaternion, scale, camera_T_world, K, center, rank, opacity_act)
+        f = preprocess_forward(xyz, quaternion, scale, opacity, rgb, sh, camera_T_world, K, width, height,
+                               near_thresh, far_thresh, cull_mask_padding, mh_dist, tile_rows, sort_prefix)
+        V = f.V
+        ctx.save_for_backward(xyz, quaternion, scale, camera_T_world, K)
         ctx.set_materialize_grads(False)   # no zero tensors for the auxiliary outputs in backward
-        ctx.V = V
-        ctx.n_sh = n_sh
-        ctx.sh_shape = None if sh is None else tuple(sh.shape)
-        uv_v, conic_v, opa_v, rgb_v = uv[:V], conic[:V], opacity_act[:V], rgb_render[:V]
-        aux = (packed, xyz_cam[:V], culling_mask, ranges[:T + 1], sorted_g, vis_idx[:V], keys)
+        ctx.f = SimpleNamespace(N=f.N, V=V, n_sh=f.n_sh, center=f.center, rank=f.rank, opacity_act=f.opacity_act)
+        uv_v, conic_v, opa_v, rgb_v = f.uv[:V], f.conic[:V], f.opacity_act[:V], f.rgb_render[:V]
+        aux = (f.packed, f.xyz_cam[:V], f.culling_mask, f.ranges, f.sorted_g, f.vis_idx[:V], f.keys)
         ctx.mark_non_differentiable(*aux)
         return (uv_v, conic_v, opa_v, rgb_v) + aux
 
     @staticmethod
     def backward(ctx, g_uv, g_conic, g_opa, g_rgb, *unused):
-        xyz, quaternion, scale, camera_T_world, K, center, rank, opacity_act = ctx.saved_tensors
-        N = xyz.shape[0]
-        V = ctx.V
-        dev = xyz.device
-
-        def dense(g, width):   # an output nobody consumed has no gradient: zeros
-            if g is None:
-                return torch.zeros(max(V, 1), width, dtype=torch.float32, device=dev)
-            return g.contiguous()
-
-        g_uv, g_conic, g_opa, g_rgb = dense(g_uv, 2), dense(g_conic, 3), dense(g_opa, 1), dense(g_rgb, 3)
-        f32 = dict(dtype=torch.float32, device=dev)
-        grad_xyz = torch.empty(N, 3, **f32)
-        grad_q = torch.empty(N, 4, **f32)
-        grad_scale = torch.empty(N, 3, **f32)
-        grad_opacity = torch.empty(N, 1, **f32)
-        grad_rgb = torch.empty(N, 3, **f32)
-        grad_sh = torch.empty(ctx.sh_shape, **f32) if ctx.sh_shape is not None else None
-        _hip.call("gs_preprocess_backward", _p(xyz), _p(quaternion), _p(scale), ctx.n_sh, _p(camera_T_world), _p(K),
-                  _p(center), _p(rank), _p(opacity_act), _p(g_uv), _p(g_conic), _p(g_opa), _p(g_rgb), N,
-                  _p(grad_xyz), _p(grad_q), _p(grad_scale), _p(grad_opacity), _p(grad_rgb), _p(grad_sh), _stream())
-        return (grad_xyz, grad_q, grad_scale, grad_opacity, grad_rgb, grad_sh) + (None,) * 10
+        xyz, quaternion, scale, camera_T_world, K = ctx.saved_tensors
+        slab = _as_slab(g_uv, g_conic, g_opa, g_rgb, ctx.f.V, xyz.device)
+        grads = preprocess_backward(xyz, quaternion, scale, camera_T_world, K, ctx.f, slab)
+        return grads + (None,) * 10
 
 
 class _Render(torch.autograd.Function):
     @staticmethod
     def forward(ctx, uv, conic, opacity, rgb, packed, ranges, sorted_g, background_rgb, height, width, tile_rows,
                 slab_sync=None, keys=None, sort_prefix=0):
-        dev = uv.device
-        ntx = (width + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
-        nty = (height + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
-        row0, row1 = tile_rows if tile_rows is not None else (0, nty)
-        # rows outside [row0, row1) are not written by the kernel: zero-fill only when sharded
-        alloc = torch.empty if tile_rows is None else torch.zeros
-        image = alloc(height, width, 3, dtype=torch.float32, device=dev)
-        nsp = alloc(height, width, dtype=torch.int32, device=dev)
-        fw = alloc(height, width, dtype=torch.float32, device=dev)
-        if sort_prefix and sorted_g.shape[0] > sort_prefix:
-            # provisional render from the ordered prefixes; tiles that ran out of prefix are flagged,
-            # sorted in full and rendered again -- three enqueues, the host never looks at the flags
-            flags = torch.empty(ntx * nty, dtype=torch.int32, device=dev)
-            S = ctypes.c_int64(sorted_g.shape[0])
-            args = (_p(packed), _p(rgb), _p(ranges), _p(sorted_g), _p(background_rgb), width, height, row0, row1,
-                    sort_prefix, _p(flags))
-            outs = (_p(nsp), _p(fw), _p(image), _stream())
-            _hip.call("gs_render_tiles_prefix", *args, 0, *outs)
-            _hip.call("gs_tile_sort_flagged", _p(ranges), _p(keys), S, _p(flags), ntx, row0, row1, _p(sorted_g),
-                      _stream())
-            _hip.call("gs_render_tiles_prefix", *args, 1, *outs)
-            global last_tile_flags
-            last_tile_flags = flags
-        else:
-            _hip.call("gs_render_tiles", _p(packed), _p(rgb), None, _p(ranges), _p(sorted_g), _p(background_rgb),
-                      width, height, 1, row0, row1, _p(nsp), _p(fw), _p(image), _hip.GS_F32, _stream())
+        image, nsp, fw = render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, width,
+                                        tile_rows, sort_prefix)
         ctx.save_for_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw)
         ctx.set_materialize_grads(False)
-        ctx.dims = (height, width, row0, row1, uv.shape[0])
+        ctx.dims = (height, width, tile_rows, uv.shape[0])
         ctx.slab_sync = slab_sync
         return image
 
     @staticmethod
     def backward(ctx, grad_image):
         packed, rgb, ranges, sorted_g, background_rgb, nsp, fw = ctx.saved_tensors
-        height, width, row0, row1, V = ctx.dims
-        dev = packed.device
+        height, width, tile_rows, V = ctx.dims
         if grad_image is None:
             return (None,) * 14
-        grad_image = grad_image.contiguous()
-        # one zero-filled slab [V, 9]: rgb 3 | opacity 1 | uv 2 | conic 3 (atomicAdd targets)
-        slab = torch.zeros(9 * V, dtype=torch.float32, device=dev)
-        g_rgb = slab[0:3 * V].view(V, 3)
-        g_opa = slab[3 * V:4 * V].view(V, 1)
-        g_uv = slab[4 * V:6 * V].view(V, 2)
-        g_conic = slab[6 * V:9 * V].view(V, 3)
-        _hip.call("gs_render_tiles_backward", _p(packed), _p(rgb), None, _p(ranges), _p(sorted_g),
-                  _p(background_rgb), _p(nsp), _p(fw), _p(grad_image), width, height, 1, row0, row1, _p(g_rgb),
-                  _p(g_opa), _p(g_uv), _p(g_conic), _hip.GS_F32, _stream())
+        slab = render_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, grad_image.contiguous(),
+                               height, width, tile_rows, V)
         if ctx.slab_sync is not None:
-            ctx.slab_sync(slab)   # multi-GPU: sum the partial per-Gaussian gradients of all bands in place
-        return (g_uv, g_conic, g_opa, g_rgb) + (None,) * 10
+            ctx.slab_sync(slab.view(-1))   # multi-GPU: sum the partial gradients of all bands in place
+        # the four gradients are views of the one slab; _Preprocess.backward recognises that
+        return (slab[:, SLAB_UV], slab[:, SLAB_CONIC], slab[:, SLAB_OPACITY], slab[:, SLAB_RGB]) + (None,) * 10
 
 
 def supported(gaussians, camera_T_world, camera, use_sh_precompute):

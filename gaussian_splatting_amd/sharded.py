@@ -2,22 +2,39 @@
 SURVEY.md 8(e)).  One process per GPU, torch.distributed over RCCL/xGMI (backend "nccl"); the same
 code runs over gloo on CPU tensors for tests.
 
-Per frame, on every rank (Gaussian parameters are replicated, as in data-parallel training):
+Per frame, on every rank (Gaussian parameters are replicated):
   forward   per-Gaussian stage for all N (cheap, replicated) -> binning, sort and render ONLY for the
             rank's band of tile rows -> all-reduce(SUM) of the image: every other rank contributes
             zeros outside its band, so the sum is the gather (12 B/px, ~13 MB at 1 MP).
   backward  every rank holds the same grad_image (the loss is evaluated on the gathered image on
             every rank); render backward over the rank's band gives PARTIAL per-Gaussian gradients
-            (uv 2, conic 3, opacity 1, colour 3 floats: a Gaussian can straddle bands) ->
-            all-reduce(SUM) of that [V, 9] slab (36 B per visible Gaussian, ~100 MB at 2.86 M) ->
-            the per-Gaussian backward runs replicated and yields identical dense parameter
-            gradients on every rank.
+            (colour 3, opacity 1, uv 2, conic 3 floats: a Gaussian can straddle bands).  Then, by
+            grad_mode:
+
+  "replicated"  all-reduce(SUM) of that [V, 9] slab (36 B per visible Gaussian, ~100 MB at 2.86 M),
+            per-Gaussian backward replicated -> identical dense parameter gradients on every rank.
+            Same contract as the single-GPU function, but the all-reduce and the replicated
+            backward bound the speed-up.
+  "owner"   rank r owns the Gaussians of an index slice (owner_range) and produces the parameter
+            gradients of that slice only, the way a sharded optimizer wants them.  The partial rows
+            travel sparsely: every rank can tell from the replicated projection which bands a
+            Gaussian reaches (HaloPlan), so ONE all_to_all moves a row only from a rank whose band
+            the Gaussian reaches to the Gaussian's owner (~36 B x Gaussians-reaching-the-band per
+            rank instead of 36 B x V), and the per-Gaussian backward runs on the owned slice.
+
 Tile lists of a band equal the single-GPU lists restricted to the band (tested bit-exactly), so
 the sharded image equals the single-GPU image bit for bit and gradients differ only by fp32
 summation order.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
+
+from .splat_py.structs import Gaussians
+
+OWNER_BLOCK = 256   # owner slices are whole blocks of the per-Gaussian kernels (csrc/halo.hip)
+SLAB_WIDTH = 9      # rgb 3 | opacity 1 | uv 2 | conic 3
 
 
 def band_of(n_tile_rows, world_size, rank):
@@ -27,6 +44,139 @@ def band_of(n_tile_rows, world_size, rank):
     return row0, row0 + base + (1 if rank < rem else 0)
 
 
+def owner_blocks(N, world_size):
+    """Boundaries, in blocks of OWNER_BLOCK Gaussians, of the index slices the ranks own."""
+    nb = (max(N, 1) + OWNER_BLOCK - 1) // OWNER_BLOCK
+    return [(nb * r) // world_size for r in range(world_size + 1)]
+
+
+def owner_range(N, world_size, rank):
+    """[i0, i1): the Gaussians whose parameter gradients `rank` produces in grad_mode "owner"."""
+    b = owner_blocks(N, world_size)
+    return min(N, OWNER_BLOCK * b[rank]), min(N, OWNER_BLOCK * b[rank + 1])
+
+
+def owned_slice(gaussians, world_size, rank, requires_grad=True):
+    """Leaf copies of the slice of every parameter that `rank` owns (what a sharded optimizer holds)."""
+    i0, i1 = owner_range(gaussians.xyz.shape[0], world_size, rank)
+
+    def cut(t):
+        return None if t is None else t.detach()[i0:i1].clone().requires_grad_(requires_grad)
+
+    g = gaussians
+    return Gaussians(cut(g.xyz), cut(g.rgb), cut(g.opacity), cut(g.scale), cut(g.quaternion), cut(g.sh))
+
+
+# ---------------------------------------------------------------------------------------------------
+# sparse exchange of the partial render gradients
+# ---------------------------------------------------------------------------------------------------
+class HaloPlan:
+    """Who sends which rows of the [V, 9] slab to whom, for one frame and one rank (csrc/halo.hip).
+
+    mask[v] bit s: visible Gaussian v reaches the band of rank s.  The send buffer of this rank is
+    slab[send_index] (visible indices with this rank's bit, ascending == grouped by owner),
+    send_splits[r] rows for owner r; from sender s this rank receives recv_splits[s] rows: its own
+    visible range [v_lo, v_hi) restricted to bit s, ascending."""
+
+    def __init__(self, world_size, rank, mask, send_index, send_splits, recv_splits, v_lo, v_hi, hip=None):
+        self.world_size, self.rank = world_size, rank
+        self.mask, self.send_index = mask, send_index
+        self.send_splits, self.recv_splits = list(send_splits), list(recv_splits)
+        self.v_lo, self.v_hi = v_lo, v_hi
+        self.hip = hip   # (N, workspace) when built by gs_halo_plan
+
+    @staticmethod
+    def reference(mask, v_bounds, world_size, rank):
+        """Plain-PyTorch construction from the masks of the visible Gaussians and the visible-index
+        bounds of the owner slices (any device; the checker of the HIP construction and the plan of
+        the reference-shaped path)."""
+        bit = (mask >> rank) & 1
+        send_index = torch.nonzero(bit, as_tuple=False).flatten()
+        bounds = torch.as_tensor(v_bounds, device=send_index.device)
+        cuts = torch.searchsorted(send_index, bounds).tolist()
+        send_splits = [cuts[r + 1] - cuts[r] for r in range(world_size)]
+        v_lo, v_hi = int(v_bounds[rank]), int(v_bounds[rank + 1])
+        mine = mask[v_lo:v_hi]
+        recv_splits = [int(((mine >> s) & 1).sum()) for s in range(world_size)]
+        return HaloPlan(world_size, rank, mask, send_index, send_splits, recv_splits, v_lo, v_hi)
+
+    def pack(self, slab):
+        return slab.index_select(0, self.send_index)
+
+    def unpack(self, recv):
+        """[sum(recv_splits), 9] -> the summed rows of the owned visible range [v_hi - v_lo, 9]"""
+        n = self.v_hi - self.v_lo
+        out = torch.zeros(max(n, 1), SLAB_WIDTH, dtype=recv.dtype, device=recv.device)[:n]
+        if n == 0:
+            return out
+        if self.hip is not None:
+            from . import _hip
+            N, workspace = self.hip
+            off, offsets = 0, []
+            for c in self.recv_splits:
+                offsets.append(off)
+                off += c
+            offs = (ctypes.c_int32 * len(offsets))(*offsets)
+            _hip.call("gs_halo_gather_sum", ctypes.c_void_p(self.mask.data_ptr()),
+                      ctypes.c_void_p(workspace.data_ptr()), N, self.world_size, self.rank, self.v_lo, self.v_hi,
+                      ctypes.c_void_p(recv.data_ptr()), offs, ctypes.c_void_p(out.data_ptr()),
+                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            return out
+        mine = self.mask[self.v_lo:self.v_hi]
+        off = 0
+        for s, c in enumerate(self.recv_splits):
+            idx = torch.nonzero((mine >> s) & 1, as_tuple=False).flatten()
+            out.index_add_(0, idx, recv[off:off + c])
+            off += c
+        return out
+
+    def exchange(self, slab, group=None, all_to_all=None):
+        """partial slab [V, 9] of this rank's band -> summed rows of the owned visible range"""
+        send = self.pack(slab).contiguous()
+        recv = torch.empty(sum(self.recv_splits), SLAB_WIDTH, dtype=slab.dtype, device=slab.device)
+        if all_to_all is not None:
+            all_to_all(recv, send, self.recv_splits, self.send_splits)
+        else:
+            dist.all_to_all_single(recv, send, self.recv_splits, self.send_splits, group=group)
+        return self.unpack(recv)
+
+
+def _band_rows(n_tile_rows, world_size):
+    return [band_of(n_tile_rows, world_size, r)[0] for r in range(world_size)] + [n_tile_rows]
+
+
+def enqueue_hip_plan(f, world_size, rank):
+    """preprocess_forward's `plan` hook: enqueues gs_halo_plan after the tile count; the returned
+    device record (S, V, v_lo, v_hi, send[G], recv[G]) rides on the frame's one host read."""
+    from . import _hip
+    dev = f.uv.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    G = world_size
+    f.halo_mask = torch.empty(f.N, **i32)
+    f.halo_ws = torch.empty(_hip.lib().gs_halo_workspace_ints(f.N, G), **i32)
+    f.halo_send_index = torch.empty(f.N, **i32)
+    record = torch.empty(4 + 2 * G, **i32)
+    rows = (ctypes.c_int32 * (G + 1))(*_band_rows(f.nty, G))
+    blks = (ctypes.c_int32 * (G + 1))(*owner_blocks(f.N, G))
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _hip.call("gs_halo_plan", p(f.uv), p(f.conic), f.N, p(f.count), p(f.ws), f.ntx, f.nty,
+              ctypes.c_float(float(f.mh_dist)), rows, blks, G, rank, p(f.ranges_buf[f.T:]), p(f.halo_mask),
+              p(f.halo_ws), p(f.halo_send_index), p(record),
+              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    return record
+
+
+def finish_hip_plan(f, world_size, rank):
+    G = world_size
+    h = f.host
+    send_splits, recv_splits = h[4:4 + G], h[4 + G:4 + 2 * G]
+    return HaloPlan(G, rank, f.halo_mask, f.halo_send_index[:sum(send_splits)], send_splits, recv_splits,
+                    h[2], h[3], hip=(f.N, f.halo_ws))
+
+
+# ---------------------------------------------------------------------------------------------------
+# autograd pieces
+# ---------------------------------------------------------------------------------------------------
 class _GatherImage(torch.autograd.Function):
     """forward: sum over ranks of band images (disjoint support == gather); backward: identity,
     because every rank evaluates the same loss on the same gathered image."""
@@ -64,14 +214,163 @@ class _SumGradsAcrossRanks(torch.autograd.Function):
         return (None,) + tuple(out)
 
 
+class _OwnerExchange(torch.autograd.Function):
+    """Reference-shaped path, grad_mode "owner": identity in forward; in backward the partial
+    gradients (rgb [V,3], opacity [V,1], uv [V,2], conic [V,3]) become complete for the visible
+    Gaussians this rank owns (sparse all_to_all) and zero elsewhere, so the dense per-Gaussian
+    backward that follows is exact on the owned slice."""
+
+    @staticmethod
+    def forward(ctx, rast, plan_of, rgb, opacity, uv, conic):
+        ctx.rast, ctx.plan_of = rast, plan_of
+        return rgb.view_as(rgb), opacity.view_as(opacity), uv.view_as(uv), conic.view_as(conic)
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_opacity, g_uv, g_conic):
+        plan = ctx.plan_of()
+        slab = torch.cat([g_rgb, g_opacity, g_uv, g_conic], dim=1).contiguous()
+        owned = plan.exchange(slab, group=ctx.rast.group)
+        full = torch.zeros_like(slab)
+        full[plan.v_lo:plan.v_hi] = owned
+        return None, None, full[:, 0:3], full[:, 3:4], full[:, 4:6], full[:, 6:9]
+
+
+class _OwnerFrameFused(torch.autograd.Function):
+    """One node for the whole frame on the fused HIP path: the owned parameter slices are the
+    differentiable inputs (they receive the gradients), the replicated full tensors provide the
+    values."""
+
+    @staticmethod
+    def forward(ctx, o_xyz, o_quaternion, o_scale, o_opacity, o_rgb, o_sh, rast, g, camera_T_world, K, width,
+                height, near_thresh, far_thresh, cull_mask_padding, mh_dist, background_rgb):
+        from . import _hip, fused
+        G, me = rast.world_size, rast.rank
+        sort_prefix = _hip.GS_SORT_PREFIX if fused.SORT_PREFIX else 0
+        sh = g.sh.contiguous() if g.sh is not None else None
+        full = (g.xyz.detach().contiguous(), g.quaternion.detach().contiguous(), g.scale.detach().contiguous(),
+                g.opacity.detach().contiguous(), g.rgb.detach().contiguous(),
+                sh.detach() if sh is not None else None)
+        f = fused.preprocess_forward(*full, camera_T_world, K, width, height, near_thresh, far_thresh,
+                                     cull_mask_padding, mh_dist, rast.tile_rows, sort_prefix,
+                                     plan=lambda fr: enqueue_hip_plan(fr, G, me))
+        plan = finish_hip_plan(f, G, me)
+        V = f.V
+        rgb_v = f.rgb_render[:V]
+        image, nsp, fw = fused.render_forward(f.packed, rgb_v, f.ranges, f.sorted_g, f.keys, background_rgb,
+                                              height, width, rast.tile_rows, sort_prefix)
+        rast.gather_image_(image)
+        ctx.save_for_backward(full[0], full[1], full[2], camera_T_world, K, f.packed, rgb_v, f.ranges, f.sorted_g,
+                              background_rgb, nsp, fw)
+        ctx.f, ctx.plan, ctx.rast, ctx.dims = f, plan, rast, (height, width)
+        ctx.set_materialize_grads(False)
+        uv = f.uv[:V]
+        ctx.mark_non_differentiable(f.culling_mask, uv)
+        rast.last_plan = plan
+        return image, f.culling_mask, uv
+
+    @staticmethod
+    def backward(ctx, grad_image, *unused):
+        from . import fused
+        if grad_image is None:
+            return (None,) * 17
+        (xyz, quaternion, scale, camera_T_world, K, packed, rgb_v, ranges, sorted_g, background_rgb, nsp,
+         fw) = ctx.saved_tensors
+        f, plan, rast = ctx.f, ctx.plan, ctx.rast
+        height, width = ctx.dims
+        slab = fused.render_backward(packed, rgb_v, ranges, sorted_g, background_rgb, nsp, fw,
+                                     grad_image.contiguous(), height, width, rast.tile_rows, f.V)
+        owned = plan.exchange(slab, group=rast.group, all_to_all=rast.all_to_all)
+        rast.last_owned_render_grads = owned
+        i0, i1 = owner_range(f.N, rast.world_size, rast.rank)
+        grads = fused.preprocess_backward(xyz, quaternion, scale, camera_T_world, K, f, owned, v_base=plan.v_lo,
+                                          i0=i0, i1=i1)
+        return grads + (None,) * 11
+
+
+class _OwnerFrameGeneric(torch.autograd.Function):
+    """grad_mode "owner" over the reference-shaped path (any dtype / colour mode, CPU tensors in the
+    tests): the frame's graph is built on replicated leaf copies, the sparse exchange completes the
+    render gradients of the owned Gaussians, and the owned rows of the dense gradients are handed to
+    the owned parameter slices."""
+
+    @staticmethod
+    def forward(ctx, o_xyz, o_quaternion, o_scale, o_opacity, o_rgb, o_sh, rast, g, camera_T_world, camera, args,
+                background_rgb):
+        from . import backend
+        from .splat_py.rasterize import rasterize as impl
+        near_thresh, far_thresh, cull_mask_padding, mh_dist, use_sh_precompute = args
+        G, me = rast.world_size, rast.rank
+        names = ("xyz", "rgb", "opacity", "scale", "quaternion", "sh")
+        state = {}
+
+        def plan_of():
+            return state["plan"]
+
+        def sync(rgb, opacity, uv, conic):
+            if rgb.dim() != 2:   # per-pixel SH colour: [V, 3, n_sh] rows do not fit the 9-wide slab
+                return _SumGradsAcrossRanks.apply(rast.group, rgb, opacity, uv, conic)
+            ntx, nty = (camera.width + 15) // 16, (camera.height + 15) // 16
+            mask = backend.get().band_mask(uv.detach().contiguous(), conic.detach().contiguous(), ntx, nty,
+                                           mh_dist, _band_rows(nty, G))
+            state["mask"] = mask
+            return _OwnerExchange.apply(rast, plan_of, rgb, opacity, uv, conic)
+
+        with torch.enable_grad():
+            rep = Gaussians(*[None if getattr(g, k) is None else getattr(g, k).detach().clone().requires_grad_(True)
+                              for k in ("xyz", "rgb", "opacity", "scale", "quaternion", "sh")])
+            image, culling_mask, uv = impl(rep, camera_T_world, camera, near_thresh, far_thresh, cull_mask_padding,
+                                           mh_dist, use_sh_precompute, background_rgb, tile_rows=rast.tile_rows,
+                                           grad_sync=sync)
+        N = g.xyz.shape[0]
+        if "mask" in state:
+            keep = ~culling_mask
+            prefix = torch.cumsum(keep.to(torch.int64), 0)
+            v_bounds = [0 if i == 0 else int(prefix[i - 1])
+                        for i in (min(N, OWNER_BLOCK * b) for b in owner_blocks(N, G))]
+            state["plan"] = HaloPlan.reference(state["mask"], v_bounds, G, me)
+            rast.last_plan = state["plan"]
+        ctx.rep, ctx.local_image, ctx.names = rep, image, names
+        ctx.range = owner_range(N, G, me)
+        out = image.detach().clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=rast.group)
+        uv_out = uv.detach()
+        ctx.mark_non_differentiable(culling_mask, uv_out)
+        return out, culling_mask, uv_out
+
+    @staticmethod
+    def backward(ctx, grad_image, *unused):
+        torch.autograd.backward(ctx.local_image, grad_image)
+        i0, i1 = ctx.range
+        rep = ctx.rep
+        order = ("xyz", "quaternion", "scale", "opacity", "rgb", "sh")
+        grads = tuple(None if getattr(rep, k) is None else getattr(rep, k).grad[i0:i1] for k in order)
+        return grads + (None,) * 6
+
+
 class ShardedRasterizer:
-    def __init__(self, image_height, world_size=None, rank=None, group=None, fused=True):
+    def __init__(self, image_height, world_size=None, rank=None, group=None, fused=True, grad_mode="replicated",
+                 all_to_all=None):
+        if grad_mode not in ("replicated", "owner"):
+            raise ValueError("grad_mode must be 'replicated' or 'owner'")
         self.group = group
         self.world_size = world_size if world_size is not None else dist.get_world_size(group)
         self.rank = rank if rank is not None else dist.get_rank(group)
         self.fused = fused
+        self.grad_mode = grad_mode
+        self.all_to_all = all_to_all   # test hook: stands in for dist.all_to_all_single
         n_tile_rows = (image_height + 15) // 16
         self.tile_rows = band_of(n_tile_rows, self.world_size, self.rank)
+        self.last_plan = None
+        self.last_owned_render_grads = None
+
+    def owned_range(self, N):
+        return owner_range(N, self.world_size, self.rank)
+
+    def gather_image_(self, image):
+        """in place: band images (zero outside the band) -> the full frame on every rank"""
+        if self.all_to_all is None:
+            dist.all_reduce(image, op=dist.ReduceOp.SUM, group=self.group)
+        return image
 
     def _grad_sync(self, *tensors):
         return _SumGradsAcrossRanks.apply(self.group, *tensors)
@@ -80,17 +379,31 @@ class ShardedRasterizer:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
 
     def rasterize(self, gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_mask_padding, mh_dist,
-                  use_sh_precompute, background_rgb):
+                  use_sh_precompute, background_rgb, owned=None):
         """Same contract as splat_py.rasterize.rasterize; the returned image is the full frame on
-        every rank."""
-        if self.fused:
-            from . import fused
+        every rank.  grad_mode "owner": `gaussians` holds the replicated values, `owned` (see
+        owned_slice) the leaf tensors of this rank's slice, which receive the gradients."""
+        from . import fused
+        use_fused = self.fused and fused.supported(gaussians, camera_T_world, camera, use_sh_precompute)
+        if self.grad_mode == "owner":
+            if owned is None:
+                raise ValueError("grad_mode 'owner' needs owned= (the parameter slices of this rank)")
+            o = (owned.xyz, owned.quaternion, owned.scale, owned.opacity, owned.rgb, owned.sh)
+            if use_fused:
+                return _OwnerFrameFused.apply(
+                    *o, self, gaussians, camera_T_world.contiguous(), camera.K.contiguous(), int(camera.width),
+                    int(camera.height), near_thresh, far_thresh, cull_mask_padding, mh_dist,
+                    background_rgb.contiguous())
+            return _OwnerFrameGeneric.apply(
+                *o, self, gaussians, camera_T_world, camera,
+                (near_thresh, far_thresh, cull_mask_padding, mh_dist, use_sh_precompute), background_rgb)
+        if use_fused:
             impl = fused.rasterize
         else:
             from .splat_py.rasterize import rasterize as impl
         image, culling_mask, uv = impl(
             gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_mask_padding, mh_dist,
             use_sh_precompute, background_rgb, tile_rows=self.tile_rows, grad_sync=self._grad_sync,
-            **({"slab_sync": self._slab_sync} if self.fused else {}))
+            **({"slab_sync": self._slab_sync} if use_fused else {}))
         image = _GatherImage.apply(image, self.group)
         return image, culling_mask, uv

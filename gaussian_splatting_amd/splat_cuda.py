@@ -224,6 +224,30 @@ def get_sorted_gaussian_list(max_tiles_per_gaussian, uvs, xyz_camera_frame, coni
     return sorted_g, ranges
 
 
+def band_mask(uvs, conic, n_tiles_x, n_tiles_y, mh_dist, band_rows):
+    """Multi-GPU bookkeeping (no reference counterpart; gaussian_splatting_amd.sharded): bit s of
+    mask[g] is set when the candidate tile window of Gaussian g reaches tile rows
+    [band_rows[s], band_rows[s+1]).  int32 tensor [V]."""
+    _valid(uvs=uvs, conic=conic)
+    V, G = uvs.shape[0], len(band_rows) - 1
+    i32 = dict(dtype=torch.int32, device=uvs.device)
+    if V == 0:
+        return torch.empty(0, **i32)
+    nblk = (V + 255) // 256
+    count = torch.full((1,), V, **i32)
+    pre_ws = torch.zeros(2 * nblk, **i32)
+    mask = torch.empty(V, **i32)
+    ws = torch.empty(_hip.lib().gs_halo_workspace_ints(V, G), **i32)
+    send_index = torch.empty(V, **i32)
+    plan = torch.empty(4 + 2 * G, **i32)
+    rows = (ctypes.c_int32 * (G + 1))(*[int(r) for r in band_rows])
+    blks = (ctypes.c_int32 * (G + 1))(*([0] * G + [nblk]))
+    _hip.call("gs_halo_plan", _p(uvs), _p(conic), V, _p(count), _p(pre_ws), int(n_tiles_x), int(n_tiles_y),
+              ctypes.c_float(float(mh_dist)), rows, blks, G, 0, None, _p(mask), _p(ws), _p(send_index), _p(plan),
+              _stream())
+    return mask
+
+
 # ---- render.cu / render_backward.cu / depth.cu --------------------------------------------------------------
 def _pack(uvs, opacity, conic, dt, rgb=None):
     V = uvs.shape[0]

@@ -111,9 +111,8 @@ int gs_precompute_rgb_from_sh_backward(const void* xyz, const void* matrix, cons
  *   of it, so for a tile with GS_SORT_PREFIX < n <= 8192 entries only the GS_SORT_PREFIX nearest are
  *   selected and ordered into sorted_gaussians[start .. start+GS_SORT_PREFIX); the rest of that
  *   segment is undefined.  Results stay exact: gs_render_tiles_prefix raises tile_flags[t] when a
- *   tile ran out of prefix with an unsaturated pixel; gs_tile_sort_flagged then sorts those tiles
- *   in full from the untouched `keys`, and a second gs_render_tiles_prefix call with
- *   flagged_only = 1 re-renders them.  All three are plain enqueues, no host read. */
+ *   tile ran out of prefix with an unsaturated pixel, sorts those tiles in full from the untouched
+ *   `keys` (gs_tile_sort_flagged) and renders them again -- plain enqueues, no host read. */
 size_t gs_tile_workspace_ints(int n_tiles);
 int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visible_count,
                   int n_tiles_x, int n_tiles_y, float mh_dist, int tile_row0, int tile_row1,
@@ -156,18 +155,23 @@ int gs_preprocess_forward(const void* xyz, const void* quaternion, const void* s
                           void* xyz_camera_frame, void* conic, void* opacity_act, void* rgb_render,
                           void* packed, void* stream);
 /* Backward of the above (projection_backward.cu:9-471, precompute_sh.cu:61-111 and the autograd of
- * the glue: sigmoid', the cat split, the dense scatter of rasterize.py:52-75, matmul').  Takes the
- * render gradients w.r.t. uv[V,2], conic[V,3], opacity_act[V,1], rgb_render[V,3] and writes the
- * dense parameter gradients, every row exactly once (zeros for culled Gaussians): grad_xyz[N,3],
- * grad_quaternion[N,4], grad_scale[N,3], grad_opacity_logit[N,1], grad_rgb_param[N,3],
- * grad_sh[N,3,n_sh-1] (NULL when n_sh == 1). */
+ * the glue: sigmoid', the cat split, the dense scatter of rasterize.py:52-75, matmul').
+ * grad_slab: the render gradients, one row of 9 floats per visible Gaussian in the order
+ *   (rgb_render 3 | opacity_act 1 | uv 2 | conic 3) -- the layout gs_render_tiles_backward_slab
+ *   accumulates into; the row of visible Gaussian v is grad_slab[(v - v_base) * 9].
+ * Writes the dense parameter gradients, every row exactly once (zeros for culled Gaussians):
+ * grad_xyz[N,3], grad_quaternion[N,4], grad_scale[N,3], grad_opacity_logit[N,1],
+ * grad_rgb_param[N,3], grad_sh[N,3,n_sh-1] (NULL when n_sh == 1).
+ * A slice [i0, i1) of the Gaussians (multi-GPU: the slice this rank owns) is processed by passing
+ * the parameter / rank / output pointers advanced to row i0, N = i1 - i0, and a slab that holds
+ * the rows of the slice's visible Gaussians with v_base = their first visible index;
+ * opacity_act stays the full array (it is indexed by v). */
 int gs_preprocess_backward(const void* xyz, const void* quaternion, const void* scale, int n_sh,
                            const void* camera_T_world, const void* K, const void* camera_center,
-                           const int32_t* rank, const void* opacity_act, const void* grad_uv,
-                           const void* grad_conic, const void* grad_opacity, const void* grad_rgb,
-                           int N, void* grad_xyz, void* grad_quaternion, void* grad_scale,
-                           void* grad_opacity_logit, void* grad_rgb_param, void* grad_sh,
-                           void* stream);
+                           const int32_t* rank, const void* opacity_act, const void* grad_slab,
+                           int v_base, int N, void* grad_xyz, void* grad_quaternion,
+                           void* grad_scale, void* grad_opacity_logit, void* grad_rgb_param,
+                           void* grad_sh, void* stream);
 
 /* ---- tile renderer ---------------------------------------------------------------------------- */
 /* Packs what the render kernels read per splat into one 48-byte (fp32) record per visible Gaussian:
@@ -189,16 +193,16 @@ int gs_render_tiles(const void* packed, const void* rgb, const void* view_dir_by
                     int tile_row1, int32_t* num_splats_per_pixel, void* final_weight_per_pixel,
                     void* image, int dtype, void* stream);
 /* The same kernel over lists produced with sort_prefix = GS_SORT_PREFIX (fp32, n_sh == 1).
- * flagged_only == 0: renders every tile of the band, reading at most the ordered prefix of a
- *   prefix-sorted tile, and writes tile_flags[t] = 1 if tile t needs its full list (0 otherwise;
- *   the outputs of such a tile are then provisional).
- * flagged_only == 1: renders only tiles with tile_flags[t] != 0, from their full lists (after
- *   gs_tile_sort_flagged).  tile_flags: int32[n_tiles].
- * After both calls every output equals what gs_render_tiles gives on fully sorted lists. */
+ * Enqueues (1) a provisional render that reads at most the ordered prefix of a prefix-sorted tile
+ * and writes tile_flags[t] = 1 if tile t ran out of it with an unsaturated pixel (0 otherwise),
+ * (2) gs_tile_sort_flagged, (3) a second render of the flagged tiles from their full lists.
+ * Afterwards every output equals what gs_render_tiles gives on fully sorted lists, and the
+ * segments of the flagged tiles in sorted_gaussians are fully sorted (the backward pass reads them).
+ * keys, S: as passed to gs_tile_emit_sort.  tile_flags: int32[n_tiles] scratch/out. */
 int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* tile_ranges,
-                           const int32_t* sorted_gaussians, const void* background_rgb, int W,
-                           int H, int tile_row0, int tile_row1, int sort_prefix,
-                           int32_t* tile_flags, int flagged_only, int32_t* num_splats_per_pixel,
+                           int32_t* sorted_gaussians, const uint64_t* keys, int64_t S,
+                           const void* background_rgb, int W, int H, int tile_row0, int tile_row1,
+                           int32_t* tile_flags, int32_t* num_splats_per_pixel,
                            void* final_weight_per_pixel, void* image, void* stream);
 /* render_tiles_backward_cuda (bindings.cpp:120; render_backward.cu:12-595).
  * grad_rgb[V,3,n_sh], grad_opacity[V,1], grad_uv[V,2], grad_conic[V,3] are accumulated.
@@ -210,11 +214,53 @@ int gs_render_tiles_backward(const void* packed, const void* rgb, const void* vi
                              int H, int n_sh, int tile_row0, int tile_row1, void* grad_rgb,
                              void* grad_opacity, void* grad_uv, void* grad_conic, int dtype,
                              void* stream);
+/* The fused renderer's form of the above (fp32, n_sh == 1): the four gradients of a Gaussian are
+ * accumulated into one row of grad_slab[V, 9] = (rgb 3 | opacity 1 | uv 2 | conic 3), which must be
+ * zero-initialised (or hold values to accumulate onto). */
+int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int32_t* tile_ranges,
+                                  const int32_t* sorted_gaussians, const void* background_rgb,
+                                  const int32_t* num_splats_per_pixel,
+                                  const void* final_weight_per_pixel, const void* grad_image, int W,
+                                  int H, int tile_row0, int tile_row1, void* grad_slab,
+                                  void* stream);
 /* render_depth_cuda (bindings.cpp:158; depth.cu:7-177), fp32 only.  depth_image[H,W] is written
  * only where the accumulated alpha passes alpha_threshold (caller pre-fills with -1). */
 int gs_render_depth(const void* packed, const void* xyz_camera_frame, const int32_t* tile_ranges,
                     const int32_t* sorted_gaussians, int W, int H, float alpha_threshold,
                     void* depth_image, void* stream);
+
+/* ---- multi-GPU: tile-row bands with owner-sliced gradients ------------------------------------
+ * (no reference counterpart: the reference is single-GPU; BASELINE.json north_star asks for frames
+ * sharded by tile rows over up to 8 GPUs.)  Rank b renders tile rows [band_rows[b], band_rows[b+1]);
+ * rank r owns the Gaussians [256*owner_blocks[r], 256*owner_blocks[r+1]) and runs the per-Gaussian
+ * backward for them, so the partial render gradients of the bands are exchanged sparsely: a row
+ * travels only from a rank whose band the Gaussian's candidate tile window reaches to its owner.
+ *
+ * gs_halo_plan (after gs_preprocess_forward and gs_tile_count of the same frame; inputs are the
+ * capacity-N buffers and the device-side visible_count):
+ *   mask[N]        bit s = visible Gaussian v reaches the band of rank s
+ *   send_index[N]  the visible indices with bit `rank`, ascending: row k of the send buffer is
+ *                  grad_slab[send_index[k]]; consecutive owners' parts, plan[4 + r] rows for owner r
+ *   plan[4 + 2G]   device record for the frame's one host read: S (= *instance_count, or 0),
+ *                  V, v_lo, v_hi (visible-index range of the Gaussians this rank owns),
+ *                  send counts [G], receive counts [G]
+ *   workspace      int32[gs_halo_workspace_ints(N, G)], read again by gs_halo_gather_sum
+ * band_rows, owner_blocks: host arrays of G + 1 ints.  G <= GS_MAX_RANKS.
+ *
+ * gs_halo_gather_sum (after the all_to_all): recv holds, for sender s = 0..G-1 at row offset
+ * recv_offsets[s] (host array, the exclusive prefix of the receive counts), the rows of the
+ * Gaussians v in [v_lo, v_hi) with bit s, ascending; out[(v - v_lo) * 9 ..] = their sum, every
+ * row of the range written once (zeros where no band reaches the Gaussian). */
+#define GS_MAX_RANKS 8
+size_t gs_halo_workspace_ints(int N, int G);
+int gs_halo_plan(const void* uvs, const void* conic, int N, const int32_t* visible_count,
+                 const int32_t* preprocess_workspace, int n_tiles_x, int n_tiles_y, float mh_dist,
+                 const int32_t* band_rows, const int32_t* owner_blocks, int G, int rank,
+                 const int32_t* instance_count, uint32_t* mask, int32_t* workspace,
+                 int32_t* send_index, int32_t* plan, void* stream);
+int gs_halo_gather_sum(const uint32_t* mask, const int32_t* workspace, int N, int G, int rank,
+                       int v_lo, int v_hi, const void* recv, const int32_t* recv_offsets,
+                       void* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -581,6 +581,33 @@ INST(float, f32)
 INST(double, f64)
 #undef INST
 
+// Multi-GPU bookkeeping (no reference counterpart; checker for gs_halo_plan): bit s of mask[g] is
+// set when the candidate tile window of Gaussian g (tile_culling.cu:138-156) reaches the tile rows
+// [band_rows[s], band_rows[s+1]) -- a superset of the rows in which the separating-axis test
+// accepts a tile.
+void orc_band_mask(const float* uvs, const float* conic, int ntx, int nty, float mh, int N,
+                   const int* band_rows, int G, uint32_t* mask) {
+    for (int g = 0; g < N; g++) {
+        const float u = uvs[g * 2], v = uvs[g * 2 + 1];
+        const float a = conic[g * 3] + 0.25f;
+        const float b = conic[g * 3 + 1] / 2.0f;
+        const float c = conic[g * 3 + 2] + 0.25f;
+        float obb[8];
+        const int r = compute_obb(u, v, a, b, c, mh, obb);
+        const int px = f2i(floorf(u / 16.0f));
+        const int sx = f2i(fmaxf(0.0f, (float)(int)((unsigned)px - (unsigned)r)));
+        const int ex = f2i(fminf((float)ntx, (float)(int)((unsigned)px + (unsigned)r)));
+        const int py = f2i(floorf(v / 16.0f));
+        const int sy = f2i(fmaxf(0.0f, (float)(int)((unsigned)py - (unsigned)r)));
+        const int ey = f2i(fminf((float)nty, (float)(int)((unsigned)py + (unsigned)r)));
+        uint32_t m = 0;
+        if (sx < ex && sy < ey)
+            for (int s = 0; s < G; s++)
+                if (sy < band_rows[s + 1] && ey > band_rows[s]) m |= 1u << s;
+        mask[g] = m;
+    }
+}
+
 // tile_culling.cu:124-177 + host :269-296.  Returns the number of Gaussian-tile instances S.
 // num_tiles_per_gaussian[N], num_gaussians_per_tile[T] are overwritten.
 int64_t orc_tile_count(const float* uvs, const float* conic, int ntx, int nty, float mh, int N,

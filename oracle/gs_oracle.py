@@ -175,6 +175,18 @@ def get_sorted_gaussian_list(max_tiles_per_gaussian, uvs, xyz_camera_frame, coni
     return sorted_g, ranges
 
 
+def band_mask(uvs, conic, n_tiles_x, n_tiles_y, mh_dist, band_rows):
+    """bit s of mask[g]: the candidate tile window of Gaussian g reaches tile rows
+    [band_rows[s], band_rows[s+1]) (checker for gs_halo_plan; int32 tensor, G <= 31)"""
+    _check(uvs, conic)
+    G = len(band_rows) - 1
+    rows = (ctypes.c_int * (G + 1))(*[int(r) for r in band_rows])
+    mask = torch.zeros(uvs.shape[0], dtype=torch.int32)
+    lib().orc_band_mask(_p(uvs), _p(conic), int(n_tiles_x), int(n_tiles_y), ctypes.c_float(mh_dist),
+                        uvs.shape[0], rows, G, _p(mask))
+    return mask
+
+
 def render_tiles_cuda(uvs, opacity, rgb, conic, view_dir_by_pixel, splat_start_end_idx_by_tile_idx,
                       gaussian_idx_by_splat_idx, background_rgb, num_splats_per_pixel,
                       final_weight_per_pixel, rendered_image, tile_rows=None):

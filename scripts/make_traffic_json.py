@@ -15,13 +15,13 @@ for name in ("pass3.txt", "pass4.txt"):
             k = re.sub(r"\(.*", "", m.group(1).strip()).replace("void ", "")
             vals.setdefault(k, {})[m.group(2)] = float(m.group(3))
 ENTRY = {
-    "gs_render_tiles_backward": ["gs::k_render_bwd<float, 1>"],
-    "gs_render_tiles": ["gs::k_render_fwd<float, 1>"],
+    "gs_render_tiles_backward_slab": ["gs::k_render_bwd<float, 1>"],
+    "gs_render_tiles_prefix": ["gs::k_render_fwd<float, 1>", "gs::k_render_fwd_flagged", "gs::k_tile_sort_flagged<8192>",
+                               "gs::k_tile_sort_flagged<4096>"],
     "gs_preprocess_forward": ["gs::k_preprocess<16>", "gs::k_cull_count", "gs::k_scan_counts", "gs::k_camera_center"],
     "gs_preprocess_backward": ["gs::k_preprocess_bwd<16>"],
     "gs_tile_count": ["gs::k_bin_count", "gs::k_bin_colscan", "gs::k_scan_tiles"],
-    "gs_tile_emit_sort": ["gs::k_bin_emit", "gs::k_tile_sort_lds<0, 1024>", "gs::k_tile_sort_lds<1024, 4096>",
-                          "gs::k_tile_sort_lds<4096, 8192>", "gs::k_tile_sort_global"],
+    "gs_tile_emit_sort": ["gs::k_bin_emit", "gs::k_tile_sort<true>", "gs::k_tile_sort_big<true>"],
 }
 res = {"workload": workload, "source": pmc_dir, "note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
        "entries": {}}

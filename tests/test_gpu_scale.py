@@ -163,7 +163,7 @@ def test_prefix_sort_selects_the_nearest_entries():
     from gaussian_splatting_amd import _hip
     orc = oracle()
     gen = torch.Generator().manual_seed(12)
-    chunks, sizes = [], (700, 1025, 3000, 4097, 8192, 9000)
+    chunks, sizes = [], (700, 1025, 3000, 4097, 8192, 9000, 1, 40, 64, 65, 200, 256, 257, 1024)
     for tile_x, n in enumerate(sizes):
         uvs = torch.rand(n, 2, generator=gen) * 10 + 3
         uvs[:, 0] += 16 * tile_x
@@ -179,6 +179,10 @@ def test_prefix_sort_selects_the_nearest_entries():
     ntx = len(sizes)
     ref_sorted, ref_ranges = orc.get_sorted_gaussian_list(1024, uv, xyz_c, conic, ntx, 1, 3.0)
     assert (ref_ranges[1:] - ref_ranges[:-1]).tolist() == list(sizes)
+    # full mode (the drop-in function) over the same tiles: every size class of the wave-level sorts
+    from gaussian_splatting_amd import splat_cuda
+    full = splat_cuda.get_sorted_gaussian_list(1024, uv.to(DEV), xyz_c.to(DEV), conic.to(DEV), ntx, 1, 3.0)
+    assert torch.equal(full[1].cpu(), ref_ranges) and torch.equal(full[0].cpu(), ref_sorted)
 
     p = lambda x: ctypes.c_void_p(x.data_ptr())
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -199,7 +203,7 @@ def test_prefix_sort_selects_the_nearest_entries():
         m = 1024 if 1024 < n <= 8192 else n
         assert torch.equal(got[s0:s0 + m], ref_sorted[s0:s0 + m]), (t, n)
     # repair pass: flag two of the prefix tiles, they come back fully sorted, the others untouched
-    flags = torch.tensor([0, 1, 0, 0, 1, 0], dtype=torch.int32, device=DEV)
+    flags = torch.tensor([0, 1, 0, 0, 1, 0] + [0] * 8, dtype=torch.int32, device=DEV)
     before = got.clone()
     got_d = got.to(DEV)
     _hip.call("gs_tile_sort_flagged", p(ranges), p(keys), ctypes.c_int64(S), p(flags), ntx, 0, 1, p(got_d), stream)

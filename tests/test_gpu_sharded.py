@@ -1,0 +1,144 @@
+"""GPU tests of the multi-GPU frame (gaussian_splatting_amd.sharded) on ONE device: the HIP halo plan
+against its plain-PyTorch restatement and the CPU oracle's band masks, and the owner-mode frame with
+G simulated ranks (the real kernels of every rank run one after the other, the all_to_all is routed
+in-process) against the single-GPU gradients; plus the real RCCL collectives at world size 1."""
+import pytest
+import torch
+
+from gaussian_splatting_amd import fused
+from gaussian_splatting_amd.sharded import (HaloPlan, ShardedRasterizer, _band_rows, enqueue_hip_plan,
+                                            finish_hip_plan, owned_slice, owner_blocks, owner_range)
+from gaussian_splatting_amd.synthetic import make_grad_image, make_scene
+
+from .helpers import scaled_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+PARAMS = ("xyz", "rgb", "opacity", "scale", "quaternion", "sh")
+ARGS = (2.0, 25.0, 20, 3.0)   # near, far, padding, mh_dist: a real frustum cull (V < N)
+
+
+def single_gpu_frame(N, W, H, deg, seed, gi, bg):
+    g, cam, T = make_scene(N, W, H, deg, seed=seed, device=DEV)
+    for k in PARAMS:
+        if getattr(g, k) is not None:
+            getattr(g, k).requires_grad_(True)
+    img, mask, uv = fused.rasterize(g, T, cam, *ARGS, True, bg)
+    img.backward(gi)
+    return img.detach(), mask, {k: getattr(g, k).grad for k in PARAMS if getattr(g, k) is not None}
+
+
+@pytest.mark.parametrize("G", [1, 2, 3, 8])
+def test_halo_plan_matches_reference_and_oracle(G):
+    from oracle import gs_oracle
+    N, W, H, deg = 30000, 640, 472, 0
+    g, cam, T = make_scene(N, W, H, deg, seed=13, device=DEV)
+    nty = (H + 15) // 16
+    for me in sorted({0, G // 2, G - 1}):
+        f = fused.preprocess_forward(g.xyz, g.quaternion, g.scale, g.opacity, g.rgb, None, T, cam.K, W, H, *ARGS,
+                                     (0, nty), 0, plan=lambda fr: enqueue_hip_plan(fr, G, me))
+        plan = finish_hip_plan(f, G, me)
+        V = f.V
+        assert 0 < V < N and f.host[0] == f.S and f.host[1] == V
+        mask = f.halo_mask[:V]
+        ref_mask = gs_oracle.band_mask(f.uv[:V].cpu(), f.conic[:V].cpu(), f.ntx, f.nty, ARGS[3], _band_rows(nty, G))
+        assert torch.equal(mask.cpu(), ref_mask)
+        assert bool((f.halo_mask[V:] == 0).all())
+        keep = ~f.culling_mask
+        prefix = torch.cumsum(keep.long(), 0)
+        v_bounds = [0 if i == 0 else int(prefix[i - 1]) for i in (min(N, 256 * b) for b in owner_blocks(N, G))]
+        ref = HaloPlan.reference(mask, v_bounds, G, me)
+        assert (plan.v_lo, plan.v_hi) == (ref.v_lo, ref.v_hi)
+        assert plan.send_splits == ref.send_splits and plan.recv_splits == ref.recv_splits
+        assert torch.equal(plan.send_index.long(), ref.send_index)
+        # gather-sum kernel == index_add restatement
+        recv = torch.randn(sum(plan.recv_splits), 9, device=DEV)
+        assert torch.allclose(plan.unpack(recv), ref.unpack(recv), atol=1e-6)
+        # a Gaussian that reaches no band of the frame has no tile: the masks cover every instance
+        if G > 1:
+            band = (plan.mask[:V] >> me) & 1
+            rows = _band_rows(nty, G)
+            fb = fused.preprocess_forward(g.xyz, g.quaternion, g.scale, g.opacity, g.rgb, None, T, cam.K, W, H,
+                                          *ARGS, (rows[me], rows[me + 1]), 0)
+            touched = torch.zeros(V, dtype=torch.bool, device=DEV)
+            touched[fb.sorted_g.long()] = True
+            assert bool((touched <= band.bool()).all())
+
+
+@pytest.mark.parametrize("G,deg,N,W,H", [(2, 3, 20000, 640, 472), (3, 0, 20000, 640, 472), (8, 3, 60000, 800, 608)])
+def test_owner_mode_with_simulated_ranks(G, deg, N, W, H):
+    bg = torch.full((3,), 0.5, device=DEV)
+    gi = make_grad_image(W, H, seed=2, device=DEV)
+    ref_img, ref_mask, ref_grads = single_gpu_frame(N, W, H, deg, 7, gi, bg)
+    sent = {}
+
+    def run(rank, a2a):
+        g, cam, T = make_scene(N, W, H, deg, seed=7, device=DEV)
+        owned = owned_slice(g, G, rank)
+        rast = ShardedRasterizer(H, G, rank, grad_mode="owner", all_to_all=a2a)
+        img, mask, uv = rast.rasterize(g, T, cam, *ARGS, True, bg, owned=owned)
+        img.backward(gi)
+        return img.detach(), mask, owned, rast
+
+    def recorder(rank):
+        def a2a(recv, send, recv_splits, send_splits):
+            sent[rank] = (send.clone(), list(send_splits))
+            recv.zero_()
+        return a2a
+
+    def router(rank):
+        def a2a(recv, send, recv_splits, send_splits):
+            off = 0
+            for s in range(G):
+                buf, splits = sent[s]
+                lo = sum(splits[:rank])
+                assert splits[rank] == recv_splits[s]
+                recv[off:off + recv_splits[s]] = buf[lo:lo + splits[rank]]
+                off += recv_splits[s]
+        return a2a
+
+    for r in range(G):
+        run(r, recorder(r))
+    images, sparse_rows = [], 0
+    for r in range(G):
+        img, mask, owned, rast = run(r, router(r))
+        images.append(img)
+        assert torch.equal(mask, ref_mask)
+        i0, i1 = owner_range(N, G, r)
+        for k, ref in ref_grads.items():
+            got = getattr(owned, k).grad
+            assert got.shape == ref[i0:i1].shape
+            err = (got - ref[i0:i1]).abs().max() / ref.abs().max()
+            assert float(err) < 1e-5, (r, k, float(err))
+        sparse_rows += sum(rast.last_plan.send_splits)
+    assert torch.equal(sum(images), ref_img)
+    V = int((~ref_mask).sum())
+    if G > 1:
+        assert sparse_rows < 0.75 * G * V, "the exchange should move fewer rows than G dense slabs"
+
+
+def test_owner_mode_single_rank_rccl():
+    """the real collectives (RCCL all_reduce + all_to_all_single) at world size 1"""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV, 0))
+    try:
+        N, W, H, deg = 3000, 256, 192, 3
+        bg = torch.zeros(3, device=DEV)
+        gi = make_grad_image(W, H, seed=2, device=DEV)
+        ref_img, _, ref_grads = single_gpu_frame(N, W, H, deg, 9, gi, bg)
+        g, cam, T = make_scene(N, W, H, deg, seed=9, device=DEV)
+        owned = owned_slice(g, 1, 0)
+        rast = ShardedRasterizer(H, 1, 0, grad_mode="owner")
+        img, mask, uv = rast.rasterize(g, T, cam, *ARGS, True, bg, owned=owned)
+        img.backward(gi)
+        assert torch.equal(img.detach(), ref_img)
+        for k, ref in ref_grads.items():
+            assert scaled_err(getattr(owned, k).grad, ref) < 1e-5, k
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -93,3 +93,99 @@ def test_sharded_matches_single_process(world, deg):
         assert ok, f"rank {rank}: sharded image differs from the single-process image"
         assert err < 1e-6, f"rank {rank}: gradient error {err}"
         assert same, f"rank {rank}: gradients differ between ranks"
+
+
+# ---- grad_mode "owner": sparse exchange of the partial render gradients --------------------------------
+def test_owner_ranges_partition_the_gaussians():
+    from gaussian_splatting_amd.sharded import OWNER_BLOCK, owner_blocks, owner_range
+    for N in (1, 255, 256, 257, 600, 100000, 2860000):
+        for world in (1, 2, 3, 8):
+            ranges = [owner_range(N, world, r) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == N
+            for a, b in zip(ranges, ranges[1:]):
+                assert a[1] == b[0]
+            assert all(lo % OWNER_BLOCK == 0 for lo, _ in ranges)
+            assert len(owner_blocks(N, world)) == world + 1
+
+
+def test_halo_plan_reference_is_a_consistent_exchange():
+    """all ranks' plans (pure bookkeeping, no process group): what s sends to r is what r expects
+    from s, and pack -> route -> unpack equals the dense sum restricted to the owned range"""
+    from gaussian_splatting_amd.sharded import HaloPlan
+    gen = torch.Generator().manual_seed(3)
+    G, V = 4, 5000
+    mask = torch.randint(0, 2 ** G, (V,), generator=gen, dtype=torch.int32)
+    mask[::17] = 0
+    v_bounds = [0, 1300, 1300, 4100, V]   # an empty owner range included
+    plans = [HaloPlan.reference(mask, v_bounds, G, r) for r in range(G)]
+    for s in range(G):
+        for r in range(G):
+            assert plans[s].send_splits[r] == plans[r].recv_splits[s]
+    # slab of rank s: non-zero only where bit s is set (a band's partial sums)
+    slabs = [torch.randn(V, 9, generator=gen) * ((mask >> s) & 1).unsqueeze(1) for s in range(G)]
+    dense = sum(slabs)
+    sends = [plans[s].pack(slabs[s]) for s in range(G)]
+    for r in range(G):
+        chunks = []
+        for s in range(G):
+            off = sum(plans[s].send_splits[:r])
+            chunks.append(sends[s][off:off + plans[s].send_splits[r]])
+        owned = plans[r].unpack(torch.cat(chunks))
+        assert owned.shape[0] == v_bounds[r + 1] - v_bounds[r]
+        assert torch.allclose(owned, dense[v_bounds[r]:v_bounds[r + 1]], atol=1e-6)
+
+
+def _owner_worker(rank, world, port, deg, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gaussian_splatting_amd import backend
+        from gaussian_splatting_amd.sharded import owned_slice, owner_range
+        from gaussian_splatting_amd.splat_py.rasterize import rasterize
+        from gaussian_splatting_amd.synthetic import make_grad_image, make_scene
+        from oracle import gs_oracle
+        gs_oracle.set_modes(0, 0)
+        backend.use(gs_oracle)
+        ref_img, ref_mask, _, ref_grads = _frame(rasterize, deg)
+        W, H = 112, 100
+        g, cam, T = make_scene(600, W, H, deg, seed=4)
+        owned = owned_slice(g, world, rank)
+        sharded = ShardedRasterizer(H, world, rank, fused=False, grad_mode="owner")
+        img, mask, uv = sharded.rasterize(g, T, cam, 2.0, 25.0, 10, 3.0, True, torch.full((3,), 0.5), owned=owned)
+        img.backward(make_grad_image(W, H, seed=8))
+        i0, i1 = owner_range(600, world, rank)
+        ok = torch.equal(img.detach(), ref_img) and torch.equal(mask, ref_mask)
+        err = 0.0
+        for k in PARAMS:
+            if getattr(owned, k) is None:
+                continue
+            got, ref = getattr(owned, k).grad, ref_grads[k][i0:i1]
+            assert got.shape == ref.shape
+            err = max(err, ((got - ref).abs().max() / ref_grads[k].abs().max().clamp(min=1e-30)).item())
+        plan = sharded.last_plan
+        sparse = plan is not None and sum(plan.send_splits) < int(mask.numel() - mask.sum())
+        out.put((rank, bool(ok), float(err), bool(sparse), (i0, i1)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,deg", [(2, 0), (3, 3)])
+def test_owner_mode_matches_single_process(world, deg):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_owner_worker, args=(r, world, port, deg, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    spans = sorted(r[4] for r in results)
+    assert spans[0][0] == 0 and spans[-1][1] == 600
+    for rank, ok, err, sparse, _ in results:
+        assert ok, f"rank {rank}: sharded image differs from the single-process image"
+        assert err < 1e-6, f"rank {rank}: owned-slice gradient error {err}"
+        assert sparse, f"rank {rank}: the exchange was not sparse"
