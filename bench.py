@@ -45,6 +45,8 @@ def algorithmic_bytes(N, V, S, P, n_coeff):
     return per
 
 
+PARAM_NAMES = ("xyz", "rgb", "opacity", "scale", "quaternion", "sh")
+
 # C-ABI entry points of the fused path that are variants of a SURVEY.md 8(d) row
 ENTRY_ALIAS = {"gs_render_tiles_backward_slab": "gs_render_tiles_backward", "gs_render_tiles_prefix": "gs_render_tiles"}
 
@@ -60,6 +62,10 @@ def parse():
     ap.add_argument("--also", default="", help="comma-separated extra workloads to time after the headline one "
                     "(reported under other_workloads; off by default so that a profile of the default "
                     "command contains one workload only)")
+    ap.add_argument("--grad-mode", default="owner", choices=["owner", "replicated"],
+                    help="multi-GPU only: 'owner' = every rank produces the parameter gradients of the Gaussians "
+                    "it owns (sparse all_to_all of the partial render gradients); 'replicated' = identical dense "
+                    "gradients on every rank (all-reduce of the whole render-gradient slab)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (ShardedRasterizer over RCCL) even with one rank")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -181,12 +187,13 @@ def main():
     _hip.lib()   # fail loudly if the HIP extension is missing
     N, W, H, deg = WORKLOADS[args.workload]
     g, cam, T = make_scene(N, W, H, deg, seed=0, device=dev)
-    for name in ("xyz", "rgb", "opacity", "scale", "quaternion", "sh"):
+    for name in PARAM_NAMES:
         p = getattr(g, name)
         if p is not None:
             p.requires_grad_(True)
     grad_image = make_grad_image(W, H, seed=1, device=dev)
     bg = torch.zeros(3, device=dev)
+    owned, grad_holder = None, g
 
     path = args.path
     fused_mod = None
@@ -199,11 +206,18 @@ def main():
         path = "fused" if fused_mod is not None else "reference"
 
     if world > 1 or args.force_sharded:
-        from gaussian_splatting_amd.sharded import ShardedRasterizer
-        rast = ShardedRasterizer(cam.height, world, rank, fused=(path == "fused"))
+        from gaussian_splatting_amd.sharded import ShardedRasterizer, owned_slice
+        rast = ShardedRasterizer(cam.height, world, rank, fused=(path == "fused"), grad_mode=args.grad_mode)
+        if args.grad_mode == "owner":
+            # the replicated tensors carry the values, the owned slices receive the gradients
+            owned = owned_slice(g, world, rank)
+            for name in PARAM_NAMES:
+                if getattr(g, name) is not None:
+                    getattr(g, name).requires_grad_(False)
+            grad_holder = owned
 
         def forward():
-            return rast.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, **DEFAULTS)
+            return rast.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, owned=owned, **DEFAULTS)
     elif path == "fused":
         def forward():
             return fused_mod.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, **DEFAULTS)
@@ -216,8 +230,8 @@ def main():
     stats = {}
 
     def step():
-        for name in ("xyz", "rgb", "opacity", "scale", "quaternion", "sh"):
-            p = getattr(g, name)
+        for name in PARAM_NAMES:
+            p = getattr(grad_holder, name)
             if p is not None:
                 p.grad = None
         image, mask, uv = forward()
@@ -305,7 +319,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {N} Gaussians, {W}x{H}, SH degree {deg}, seed 0",
                        "N": N, "V": V, "S": S, "P": P, "path": path,
-                       "parallelism": "single" if world == 1 else f"tile-rows x{world}"},
+                       "parallelism": "single" if world == 1 and not args.force_sharded
+                       else f"tile-rows x{world}, {args.grad_mode} gradients"},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "other_workloads": other,
         }
         print(json.dumps(line))

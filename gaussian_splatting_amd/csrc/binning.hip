@@ -111,14 +111,28 @@ __device__ inline void for_each_tile(const float* __restrict__ uvs,
     }
 }
 
+// Which Gaussians a binning kernel walks: all V rows, the first *v_dev of them (fill level known
+// only on the device), or the *subset_n entries of an index list (multi-GPU: the Gaussians whose
+// candidate window reaches the rank's band; any list that contains every Gaussian with a tile in
+// the rows [row0, row1) gives the same tile lists).
+struct Items {
+    const int* v_dev;
+    const int* subset;
+    const int* subset_n;
+};
+__device__ inline int item_count(const Items& it, int V) {
+    return it.subset ? *it.subset_n : (it.v_dev ? *it.v_dev : V);
+}
+__device__ inline int item_at(const Items& it, int i) { return it.subset ? it.subset[i] : i; }
+
 __global__ __launch_bounds__(BIN_BLOCK) void k_tile_count(const float* __restrict__ uvs,
                                                           const float* __restrict__ conic, int V,
                                                           int ntx, int nty, float mh, int row0,
                                                           int row1, int* __restrict__ counts,
-                                                          const int* __restrict__ v_dev) {
-    const int g = blockIdx.x * BIN_BLOCK + threadIdx.x;
-    if (g >= (v_dev ? *v_dev : V)) return;
-    for_each_tile(uvs, conic, g, ntx, nty, mh, row0, row1,
+                                                          Items items) {
+    const int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
+    if (i >= item_count(items, V)) return;
+    for_each_tile(uvs, conic, item_at(items, i), ntx, nty, mh, row0, row1,
                   [&](int tile) { atomicAdd(counts + tile, 1); });
 }
 
@@ -181,15 +195,15 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_count(const float* __restric
                                                           const float* __restrict__ conic, int V,
                                                           int ntx, int nty, float mh, int row0,
                                                           int row1, int* __restrict__ hist,
-                                                          const int* __restrict__ v_dev) {
+                                                          Items items) {
     extern __shared__ int s_hist[];
     const int T = ntx * nty;
     for (int t = threadIdx.x; t < T; t += PRIV_BLOCK) s_hist[t] = 0;
     __syncthreads();
     int g0, g1;
-    slice_of(blockIdx.x, v_dev ? *v_dev : V, g0, g1);
-    for (int g = g0 + threadIdx.x; g < g1; g += PRIV_BLOCK)
-        for_each_tile(uvs, conic, g, ntx, nty, mh, row0, row1,
+    slice_of(blockIdx.x, item_count(items, V), g0, g1);
+    for (int i = g0 + threadIdx.x; i < g1; i += PRIV_BLOCK)
+        for_each_tile(uvs, conic, item_at(items, i), ntx, nty, mh, row0, row1,
                       [&](int tile) { atomicAdd(&s_hist[tile], 1); });
     __syncthreads();
     int* row = hist + (size_t)blockIdx.x * T;
@@ -239,9 +253,10 @@ __global__ __launch_bounds__(BIN_BLOCK) void k_tile_emit(
     const float* __restrict__ uvs, const float* __restrict__ xyz_cam,
     const float* __restrict__ conic, int V, int ntx, int nty, float mh, int row0, int row1,
     const int* __restrict__ ranges, int* __restrict__ cursor, uint64_t* __restrict__ keys,
-    const int* __restrict__ v_dev, int64_t cap) {
-    const int g = blockIdx.x * BIN_BLOCK + threadIdx.x;
-    if (g >= (v_dev ? *v_dev : V)) return;
+    Items items, int64_t cap) {
+    const int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
+    if (i >= item_count(items, V)) return;
+    const int g = item_at(items, i);
     const uint64_t key = ((uint64_t)sortable_bits(xyz_cam[g * 3 + 2]) << 32) | (uint32_t)g;
     for_each_tile(uvs, conic, g, ntx, nty, mh, row0, row1, [&](int tile) {
         const int pos = ranges[tile] + atomicAdd(cursor + tile, 1);
@@ -253,15 +268,16 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_emit(
     const float* __restrict__ uvs, const float* __restrict__ xyz_cam,
     const float* __restrict__ conic, int V, int ntx, int nty, float mh, int row0, int row1,
     const int* __restrict__ ranges, const int* __restrict__ hist, uint64_t* __restrict__ keys,
-    const int* __restrict__ v_dev, int64_t cap) {
+    Items items, int64_t cap) {
     extern __shared__ int s_cursor[];
     const int T = ntx * nty;
     const int* row = hist + (size_t)blockIdx.x * T;
     for (int t = threadIdx.x; t < T; t += PRIV_BLOCK) s_cursor[t] = ranges[t] + row[t];
     __syncthreads();
     int g0, g1;
-    slice_of(blockIdx.x, v_dev ? *v_dev : V, g0, g1);
-    for (int g = g0 + threadIdx.x; g < g1; g += PRIV_BLOCK) {
+    slice_of(blockIdx.x, item_count(items, V), g0, g1);
+    for (int i = g0 + threadIdx.x; i < g1; i += PRIV_BLOCK) {
+        const int g = item_at(items, i);
         const uint64_t key = ((uint64_t)sortable_bits(xyz_cam[g * 3 + 2]) << 32) | (uint32_t)g;
         for_each_tile(uvs, conic, g, ntx, nty, mh, row0, row1, [&](int tile) {
             const int pos = atomicAdd(&s_cursor[tile], 1);
@@ -832,8 +848,12 @@ size_t gs_tile_workspace_ints(int n_tiles) {
 }
 
 int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visible_count,
-                  int n_tiles_x, int n_tiles_y, float mh_dist, int tile_row0, int tile_row1,
-                  int32_t* workspace, int32_t* tile_ranges, void* stream) {
+                  const int32_t* subset, const int32_t* subset_count, int n_tiles_x, int n_tiles_y,
+                  float mh_dist, int tile_row0, int tile_row1, int32_t* workspace,
+                  int32_t* tile_ranges, void* stream) {
+    GS_REQUIRE((subset == nullptr) == (subset_count == nullptr),
+               "subset and subset_count go together");
+    const Items items{visible_count, subset, subset_count};
     GS_REQUIRE(n_tiles_x > 0 && n_tiles_y > 0, "tile grid must be positive");
     GS_REQUIRE(tile_row0 >= 0 && tile_row1 <= n_tiles_y && tile_row0 <= tile_row1,
                "bad tile row range");
@@ -844,7 +864,7 @@ int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visi
         int32_t* hist = workspace + T;
         k_bin_count<<<PRIV_NB, PRIV_BLOCK, sizeof(int) * (size_t)T, s>>>(
             (const float*)uvs, (const float*)conic, V, n_tiles_x, n_tiles_y, mh_dist, tile_row0,
-            tile_row1, hist, visible_count);
+            tile_row1, hist, items);
         k_bin_colscan<<<div_up(T, CS_TILES), CS_TILES * CS_SEGS, 0, s>>>(hist, T, counts);
     } else {
         if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)T, s) != hipSuccess) {
@@ -854,7 +874,7 @@ int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visi
         if (V > 0) {
             k_tile_count<<<div_up(V, BIN_BLOCK), BIN_BLOCK, 0, s>>>(
                 (const float*)uvs, (const float*)conic, V, n_tiles_x, n_tiles_y, mh_dist,
-                tile_row0, tile_row1, counts, visible_count);
+                tile_row0, tile_row1, counts, items);
         }
     }
     k_scan_tiles<<<1, 1024, 0, s>>>(counts, T, tile_ranges, visible_count);
@@ -862,12 +882,16 @@ int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visi
 }
 
 int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void* conic, int V,
-                      const int32_t* visible_count, int n_tiles_x, int n_tiles_y, float mh_dist,
+                      const int32_t* visible_count, const int32_t* subset,
+                      const int32_t* subset_count, int n_tiles_x, int n_tiles_y, float mh_dist,
                       int tile_row0, int tile_row1, const int32_t* tile_ranges, int32_t* workspace,
                       uint64_t* keys, int64_t S, int32_t* sorted_gaussians, int sort_prefix,
                       void* stream) {
     GS_REQUIRE(tile_row0 >= 0 && tile_row1 <= n_tiles_y && tile_row0 <= tile_row1,
                "bad tile row range");
+    GS_REQUIRE((subset == nullptr) == (subset_count == nullptr),
+               "subset and subset_count go together");
+    const Items items{visible_count, subset, subset_count};
     GS_REQUIRE(sort_prefix == 0 || sort_prefix == GS_SORT_PREFIX,
                "sort_prefix must be 0 or GS_SORT_PREFIX (%d)", GS_SORT_PREFIX);
     hipStream_t s = (hipStream_t)stream;
@@ -877,7 +901,7 @@ int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void*
         const int32_t* hist = workspace + T;
         k_bin_emit<<<PRIV_NB, PRIV_BLOCK, sizeof(int) * (size_t)T, s>>>(
             (const float*)uvs, (const float*)xyz_camera_frame, (const float*)conic, V, n_tiles_x,
-            n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, hist, keys, visible_count, S);
+            n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, hist, keys, items, S);
     } else {
         int32_t* cursor = workspace;
         if (hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)T, s) != hipSuccess) {
@@ -886,7 +910,7 @@ int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void*
         }
         k_tile_emit<<<div_up(V, BIN_BLOCK), BIN_BLOCK, 0, s>>>(
             (const float*)uvs, (const float*)xyz_camera_frame, (const float*)conic, V, n_tiles_x,
-            n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, cursor, keys, visible_count, S);
+            n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, cursor, keys, items, S);
     }
     const int t0 = tile_row0 * n_tiles_x;
     const int nt = (tile_row1 - tile_row0) * n_tiles_x;

@@ -19,7 +19,8 @@
 //   k_halo_mask        mask[v] + per-256-block counts of every bit
 //   k_halo_scan        exclusive prefix of the block counts, one workgroup per bit
 //   k_halo_bounds      visible-index bounds of the owner slices, P_s at those bounds, the split
-//                      sizes, and the frame's host-read record (S, V, v_lo, v_hi, send, recv)
+//                      sizes, and the frame's host-read record (rows to send, V, v_lo, v_hi, send,
+//                      recv)
 //   k_halo_send_index  the send list
 //   k_halo_gather_sum  out[v - v_lo] = sum over senders of the received rows of v (no atomics)
 #include "tile_math.h"
@@ -133,7 +134,7 @@ __device__ inline int prefix_at(const uint32_t* __restrict__ mask, const int* __
 __global__ __launch_bounds__(GS_WAVE*(GS_MAX_RANKS + 1)) void k_halo_bounds(
     const uint32_t* __restrict__ mask, const int* __restrict__ offsets, int nblk,
     const int* __restrict__ visible_count, const int* __restrict__ pre_offsets, RankInts owner_blk,
-    int G, int me, const int* __restrict__ instance_count, int* __restrict__ vb /*[G+1]*/,
+    int G, int me, int* __restrict__ vb /*[G+1]*/,
     int* __restrict__ Pb /*[G][G+1]*/, int* __restrict__ plan /*[4+2G]*/) {
     __shared__ int s_vb[GS_MAX_RANKS + 1];
     __shared__ int s_P[GS_MAX_RANKS][GS_MAX_RANKS + 1];
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(GS_WAVE*(GS_MAX_RANKS + 1)) void k_halo_bounds(
     __syncthreads();
     const int t = threadIdx.x;
     if (t == 0) {
-        plan[0] = instance_count ? *instance_count : 0;
+        plan[0] = s_P[me][G];   // rows of the send list: every visible Gaussian that reaches my band
         plan[1] = V;
         plan[2] = s_vb[me];
         plan[3] = s_vb[me + 1];
@@ -239,8 +240,8 @@ size_t gs_halo_workspace_ints(int N, int G) {
 int gs_halo_plan(const void* uvs, const void* conic, int N, const int32_t* visible_count,
                  const int32_t* preprocess_workspace, int n_tiles_x, int n_tiles_y, float mh_dist,
                  const int32_t* band_rows, const int32_t* owner_blocks, int G, int rank,
-                 const int32_t* instance_count, uint32_t* mask, int32_t* workspace,
-                 int32_t* send_index, int32_t* plan, void* stream) {
+                 uint32_t* mask, int32_t* workspace, int32_t* send_index, int32_t* plan,
+                 void* stream) {
     GS_REQUIRE(G >= 1 && G <= GS_MAX_RANKS, "halo_plan: 1 <= G <= %d", GS_MAX_RANKS);
     GS_REQUIRE(rank >= 0 && rank < G, "halo_plan: bad rank");
     GS_REQUIRE(N > 0, "halo_plan: N must be positive");
@@ -258,7 +259,7 @@ int gs_halo_plan(const void* uvs, const void* conic, int N, const int32_t* visib
     k_halo_scan<<<G, 1024, 0, s>>>(blk_counts, nblk, offsets);
     k_halo_bounds<<<1, GS_WAVE*(GS_MAX_RANKS + 1), 0, s>>>(
         mask, offsets, nblk, visible_count, pre_offsets, rank_ints(owner_blocks, G + 1), G, rank,
-        instance_count, vb, Pb, plan);
+        vb, Pb, plan);
     k_halo_send_index<<<nblk, HB, 0, s>>>(mask, offsets, nblk, visible_count, rank, send_index);
     return check_launch("halo_plan");
 }

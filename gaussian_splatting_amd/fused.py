@@ -68,9 +68,10 @@ def _pinned_ints(dev, n):
 def preprocess_forward(xyz, quaternion, scale, opacity, rgb, sh, camera_T_world, K, width, height, near_thresh,
                        far_thresh, cull_mask_padding, mh_dist, tile_rows, sort_prefix, plan=None):
     """Per-Gaussian stage, binning and per-tile sort of one frame.  `plan`, if given, is called as
-    plan(f) after the tile count is enqueued and returns a device int32 tensor whose first two
-    entries are (S, V); it is read back instead of the plain (S, V) pair and the host copy is left
-    in f.host (multi-GPU: the split sizes of the gradient exchange ride along)."""
+    plan(f) after the per-Gaussian stage is enqueued and returns a device int32 tensor that rides on
+    the frame's one host read (its host copy is left in f.host: multi-GPU, the split sizes of the
+    gradient exchange); it may set f.subset = (index list, device count) to restrict the binning
+    to those rows."""
     dev = xyz.device
     N = xyz.shape[0]
     n_sh = 1 if sh is None else sh.shape[2] + 1
@@ -101,18 +102,20 @@ def preprocess_forward(xyz, quaternion, scale, opacity, rgb, sh, camera_T_world,
               _p(f.culling_mask), _p(f.rank), _p(f.vis_idx), _p(f.uv), _p(f.xyz_cam), _p(f.conic),
               _p(f.opacity_act), _p(f.rgb_render), _p(f.packed), _stream())
 
+    f.subset = (None, None)
+    record = plan(f) if plan is not None else None
+    subset, subset_n = f.subset
     f.tile_counts = torch.empty(_hip.lib().gs_tile_workspace_ints(T), **i32)
     f.ranges_buf = torch.empty(T + 2, **i32)
-    _hip.call("gs_tile_count", _p(f.uv), _p(f.conic), N, _p(f.count), ntx, nty, _cf(mh_dist), row0, row1,
-              _p(f.tile_counts), _p(f.ranges_buf), _stream())
-    record = plan(f) if plan is not None else f.ranges_buf[T:T + 2]
+    _hip.call("gs_tile_count", _p(f.uv), _p(f.conic), N, _p(f.count), _p(subset), _p(subset_n), ntx, nty,
+              _cf(mh_dist), row0, row1, _p(f.tile_counts), _p(f.ranges_buf), _stream())
 
     def emit_sort(capacity):
         sorted_buf = torch.empty(capacity, **i32)
         keys = torch.empty(capacity, dtype=torch.int64, device=dev)
         if capacity > 0:
-            _hip.call("gs_tile_emit_sort", _p(f.uv), _p(f.xyz_cam), _p(f.conic), N, _p(f.count), ntx, nty,
-                      _cf(mh_dist), row0, row1, _p(f.ranges_buf), _p(f.tile_counts), _p(keys),
+            _hip.call("gs_tile_emit_sort", _p(f.uv), _p(f.xyz_cam), _p(f.conic), N, _p(f.count), _p(subset),
+                      _p(subset_n), ntx, nty, _cf(mh_dist), row0, row1, _p(f.ranges_buf), _p(f.tile_counts), _p(keys),
                       ctypes.c_int64(capacity), _p(sorted_buf), sort_prefix, _stream())
         return sorted_buf, keys
 
@@ -122,9 +125,16 @@ def preprocess_forward(xyz, quaternion, scale, opacity, rgb, sh, camera_T_world,
     # never write beyond the capacity and the step is repeated only if S turned out larger.
     key = (dev.index, N, T, row0, row1)
     guess = _capacity_hint.get(key)
-    host = _pinned_ints(dev, record.numel())
+    n_rec = 0 if record is None else record.numel()
+    host = _pinned_ints(dev, 2 + n_rec)
+
+    def read_back(non_blocking):
+        host[:2].copy_(f.ranges_buf[T:T + 2], non_blocking=non_blocking)
+        if record is not None:
+            host[2:].copy_(record, non_blocking=non_blocking)
+
     if guess is not None:
-        host.copy_(record, non_blocking=True)
+        read_back(True)
         ready = torch.cuda.Event()
         ready.record()
         sorted_buf, keys = emit_sort(guess)
@@ -133,11 +143,11 @@ def preprocess_forward(xyz, quaternion, scale, opacity, rgb, sh, camera_T_world,
         if S > guess:
             sorted_buf, keys = emit_sort(S)
     else:
-        host.copy_(record)
+        read_back(False)
         S, V = int(host[0]), int(host[1])
         sorted_buf, keys = emit_sort(S)
     _capacity_hint[key] = int(S * 1.25) + 4096
-    f.host = host.tolist()
+    f.host = host[2:].tolist()
     f.S, f.V = S, V
     f.sorted_g = sorted_buf[:S]
     f.keys = keys[:S]   # prefix mode: the repair pass of the render sorts flagged tiles from these

@@ -146,8 +146,10 @@ def _band_rows(n_tile_rows, world_size):
 
 
 def enqueue_hip_plan(f, world_size, rank):
-    """preprocess_forward's `plan` hook: enqueues gs_halo_plan after the tile count; the returned
-    device record (S, V, v_lo, v_hi, send[G], recv[G]) rides on the frame's one host read."""
+    """preprocess_forward's `plan` hook: enqueues gs_halo_plan; the returned device record
+    (rows to send, V, v_lo, v_hi, send[G], recv[G]) rides on the frame's one host read, and the
+    send list -- the visible Gaussians whose window reaches this rank's band -- doubles as the
+    subset the binning walks."""
     from . import _hip
     dev = f.uv.device
     i32 = dict(dtype=torch.int32, device=dev)
@@ -160,9 +162,10 @@ def enqueue_hip_plan(f, world_size, rank):
     blks = (ctypes.c_int32 * (G + 1))(*owner_blocks(f.N, G))
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     _hip.call("gs_halo_plan", p(f.uv), p(f.conic), f.N, p(f.count), p(f.ws), f.ntx, f.nty,
-              ctypes.c_float(float(f.mh_dist)), rows, blks, G, rank, p(f.ranges_buf[f.T:]), p(f.halo_mask),
-              p(f.halo_ws), p(f.halo_send_index), p(record),
-              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+              ctypes.c_float(float(f.mh_dist)), rows, blks, G, rank, p(f.halo_mask), p(f.halo_ws),
+              p(f.halo_send_index), p(record), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if G > 1:
+        f.subset = (f.halo_send_index, record)   # record[0] = length of the list
     return record
 
 

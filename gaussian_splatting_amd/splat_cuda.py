@@ -212,13 +212,13 @@ def get_sorted_gaussian_list(max_tiles_per_gaussian, uvs, xyz_camera_frame, coni
     counts = torch.empty(_hip.lib().gs_tile_workspace_ints(T), dtype=torch.int32, device=dev)
     ranges = torch.empty(T + 1, dtype=torch.int32, device=dev)
     mh = ctypes.c_float(mh_dist)
-    _hip.call("gs_tile_count", _p(uvs), _p(conic), V, None, int(n_tiles_x), int(n_tiles_y), mh, row0, row1, _p(counts),
+    _hip.call("gs_tile_count", _p(uvs), _p(conic), V, None, None, None, int(n_tiles_x), int(n_tiles_y), mh, row0, row1, _p(counts),
                           _p(ranges), _stream())
     S = int(ranges[T].item())   # the one host read: sizes the result
     sorted_g = torch.empty(S, dtype=torch.int32, device=dev)
     if S > 0:
         keys = torch.empty(S, dtype=torch.int64, device=dev)
-        _hip.call("gs_tile_emit_sort", _p(uvs), _p(xyz_camera_frame), _p(conic), V, None, int(n_tiles_x), int(n_tiles_y), mh,
+        _hip.call("gs_tile_emit_sort", _p(uvs), _p(xyz_camera_frame), _p(conic), V, None, None, None, int(n_tiles_x), int(n_tiles_y), mh,
                                   row0, row1, _p(ranges), _p(counts), _p(keys), ctypes.c_int64(S), _p(sorted_g),
                                   0, _stream())
     return sorted_g, ranges
@@ -243,7 +243,7 @@ def band_mask(uvs, conic, n_tiles_x, n_tiles_y, mh_dist, band_rows):
     rows = (ctypes.c_int32 * (G + 1))(*[int(r) for r in band_rows])
     blks = (ctypes.c_int32 * (G + 1))(*([0] * G + [nblk]))
     _hip.call("gs_halo_plan", _p(uvs), _p(conic), V, _p(count), _p(pre_ws), int(n_tiles_x), int(n_tiles_y),
-              ctypes.c_float(float(mh_dist)), rows, blks, G, 0, None, _p(mask), _p(ws), _p(send_index), _p(plan),
+              ctypes.c_float(float(mh_dist)), rows, blks, G, 0, _p(mask), _p(ws), _p(send_index), _p(plan),
               _stream())
     return mask
 

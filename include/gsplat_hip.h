@@ -99,6 +99,10 @@ int gs_precompute_rgb_from_sh_backward(const void* xyz, const void* matrix, cons
  *   capacity-V buffers whose fill level only the device knows (gs_preprocess_forward); rows
  *   beyond it are ignored and tile_ranges then has T+2 entries, [T+1] = *visible_count, so that
  *   one 8-byte read returns S and V.  Pass the same V and visible_count to both calls.
+ * subset, subset_count: both NULL, or a device list of row indices and a device pointer to its
+ *   length: only those rows are tested (multi-GPU band mode: the Gaussians whose candidate window
+ *   reaches the rank's rows, gs_halo_plan's send_index).  The list must contain every row that has
+ *   a tile in [tile_row0, tile_row1); the resulting lists are then the same as without it.
  * workspace: int32[gs_tile_workspace_ints(n_tiles)] scratch written by step 1 and read by step 2
  *   (per-workgroup tile histograms; keep it untouched between the two calls);
  * keys: uint64[S] scratch.  S may be an over-estimate (a capacity): instances beyond it are not
@@ -115,10 +119,12 @@ int gs_precompute_rgb_from_sh_backward(const void* xyz, const void* matrix, cons
  *   `keys` (gs_tile_sort_flagged) and renders them again -- plain enqueues, no host read. */
 size_t gs_tile_workspace_ints(int n_tiles);
 int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visible_count,
-                  int n_tiles_x, int n_tiles_y, float mh_dist, int tile_row0, int tile_row1,
-                  int32_t* workspace, int32_t* tile_ranges /*[T+1] or [T+2]*/, void* stream);
+                  const int32_t* subset, const int32_t* subset_count, int n_tiles_x, int n_tiles_y,
+                  float mh_dist, int tile_row0, int tile_row1, int32_t* workspace,
+                  int32_t* tile_ranges /*[T+1] or [T+2]*/, void* stream);
 int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void* conic, int V,
-                      const int32_t* visible_count, int n_tiles_x, int n_tiles_y, float mh_dist,
+                      const int32_t* visible_count, const int32_t* subset,
+                      const int32_t* subset_count, int n_tiles_x, int n_tiles_y, float mh_dist,
                       int tile_row0, int tile_row1, const int32_t* tile_ranges, int32_t* workspace,
                       uint64_t* keys, int64_t S, int32_t* sorted_gaussians /*[S]*/, int sort_prefix,
                       void* stream);
@@ -236,13 +242,13 @@ int gs_render_depth(const void* packed, const void* xyz_camera_frame, const int3
  * backward for them, so the partial render gradients of the bands are exchanged sparsely: a row
  * travels only from a rank whose band the Gaussian's candidate tile window reaches to its owner.
  *
- * gs_halo_plan (after gs_preprocess_forward and gs_tile_count of the same frame; inputs are the
- * capacity-N buffers and the device-side visible_count):
+ * gs_halo_plan (after gs_preprocess_forward of the same frame; inputs are the capacity-N buffers
+ * and the device-side visible_count):
  *   mask[N]        bit s = visible Gaussian v reaches the band of rank s
  *   send_index[N]  the visible indices with bit `rank`, ascending: row k of the send buffer is
  *                  grad_slab[send_index[k]]; consecutive owners' parts, plan[4 + r] rows for owner r
- *   plan[4 + 2G]   device record for the frame's one host read: S (= *instance_count, or 0),
- *                  V, v_lo, v_hi (visible-index range of the Gaussians this rank owns),
+ *   plan[4 + 2G]   device record for the frame's host read: number of rows in send_index, V,
+ *                  v_lo, v_hi (visible-index range of the Gaussians this rank owns),
  *                  send counts [G], receive counts [G]
  *   workspace      int32[gs_halo_workspace_ints(N, G)], read again by gs_halo_gather_sum
  * band_rows, owner_blocks: host arrays of G + 1 ints.  G <= GS_MAX_RANKS.
@@ -256,8 +262,8 @@ size_t gs_halo_workspace_ints(int N, int G);
 int gs_halo_plan(const void* uvs, const void* conic, int N, const int32_t* visible_count,
                  const int32_t* preprocess_workspace, int n_tiles_x, int n_tiles_y, float mh_dist,
                  const int32_t* band_rows, const int32_t* owner_blocks, int G, int rank,
-                 const int32_t* instance_count, uint32_t* mask, int32_t* workspace,
-                 int32_t* send_index, int32_t* plan, void* stream);
+                 uint32_t* mask, int32_t* workspace, int32_t* send_index, int32_t* plan,
+                 void* stream);
 int gs_halo_gather_sum(const uint32_t* mask, const int32_t* workspace, int N, int G, int rank,
                        int v_lo, int v_hi, const void* recv, const int32_t* recv_offsets,
                        void* out, void* stream);

@@ -9,7 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gaussian_splatting_amd import _hip, fused
-from gaussian_splatting_amd.sharded import band_of
+from gaussian_splatting_amd.sharded import ShardedRasterizer, band_of, owned_slice
 from gaussian_splatting_amd.synthetic import DEFAULTS, WORKLOADS, make_grad_image, make_scene
 
 ap = argparse.ArgumentParser()
@@ -17,6 +17,8 @@ ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--rank", type=int, default=3)
 ap.add_argument("--workload", default="D")
 ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--grad-mode", default="replicated", choices=["replicated", "owner"],
+                help="owner: the sparse-exchange path with the all_to_all replaced by a local fill (compute only)")
 a = ap.parse_args()
 N, W, H, deg = WORKLOADS[a.workload]
 g, cam, T = make_scene(N, W, H, deg, seed=0, device="cuda")
@@ -28,7 +30,27 @@ bg = torch.zeros(3, device="cuda")
 rows = band_of((H + 15) // 16, a.world, a.rank)
 
 
+moved = {}
+if a.grad_mode == "owner":
+    def fake_a2a(recv, send, recv_splits, send_splits):
+        moved["send_rows"], moved["recv_rows"] = sum(send_splits), sum(recv_splits)
+        moved["send_rows_remote"] = sum(send_splits) - send_splits[a.rank]
+        recv.zero_()
+
+    for p in params:
+        p.requires_grad_(False)
+    owned = owned_slice(g, a.world, a.rank)
+    rast = ShardedRasterizer(H, a.world, a.rank, grad_mode="owner", all_to_all=fake_a2a)
+
+
 def step():
+    if a.grad_mode == "owner":
+        for p in (owned.xyz, owned.rgb, owned.opacity, owned.scale, owned.quaternion, owned.sh):
+            if p is not None:
+                p.grad = None
+        img, _, _ = rast.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, owned=owned, **DEFAULTS)
+        img.backward(gi)
+        return
     for p in params:
         p.grad = None
     img, _, _ = fused.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, tile_rows=rows, **DEFAULTS)
@@ -46,4 +68,4 @@ torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / a.steps * 1e3
 t = _hip.collect_timing()
 print(f"world {a.world} rank {a.rank} rows {rows}: {ms:.3f} ms/step",
-      {k: round(sum(v) / len(v), 4) for k, v in sorted(t.items())})
+      {k: round(sum(v) / len(v), 4) for k, v in sorted(t.items())}, moved)

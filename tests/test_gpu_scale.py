@@ -189,14 +189,14 @@ def test_prefix_sort_selects_the_nearest_entries():
     uv_d, xyz_d, conic_d = uv.to(DEV), xyz_c.to(DEV), conic.to(DEV)
     ws = torch.empty(_hip.lib().gs_tile_workspace_ints(ntx), dtype=torch.int32, device=DEV)
     ranges = torch.empty(ntx + 1, dtype=torch.int32, device=DEV)
-    _hip.call("gs_tile_count", p(uv_d), p(conic_d), V, None, ntx, 1, ctypes.c_float(3.0), 0, 1, p(ws), p(ranges),
-              stream)
+    _hip.call("gs_tile_count", p(uv_d), p(conic_d), V, None, None, None, ntx, 1, ctypes.c_float(3.0), 0, 1, p(ws),
+              p(ranges), stream)
     assert torch.equal(ranges.cpu(), ref_ranges)
     S = int(ranges[-1])
     keys = torch.empty(S, dtype=torch.int64, device=DEV)
     got = torch.full((S,), -1, dtype=torch.int32, device=DEV)
-    _hip.call("gs_tile_emit_sort", p(uv_d), p(xyz_d), p(conic_d), V, None, ntx, 1, ctypes.c_float(3.0), 0, 1,
-              p(ranges), p(ws), p(keys), ctypes.c_int64(S), p(got), _hip.GS_SORT_PREFIX, stream)
+    _hip.call("gs_tile_emit_sort", p(uv_d), p(xyz_d), p(conic_d), V, None, None, None, ntx, 1, ctypes.c_float(3.0),
+              0, 1, p(ranges), p(ws), p(keys), ctypes.c_int64(S), p(got), _hip.GS_SORT_PREFIX, stream)
     got = got.cpu()
     for t, n in enumerate(sizes):
         s0 = int(ref_ranges[t])

@@ -34,12 +34,13 @@ def test_halo_plan_matches_reference_and_oracle(G):
     N, W, H, deg = 30000, 640, 472, 0
     g, cam, T = make_scene(N, W, H, deg, seed=13, device=DEV)
     nty = (H + 15) // 16
+    rows = _band_rows(nty, G)
     for me in sorted({0, G // 2, G - 1}):
         f = fused.preprocess_forward(g.xyz, g.quaternion, g.scale, g.opacity, g.rgb, None, T, cam.K, W, H, *ARGS,
-                                     (0, nty), 0, plan=lambda fr: enqueue_hip_plan(fr, G, me))
+                                     (rows[me], rows[me + 1]), 0, plan=lambda fr: enqueue_hip_plan(fr, G, me))
         plan = finish_hip_plan(f, G, me)
         V = f.V
-        assert 0 < V < N and f.host[0] == f.S and f.host[1] == V
+        assert 0 < V < N and f.host[0] == sum(plan.send_splits) and f.host[1] == V
         mask = f.halo_mask[:V]
         ref_mask = gs_oracle.band_mask(f.uv[:V].cpu(), f.conic[:V].cpu(), f.ntx, f.nty, ARGS[3], _band_rows(nty, G))
         assert torch.equal(mask.cpu(), ref_mask)
@@ -55,14 +56,15 @@ def test_halo_plan_matches_reference_and_oracle(G):
         recv = torch.randn(sum(plan.recv_splits), 9, device=DEV)
         assert torch.allclose(plan.unpack(recv), ref.unpack(recv), atol=1e-6)
         # a Gaussian that reaches no band of the frame has no tile: the masks cover every instance
+        # and binning over the send list gives the band's tile lists of a plain (all-rows) binning
         if G > 1:
             band = (plan.mask[:V] >> me) & 1
-            rows = _band_rows(nty, G)
             fb = fused.preprocess_forward(g.xyz, g.quaternion, g.scale, g.opacity, g.rgb, None, T, cam.K, W, H,
                                           *ARGS, (rows[me], rows[me + 1]), 0)
             touched = torch.zeros(V, dtype=torch.bool, device=DEV)
             touched[fb.sorted_g.long()] = True
             assert bool((touched <= band.bool()).all())
+            assert torch.equal(fb.ranges, f.ranges) and torch.equal(fb.sorted_g, f.sorted_g)
 
 
 @pytest.mark.parametrize("G,deg,N,W,H", [(2, 3, 20000, 640, 472), (3, 0, 20000, 640, 472), (8, 3, 60000, 800, 608)])
