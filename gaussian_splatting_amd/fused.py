@@ -33,6 +33,7 @@ def _p(t):
 
 
 def _stream():
+    # torch.cuda.current_stream() costs ~10 us of host time: every stage asks once and passes it on
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -62,20 +63,35 @@ def _pinned_ints(dev, n):
     return buf
 
 
+class _Arena:
+    """one allocation cut into 1-D blocks of the given element counts, each starting 16-byte aligned"""
+
+    def __init__(self, dtype, device, sizes):
+        self.offsets, off = [], 0
+        for n in sizes:
+            self.offsets.append((off, n))
+            off += (n + 3) & ~3
+        self.buf = torch.empty(off, dtype=dtype, device=device)
+
+    def blocks(self):
+        return [self.buf[o:o + n] for o, n in self.offsets]
+
+
 # ---------------------------------------------------------------------------------------------------
 # stages
 # ---------------------------------------------------------------------------------------------------
 def preprocess_forward(xyz, quaternion, scale, opacity, rgb, sh, camera_T_world, K, width, height, near_thresh,
-                       far_thresh, cull_mask_padding, mh_dist, tile_rows, sort_prefix, plan=None):
+                       far_thresh, cull_mask_padding, mh_dist, tile_rows, sort_prefix, plan=None, plan_ints=0,
+                       defer=False):
     """Per-Gaussian stage, binning and per-tile sort of one frame.  `plan`, if given, is called as
-    plan(f) after the per-Gaussian stage is enqueued and returns a device int32 tensor that rides on
-    the frame's one host read (its host copy is left in f.host: multi-GPU, the split sizes of the
-    gradient exchange); it may set f.subset = (index list, device count) to restrict the binning
-    to those rows."""
+    plan(f) after the per-Gaussian stage is enqueued and fills the device record f.record
+    (plan_ints int32) that rides on the frame's one host read (its host copy is left in f.host:
+    multi-GPU, the split sizes of the gradient exchange); it may set f.subset = (index list, device
+    count) to restrict the binning to those rows.  defer=True returns before the host read: the caller may enqueue the render on
+    the speculative lists (f.sorted_buf, f.keys_buf, f.capacity) and calls preprocess_finish(f)."""
     dev = xyz.device
     N = xyz.shape[0]
     n_sh = 1 if sh is None else sh.shape[2] + 1
-    f32 = dict(dtype=torch.float32, device=dev)
     i32 = dict(dtype=torch.int32, device=dev)
     ntx = (width + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
     nty = (height + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
@@ -84,31 +100,32 @@ def preprocess_forward(xyz, quaternion, scale, opacity, rgb, sh, camera_T_world,
     f = SimpleNamespace(N=N, n_sh=n_sh, ntx=ntx, nty=nty, T=T, row0=row0, row1=row1, width=width, height=height,
                         mh_dist=mh_dist, sort_prefix=sort_prefix)
 
-    f.ws = torch.empty(_hip.lib().gs_preprocess_workspace_ints(N), **i32)
-    f.center = torch.empty(3, **f32)
-    f.count = torch.empty(1, **i32)
-    f.culling_mask = torch.empty(N, dtype=torch.bool, device=dev)   # kernel writes 0/1 bytes
-    f.rank = torch.empty(N, **i32)
-    f.vis_idx = torch.empty(N, **i32)
-    f.uv = torch.empty(N, 2, **f32)
-    f.xyz_cam = torch.empty(N, 3, **f32)
-    f.conic = torch.empty(N, 3, **f32)
-    f.opacity_act = torch.empty(N, 1, **f32)
-    f.rgb_render = torch.empty(N, 3, **f32)
-    f.packed = torch.empty(N, 12, **f32)
+    stream = f.stream = _stream()
+    # two allocations for the stage's buffers (host time matters at ~1 ms per frame): an int32 arena
+    # for the bookkeeping and a float32 arena for the per-Gaussian outputs, blocks 16-byte aligned
+    n_ws = _hip.lib().gs_preprocess_workspace_ints(N)
+    n_tc = _hip.lib().gs_tile_workspace_ints(T)
+    iar = _Arena(torch.int32, dev, (n_ws, 1, N, N, n_tc, T + 2 + plan_ints, (N + 3) // 4))
+    f.ws, f.count, f.rank, f.vis_idx, f.tile_counts, f.ranges_buf, mask_bytes = iar.blocks()
+    f.culling_mask = mask_bytes.view(torch.bool)[:N]   # kernel writes 0/1 bytes
+    far = _Arena(torch.float32, dev, (3, 2 * N, 3 * N, 3 * N, N, 3 * N, 12 * N))
+    f.center, uv, xyz_cam, conic, opa, rgbr, packed = far.blocks()
+    f.uv, f.xyz_cam, f.conic = uv.view(N, 2), xyz_cam.view(N, 3), conic.view(N, 3)
+    f.opacity_act, f.rgb_render, f.packed = opa.view(N, 1), rgbr.view(N, 3), packed.view(N, 12)
     _hip.call("gs_preprocess_forward", _p(xyz), _p(quaternion), _p(scale), _p(opacity), _p(rgb), _p(sh), n_sh,
               _p(camera_T_world), _p(K), N, width, height, _cf(near_thresh), _cf(far_thresh),
               _cf(cull_mask_padding), _cf(mh_dist), row0, row1, _p(f.ws), _p(f.center), _p(f.count),
               _p(f.culling_mask), _p(f.rank), _p(f.vis_idx), _p(f.uv), _p(f.xyz_cam), _p(f.conic),
-              _p(f.opacity_act), _p(f.rgb_render), _p(f.packed), _stream())
+              _p(f.opacity_act), _p(f.rgb_render), _p(f.packed), stream)
 
+    # the plan's record lives right behind (S, V) at the tail of ranges_buf: one host read gets both
     f.subset = (None, None)
-    record = plan(f) if plan is not None else None
+    f.record = f.ranges_buf[T + 2:]
+    if plan is not None:
+        plan(f)
     subset, subset_n = f.subset
-    f.tile_counts = torch.empty(_hip.lib().gs_tile_workspace_ints(T), **i32)
-    f.ranges_buf = torch.empty(T + 2, **i32)
     _hip.call("gs_tile_count", _p(f.uv), _p(f.conic), N, _p(f.count), _p(subset), _p(subset_n), ntx, nty,
-              _cf(mh_dist), row0, row1, _p(f.tile_counts), _p(f.ranges_buf), _stream())
+              _cf(mh_dist), row0, row1, _p(f.tile_counts), _p(f.ranges_buf), stream)
 
     def emit_sort(capacity):
         sorted_buf = torch.empty(capacity, **i32)
@@ -116,43 +133,56 @@ def preprocess_forward(xyz, quaternion, scale, opacity, rgb, sh, camera_T_world,
         if capacity > 0:
             _hip.call("gs_tile_emit_sort", _p(f.uv), _p(f.xyz_cam), _p(f.conic), N, _p(f.count), _p(subset),
                       _p(subset_n), ntx, nty, _cf(mh_dist), row0, row1, _p(f.ranges_buf), _p(f.tile_counts), _p(keys),
-                      ctypes.c_int64(capacity), _p(sorted_buf), sort_prefix, _stream())
+                      ctypes.c_int64(capacity), _p(sorted_buf), sort_prefix, stream)
         return sorted_buf, keys
 
     # The frame's only device->host read: (S, V) [+ the plan's record], to size the outputs.  If a
     # previous frame of the same shape is known, the emit + sort are enqueued first with a capacity
     # guessed from it, so the GPU keeps working while the host waits for the integers; the kernels
     # never write beyond the capacity and the step is repeated only if S turned out larger.
-    key = (dev.index, N, T, row0, row1)
-    guess = _capacity_hint.get(key)
-    n_rec = 0 if record is None else record.numel()
-    host = _pinned_ints(dev, 2 + n_rec)
+    f.emit_sort = emit_sort
+    f.hint_key = (dev.index, N, T, row0, row1)
+    guess = _capacity_hint.get(f.hint_key)
+    f.host_buf = _pinned_ints(dev, 2 + plan_ints)
 
     def read_back(non_blocking):
-        host[:2].copy_(f.ranges_buf[T:T + 2], non_blocking=non_blocking)
-        if record is not None:
-            host[2:].copy_(record, non_blocking=non_blocking)
+        f.host_buf.copy_(f.ranges_buf[T:], non_blocking=non_blocking)
 
-    if guess is not None:
+    f.ranges = f.ranges_buf[:T + 1]
+    f.speculative = guess is not None
+    if f.speculative:
         read_back(True)
-        ready = torch.cuda.Event()
-        ready.record()
-        sorted_buf, keys = emit_sort(guess)
-        ready.synchronize()
-        S, V = int(host[0]), int(host[1])
-        if S > guess:
-            sorted_buf, keys = emit_sort(S)
+        f.ready = torch.cuda.Event()
+        f.ready.record()
+        f.capacity = guess
+        f.sorted_buf, f.keys_buf = emit_sort(guess)
     else:
         read_back(False)
-        S, V = int(host[0]), int(host[1])
-        sorted_buf, keys = emit_sort(S)
-    _capacity_hint[key] = int(S * 1.25) + 4096
-    f.host = host[2:].tolist()
-    f.S, f.V = S, V
-    f.sorted_g = sorted_buf[:S]
-    f.keys = keys[:S]   # prefix mode: the repair pass of the render sorts flagged tiles from these
-    f.ranges = f.ranges_buf[:T + 1]
+        f.capacity = int(f.host_buf[0])
+        f.sorted_buf, f.keys_buf = emit_sort(f.capacity)
+    if not defer:
+        preprocess_finish(f)
     return f
+
+
+def preprocess_finish(f):
+    """Waits for the frame's host read and fixes the sizes (f.S, f.V, f.sorted_g, f.keys, f.host).
+    -> True if the speculative capacity was too small and emit + sort were repeated (anything
+    enqueued on the speculative lists in between has to be repeated too)."""
+    redone = False
+    if f.speculative:
+        f.ready.synchronize()
+    S, V = int(f.host_buf[0]), int(f.host_buf[1])
+    if S > f.capacity:
+        f.sorted_buf, f.keys_buf = f.emit_sort(S)
+        f.capacity = S
+        redone = True
+    _capacity_hint[f.hint_key] = int(S * 1.25) + 4096
+    f.host = f.host_buf.tolist()[2:]
+    f.S, f.V = S, V
+    f.sorted_g = f.sorted_buf[:S]
+    f.keys = f.keys_buf[:S]   # prefix mode: the repair pass of the render sorts flagged tiles from these
+    return redone
 
 
 def preprocess_backward(xyz, quaternion, scale, camera_T_world, K, f, slab, v_base=0, i0=0, i1=None):
@@ -161,13 +191,11 @@ def preprocess_backward(xyz, quaternion, scale, camera_T_world, K, f, slab, v_ba
     i1 = f.N if i1 is None else i1
     n = i1 - i0
     dev = xyz.device
-    f32 = dict(dtype=torch.float32, device=dev)
-    grad_xyz = torch.empty(n, 3, **f32)
-    grad_q = torch.empty(n, 4, **f32)
-    grad_scale = torch.empty(n, 3, **f32)
-    grad_opacity = torch.empty(n, 1, **f32)
-    grad_rgb = torch.empty(n, 3, **f32)
-    grad_sh = torch.empty(n, 3, f.n_sh - 1, **f32) if f.n_sh > 1 else None
+    n_extra = 3 * (f.n_sh - 1)
+    gx, gq, gs, go, gc, gsh = _Arena(torch.float32, dev, (3 * n, 4 * n, 3 * n, n, 3 * n, n_extra * n)).blocks()
+    grad_xyz, grad_q, grad_scale = gx.view(n, 3), gq.view(n, 4), gs.view(n, 3)
+    grad_opacity, grad_rgb = go.view(n, 1), gc.view(n, 3)
+    grad_sh = gsh.view(n, 3, f.n_sh - 1) if f.n_sh > 1 else None
     if n > 0:
         _hip.call("gs_preprocess_backward", _p(xyz[i0:i1]), _p(quaternion[i0:i1]), _p(scale[i0:i1]), f.n_sh,
                   _p(camera_T_world), _p(K), _p(f.center), _p(f.rank[i0:i1]), _p(f.opacity_act), _p(slab),
@@ -176,28 +204,36 @@ def preprocess_backward(xyz, quaternion, scale, camera_T_world, K, f, slab, v_ba
     return grad_xyz, grad_q, grad_scale, grad_opacity, grad_rgb, grad_sh
 
 
-def render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, width, tile_rows, sort_prefix):
+def render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, width, tile_rows, sort_prefix,
+                   image_rows=None):
+    """-> image, splat counts, final weights.  image_rows > height: the image buffer gets that many
+    rows (the multi-GPU gather wants equal-sized bands); the kernels only see the first `height`."""
     dev = packed.device
     ntx = (width + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
     nty = (height + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
     row0, row1 = tile_rows if tile_rows is not None else (0, nty)
-    # rows outside [row0, row1) are not written by the kernel: zero-fill only when sharded
+    # one allocation: image [H,W,3] | final weight [H,W] | splat count [H,W] (int32 view).  Rows outside
+    # [row0, row1) are not written by the kernel: zero-fill only when sharded
     alloc = torch.empty if tile_rows is None else torch.zeros
-    image = alloc(height, width, 3, dtype=torch.float32, device=dev)
-    nsp = alloc(height, width, dtype=torch.int32, device=dev)
-    fw = alloc(height, width, dtype=torch.float32, device=dev)
+    P = height * width
+    PI = (image_rows if image_rows is not None else height) * width
+    buf = alloc(3 * PI + 2 * P, dtype=torch.float32, device=dev)
+    image = buf[:3 * PI].view(-1, width, 3)
+    fw = buf[3 * PI:3 * PI + P].view(height, width)
+    nsp = buf[3 * PI + P:].view(torch.int32).view(height, width)
+    stream = _stream()
     if sort_prefix and sorted_g.shape[0] > sort_prefix:
         # provisional render from the ordered prefixes; tiles that ran out of prefix are flagged,
         # sorted in full and rendered again -- one call, the host never looks at the flags
         flags = torch.empty(ntx * nty, dtype=torch.int32, device=dev)
         _hip.call("gs_render_tiles_prefix", _p(packed), _p(rgb), _p(ranges), _p(sorted_g), _p(keys),
                   ctypes.c_int64(sorted_g.shape[0]), _p(background_rgb), width, height, row0, row1, _p(flags),
-                  _p(nsp), _p(fw), _p(image), _stream())
+                  _p(nsp), _p(fw), _p(image), stream)
         global last_tile_flags
         last_tile_flags = flags
     else:
         _hip.call("gs_render_tiles", _p(packed), _p(rgb), None, _p(ranges), _p(sorted_g), _p(background_rgb),
-                  width, height, 1, row0, row1, _p(nsp), _p(fw), _p(image), _hip.GS_F32, _stream())
+                  width, height, 1, row0, row1, _p(nsp), _p(fw), _p(image), _hip.GS_F32, stream)
     return image, nsp, fw
 
 

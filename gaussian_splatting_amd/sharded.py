@@ -4,8 +4,8 @@ code runs over gloo on CPU tensors for tests.
 
 Per frame, on every rank (Gaussian parameters are replicated):
   forward   per-Gaussian stage for all N (cheap, replicated) -> binning, sort and render ONLY for the
-            rank's band of tile rows -> all-reduce(SUM) of the image: every other rank contributes
-            zeros outside its band, so the sum is the gather (12 B/px, ~13 MB at 1 MP).
+            rank's band of tile rows -> all-gather of the band images (12 B/px of the own band
+            out, ~13 MB in total at 1 MP).
   backward  every rank holds the same grad_image (the loss is evaluated on the gathered image on
             every rank); render backward over the rank's band gives PARTIAL per-Gaussian gradients
             (colour 3, opacity 1, uv 2, conic 3 floats: a Gaussian can straddle bands).  Then, by
@@ -33,15 +33,23 @@ import torch.distributed as dist
 
 from .splat_py.structs import Gaussians
 
+DEFER_HOST_READ = True    # owner fused path: enqueue the render before waiting for the frame's counts
 OWNER_BLOCK = 256   # owner slices are whole blocks of the per-Gaussian kernels (csrc/halo.hip)
 SLAB_WIDTH = 9      # rgb 3 | opacity 1 | uv 2 | conic 3
 
 
+def band_rows_per_rank(n_tile_rows, world_size):
+    return (n_tile_rows + world_size - 1) // world_size
+
+
 def band_of(n_tile_rows, world_size, rank):
-    """Contiguous, near-equal split of the tile rows: [row0, row1) of `rank`."""
-    base, rem = divmod(n_tile_rows, world_size)
-    row0 = rank * base + min(rank, rem)
-    return row0, row0 + base + (1 if rank < rem else 0)
+    """Contiguous split of the tile rows, [row0, row1) of `rank`: every band has
+    ceil(rows / world_size) rows except the last ones, which take what is left (possibly nothing).
+    Equal-sized bands let the image be all-gathered in place; the largest band -- which sets the
+    frame time -- is as small as with any other contiguous split."""
+    base = band_rows_per_rank(n_tile_rows, world_size)
+    row0 = min(n_tile_rows, rank * base)
+    return row0, min(n_tile_rows, row0 + base)
 
 
 def owner_blocks(N, world_size):
@@ -106,7 +114,9 @@ class HaloPlan:
     def unpack(self, recv):
         """[sum(recv_splits), 9] -> the summed rows of the owned visible range [v_hi - v_lo, 9]"""
         n = self.v_hi - self.v_lo
-        out = torch.zeros(max(n, 1), SLAB_WIDTH, dtype=recv.dtype, device=recv.device)[:n]
+        # the HIP kernel writes every row of the range; the index_add form accumulates onto zeros
+        alloc = torch.empty if self.hip is not None else torch.zeros
+        out = alloc(max(n, 1), SLAB_WIDTH, dtype=recv.dtype, device=recv.device)[:n]
         if n == 0:
             return out
         if self.hip is not None:
@@ -145,28 +155,28 @@ def _band_rows(n_tile_rows, world_size):
     return [band_of(n_tile_rows, world_size, r)[0] for r in range(world_size)] + [n_tile_rows]
 
 
+def plan_record_ints(world_size):
+    return 4 + 2 * world_size
+
+
 def enqueue_hip_plan(f, world_size, rank):
-    """preprocess_forward's `plan` hook: enqueues gs_halo_plan; the returned device record
+    """preprocess_forward's `plan` hook: enqueues gs_halo_plan; the device record f.record
     (rows to send, V, v_lo, v_hi, send[G], recv[G]) rides on the frame's one host read, and the
     send list -- the visible Gaussians whose window reaches this rank's band -- doubles as the
     subset the binning walks."""
     from . import _hip
-    dev = f.uv.device
-    i32 = dict(dtype=torch.int32, device=dev)
     G = world_size
-    f.halo_mask = torch.empty(f.N, **i32)
-    f.halo_ws = torch.empty(_hip.lib().gs_halo_workspace_ints(f.N, G), **i32)
-    f.halo_send_index = torch.empty(f.N, **i32)
-    record = torch.empty(4 + 2 * G, **i32)
+    n_ws = _hip.lib().gs_halo_workspace_ints(f.N, G)
+    buf = torch.empty(2 * f.N + n_ws, dtype=torch.int32, device=f.uv.device)
+    f.halo_mask, f.halo_send_index, f.halo_ws = buf[:f.N], buf[f.N:2 * f.N], buf[2 * f.N:]
     rows = (ctypes.c_int32 * (G + 1))(*_band_rows(f.nty, G))
     blks = (ctypes.c_int32 * (G + 1))(*owner_blocks(f.N, G))
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     _hip.call("gs_halo_plan", p(f.uv), p(f.conic), f.N, p(f.count), p(f.ws), f.ntx, f.nty,
               ctypes.c_float(float(f.mh_dist)), rows, blks, G, rank, p(f.halo_mask), p(f.halo_ws),
-              p(f.halo_send_index), p(record), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+              p(f.halo_send_index), p(f.record), f.stream)
     if G > 1:
-        f.subset = (f.halo_send_index, record)   # record[0] = length of the list
-    return record
+        f.subset = (f.halo_send_index, f.record)   # record[0] = length of the list
 
 
 def finish_hip_plan(f, world_size, rank):
@@ -180,15 +190,27 @@ def finish_hip_plan(f, world_size, rank):
 # ---------------------------------------------------------------------------------------------------
 # autograd pieces
 # ---------------------------------------------------------------------------------------------------
+def gather_bands(image, band_pixels, world_size, rank, group=None):
+    """image [>= world_size * band_pixels / W rows, W, 3] holding this rank's band at rows
+    [rank * band, (rank + 1) * band): all-gather so that every rank holds every band (12 B/px of
+    the own band out, the rest in -- 1/8 of an all-reduce's traffic at 8 ranks)."""
+    flat = image.view(-1)[:world_size * band_pixels]
+    mine = flat[rank * band_pixels:(rank + 1) * band_pixels].clone()
+    dist.all_gather_into_tensor(flat, mine, group=group)
+    return image
+
+
 class _GatherImage(torch.autograd.Function):
-    """forward: sum over ranks of band images (disjoint support == gather); backward: identity,
-    because every rank evaluates the same loss on the same gathered image."""
+    """forward: all-gather of the band images; backward: identity, because every rank evaluates
+    the same loss on the same gathered image."""
 
     @staticmethod
-    def forward(ctx, image, group):
-        out = image.clone()
-        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
-        return out
+    def forward(ctx, image, rast):
+        H, W = image.shape[0], image.shape[1]
+        out = torch.zeros(rast.padded_height, W, 3, dtype=image.dtype, device=image.device)
+        out[:H] = image
+        gather_bands(out, rast.band_pixel_rows * W * 3, rast.world_size, rast.rank, rast.group)
+        return out[:H]
 
     @staticmethod
     def backward(ctx, grad):
@@ -249,19 +271,30 @@ class _OwnerFrameFused(torch.autograd.Function):
         from . import _hip, fused
         G, me = rast.world_size, rast.rank
         sort_prefix = _hip.GS_SORT_PREFIX if fused.SORT_PREFIX else 0
-        sh = g.sh.contiguous() if g.sh is not None else None
-        full = (g.xyz.detach().contiguous(), g.quaternion.detach().contiguous(), g.scale.detach().contiguous(),
-                g.opacity.detach().contiguous(), g.rgb.detach().contiguous(),
-                sh.detach() if sh is not None else None)
+        full = tuple(None if t is None else (t if t.is_contiguous() else t.contiguous())
+                     for t in (g.xyz, g.quaternion, g.scale, g.opacity, g.rgb, g.sh))   # values only (no_grad here)
         f = fused.preprocess_forward(*full, camera_T_world, K, width, height, near_thresh, far_thresh,
                                      cull_mask_padding, mh_dist, rast.tile_rows, sort_prefix,
-                                     plan=lambda fr: enqueue_hip_plan(fr, G, me))
+                                     plan=lambda fr: enqueue_hip_plan(fr, G, me), plan_ints=plan_record_ints(G),
+                                     defer=True)
+        if not DEFER_HOST_READ:
+            fused.preprocess_finish(f)
+
+
+        def render():
+            return fused.render_forward(f.packed, f.rgb_render, f.ranges, f.sorted_buf, f.keys_buf, background_rgb,
+                                        height, width, rast.tile_rows, sort_prefix, image_rows=rast.padded_height)
+
+        # the render is enqueued on the speculative tile lists before the host looks at the frame's
+        # counts, so the GPU does not wait for the host; a too small capacity repeats it (rare)
+        out = render() if (f.speculative and DEFER_HOST_READ) else None
+        if (DEFER_HOST_READ and fused.preprocess_finish(f)) or out is None:
+            out = render()
+        image, nsp, fw = out
         plan = finish_hip_plan(f, G, me)
         V = f.V
         rgb_v = f.rgb_render[:V]
-        image, nsp, fw = fused.render_forward(f.packed, rgb_v, f.ranges, f.sorted_g, f.keys, background_rgb,
-                                              height, width, rast.tile_rows, sort_prefix)
-        rast.gather_image_(image)
+        image = rast.gather_image_(image)[:height]
         ctx.save_for_backward(full[0], full[1], full[2], camera_T_world, K, f.packed, rgb_v, f.ranges, f.sorted_g,
                               background_rgb, nsp, fw)
         ctx.f, ctx.plan, ctx.rast, ctx.dims = f, plan, rast, (height, width)
@@ -334,8 +367,7 @@ class _OwnerFrameGeneric(torch.autograd.Function):
             rast.last_plan = state["plan"]
         ctx.rep, ctx.local_image, ctx.names = rep, image, names
         ctx.range = owner_range(N, G, me)
-        out = image.detach().clone()
-        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=rast.group)
+        out = _GatherImage.forward(None, image.detach(), rast)
         uv_out = uv.detach()
         ctx.mark_non_differentiable(culling_mask, uv_out)
         return out, culling_mask, uv_out
@@ -363,6 +395,9 @@ class ShardedRasterizer:
         self.all_to_all = all_to_all   # test hook: stands in for dist.all_to_all_single
         n_tile_rows = (image_height + 15) // 16
         self.tile_rows = band_of(n_tile_rows, self.world_size, self.rank)
+        # pixel rows of a (full) band, and of an image buffer that holds world_size of them
+        self.band_pixel_rows = 16 * band_rows_per_rank(n_tile_rows, self.world_size)
+        self.padded_height = self.band_pixel_rows * self.world_size
         self.last_plan = None
         self.last_owned_render_grads = None
 
@@ -370,9 +405,9 @@ class ShardedRasterizer:
         return owner_range(N, self.world_size, self.rank)
 
     def gather_image_(self, image):
-        """in place: band images (zero outside the band) -> the full frame on every rank"""
+        """in place on a [padded_height, W, 3] buffer that holds this rank's band: -> all bands"""
         if self.all_to_all is None:
-            dist.all_reduce(image, op=dist.ReduceOp.SUM, group=self.group)
+            gather_bands(image, self.band_pixel_rows * image.shape[1] * 3, self.world_size, self.rank, self.group)
         return image
 
     def _grad_sync(self, *tensors):
@@ -408,5 +443,5 @@ class ShardedRasterizer:
             gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_mask_padding, mh_dist,
             use_sh_precompute, background_rgb, tile_rows=self.tile_rows, grad_sync=self._grad_sync,
             **({"slab_sync": self._slab_sync} if use_fused else {}))
-        image = _GatherImage.apply(image, self.group)
+        image = _GatherImage.apply(image, self)
         return image, culling_mask, uv

@@ -7,7 +7,8 @@ import torch
 
 from gaussian_splatting_amd import fused
 from gaussian_splatting_amd.sharded import (HaloPlan, ShardedRasterizer, _band_rows, enqueue_hip_plan,
-                                            finish_hip_plan, owned_slice, owner_blocks, owner_range)
+                                            finish_hip_plan, owned_slice, owner_blocks, owner_range,
+                                            plan_record_ints)
 from gaussian_splatting_amd.synthetic import make_grad_image, make_scene
 
 from .helpers import scaled_err
@@ -37,7 +38,8 @@ def test_halo_plan_matches_reference_and_oracle(G):
     rows = _band_rows(nty, G)
     for me in sorted({0, G // 2, G - 1}):
         f = fused.preprocess_forward(g.xyz, g.quaternion, g.scale, g.opacity, g.rgb, None, T, cam.K, W, H, *ARGS,
-                                     (rows[me], rows[me + 1]), 0, plan=lambda fr: enqueue_hip_plan(fr, G, me))
+                                     (rows[me], rows[me + 1]), 0, plan=lambda fr: enqueue_hip_plan(fr, G, me),
+                                     plan_ints=plan_record_ints(G))
         plan = finish_hip_plan(f, G, me)
         V = f.V
         assert 0 < V < N and f.host[0] == sum(plan.send_splits) and f.host[1] == V

@@ -24,7 +24,8 @@ def test_band_split_covers_all_rows():
             for a, b in zip(bands, bands[1:]):
                 assert a[1] == b[0]
             sizes = [b[1] - b[0] for b in bands]
-            assert max(sizes) - min(sizes) <= 1
+            full = -(-nty // world)   # every band is full-sized until the rows run out
+            assert all(x == min(full, max(0, nty - r * full)) for r, x in enumerate(sizes))
 
 
 def _free_port():
