@@ -54,6 +54,6 @@ for _ in range(a.steps):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime")
+st.sort_stats(os.environ.get("SORT", "tottime"))
 print(f"per step: {st.total_tt / a.steps * 1e3:.3f} ms host")
 st.print_stats(28)
