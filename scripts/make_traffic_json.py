@@ -18,7 +18,7 @@ ENTRY = {
     "gs_render_tiles_backward_slab": ["gs::k_render_bwd<float, 1>"],
     "gs_render_tiles_prefix": ["gs::k_render_fwd<float, 1>", "gs::k_render_fwd_flagged", "gs::k_tile_sort_flagged<8192>",
                                "gs::k_tile_sort_flagged<4096>"],
-    "gs_preprocess_forward": ["gs::k_preprocess<16>", "gs::k_cull_count", "gs::k_scan_counts", "gs::k_camera_center"],
+    "gs_preprocess_forward": ["gs::k_preprocess<16, false>", "gs::k_cull_count", "gs::k_scan_counts", "gs::k_camera_center"],
     "gs_preprocess_backward": ["gs::k_preprocess_bwd<16>"],
     "gs_tile_count": ["gs::k_bin_count", "gs::k_bin_colscan", "gs::k_scan_tiles"],
     "gs_tile_emit_sort": ["gs::k_bin_emit", "gs::k_tile_sort<true>", "gs::k_tile_sort_big<true>"],
