@@ -69,18 +69,29 @@ def test_halo_plan_matches_reference_and_oracle(G):
             assert torch.equal(fb.ranges, f.ranges) and torch.equal(fb.sorted_g, f.sorted_g)
 
 
-@pytest.mark.parametrize("G,deg,N,W,H", [(2, 3, 20000, 640, 472), (3, 0, 20000, 640, 472), (8, 3, 60000, 800, 608)])
-def test_owner_mode_with_simulated_ranks(G, deg, N, W, H):
+# (3, 1, 3000, 96, 40): more ranks than tile rows -- the last band is empty;  near = 1e4: everything culled
+@pytest.mark.parametrize("G,deg,N,W,H,near", [(2, 3, 20000, 640, 472, 2.0), (3, 0, 20000, 640, 472, 2.0),
+                                               (8, 3, 60000, 800, 608, 2.0), (4, 1, 3000, 96, 40, 2.0),
+                                               (2, 0, 3000, 96, 40, 1e4)])
+def test_owner_mode_with_simulated_ranks(G, deg, N, W, H, near):
     bg = torch.full((3,), 0.5, device=DEV)
     gi = make_grad_image(W, H, seed=2, device=DEV)
-    ref_img, ref_mask, ref_grads = single_gpu_frame(N, W, H, deg, 7, gi, bg)
+    args = (near, max(25.0, 2 * near)) + ARGS[2:]
+    g0, cam0, T0 = make_scene(N, W, H, deg, seed=7, device=DEV)
+    for k in PARAMS:
+        if getattr(g0, k) is not None:
+            getattr(g0, k).requires_grad_(True)
+    ref_img, ref_mask, _ = fused.rasterize(g0, T0, cam0, *args, True, bg)
+    ref_img.backward(gi)
+    ref_img = ref_img.detach()
+    ref_grads = {k: getattr(g0, k).grad for k in PARAMS if getattr(g0, k) is not None}
     sent = {}
 
     def run(rank, a2a):
         g, cam, T = make_scene(N, W, H, deg, seed=7, device=DEV)
         owned = owned_slice(g, G, rank)
         rast = ShardedRasterizer(H, G, rank, grad_mode="owner", all_to_all=a2a)
-        img, mask, uv = rast.rasterize(g, T, cam, *ARGS, True, bg, owned=owned)
+        img, mask, uv = rast.rasterize(g, T, cam, *args, True, bg, owned=owned)
         img.backward(gi)
         return img.detach(), mask, owned, rast
 
@@ -112,12 +123,13 @@ def test_owner_mode_with_simulated_ranks(G, deg, N, W, H):
         for k, ref in ref_grads.items():
             got = getattr(owned, k).grad
             assert got.shape == ref[i0:i1].shape
-            err = (got - ref[i0:i1]).abs().max() / ref.abs().max()
-            assert float(err) < 1e-5, (r, k, float(err))
+            if got.numel():
+                err = (got - ref[i0:i1]).abs().max() / ref.abs().max().clamp(min=1e-30)
+                assert float(err) < 1e-5, (r, k, float(err))
         sparse_rows += sum(rast.last_plan.send_splits)
     assert torch.equal(sum(images), ref_img)
     V = int((~ref_mask).sum())
-    if G > 1:
+    if G > 1 and V > 1000 and H > 100:
         assert sparse_rows < 0.75 * G * V, "the exchange should move fewer rows than G dense slabs"
 
 
