@@ -200,7 +200,7 @@ __device__ __forceinline__ void render_tile_fwd(
     const T* __restrict__ view_dir, const int* __restrict__ ranges, const int* __restrict__ sorted,
     const T* __restrict__ bg, int W, int H, int ntx, int* __restrict__ nsp_out,
     T* __restrict__ fw_out, T* __restrict__ image, int sort_prefix, int* __restrict__ tile_flags,
-    bool flagged_only) {
+    bool flagged_only, int64_t cap) {
     constexpr bool fast = sizeof(T) == 4;
     constexpr int CW = ColW<N_SH>::value;
     constexpr int RCHUNK = Chunk<T, N_SH>::value;
@@ -212,6 +212,9 @@ __device__ __forceinline__ void render_tile_fwd(
     const bool valid = px.u < W && px.v < H;
     const int s0 = ranges[tile];
     const int n_tile = ranges[tile + 1] - s0;
+    // lists enqueued with a speculative capacity: a segment beyond it was never written (the caller
+    // repeats the frame's binning and this render with the exact size)
+    if ((int64_t)s0 + n_tile > cap) return;
     // prefix mode (binning.hip "prefix sort"): only the first sort_prefix entries are there
     const bool prefix_only = !flagged_only && prefix_sorted_tile(n_tile, sort_prefix);
     const int n_list = prefix_only ? sort_prefix : n_tile;
@@ -305,11 +308,11 @@ __global__ __launch_bounds__(RB) void k_render_fwd(
     const T* __restrict__ packed, const T* __restrict__ rgb, const T* __restrict__ view_dir,
     const int* __restrict__ ranges, const int* __restrict__ sorted, const T* __restrict__ bg,
     int W, int H, int ntx, int tile0, int nt, int* __restrict__ nsp_out, T* __restrict__ fw_out,
-    T* __restrict__ image, int sort_prefix, int* __restrict__ tile_flags) {
+    T* __restrict__ image, int sort_prefix, int* __restrict__ tile_flags, int64_t cap) {
     const int t_local = tile_of_block(blockIdx.x, nt);
     if (t_local >= nt) return;
     render_tile_fwd<T, N_SH>(tile0 + t_local, packed, rgb, view_dir, ranges, sorted, bg, W, H, ntx,
-                             nsp_out, fw_out, image, sort_prefix, tile_flags, false);
+                             nsp_out, fw_out, image, sort_prefix, tile_flags, false, cap);
 }
 
 // repair pass of the prefix mode: a small grid walks the flags and renders the flagged tiles again,
@@ -318,11 +321,11 @@ __global__ __launch_bounds__(RB) void k_render_fwd_flagged(
     const float* __restrict__ packed, const float* __restrict__ rgb, const int* __restrict__ ranges,
     const int* __restrict__ sorted, const float* __restrict__ bg, int W, int H, int ntx, int tile0,
     int nt, int* __restrict__ nsp_out, float* __restrict__ fw_out, float* __restrict__ image,
-    int* __restrict__ tile_flags) {
+    int* __restrict__ tile_flags, int64_t cap) {
     for (int t = blockIdx.x; t < nt; t += gridDim.x) {
         if (tile_flags[tile0 + t] == 0) continue;
         render_tile_fwd<float, 1>(tile0 + t, packed, rgb, nullptr, ranges, sorted, bg, W, H, ntx,
-                                  nsp_out, fw_out, image, 0, tile_flags, true);
+                                  nsp_out, fw_out, image, 0, tile_flags, true, cap);
         __syncthreads();
     }
 }
@@ -693,7 +696,7 @@ int gs_render_tiles(const void* packed, const void* rgb, const void* view_dir_by
                                             sorted_gaussians, (const T*)background_rgb, W, H, ntx,
                                             tile_row0 * ntx, nt, num_splats_per_pixel,
                                             (T*)final_weight_per_pixel, (T*)image, 0,
-                                            nullptr))));
+                                            nullptr, INT64_MAX))));
     return check_launch("render_tiles");
 }
 
@@ -715,14 +718,14 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
     k_render_fwd<float, 1><<<grid, RB, 0, s>>>(
         (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
         (const float*)background_rgb, W, H, ntx, t0, nt, num_splats_per_pixel,
-        (float*)final_weight_per_pixel, (float*)image, GS_SORT_PREFIX, tile_flags);
+        (float*)final_weight_per_pixel, (float*)image, GS_SORT_PREFIX, tile_flags, S);
     if (S > GS_SORT_PREFIX) {
         // 2. + 3. flagged tiles: full sort, render again (no-ops on a dense scene)
         sort_flagged_tiles(tile_ranges, keys, sorted_gaussians, t0, nt, S, tile_flags, s);
         k_render_fwd_flagged<<<nt < 512 ? nt : 512, RB, 0, s>>>(
             (const float*)packed, (const float*)rgb, tile_ranges, sorted_gaussians,
             (const float*)background_rgb, W, H, ntx, t0, nt, num_splats_per_pixel,
-            (float*)final_weight_per_pixel, (float*)image, tile_flags);
+            (float*)final_weight_per_pixel, (float*)image, tile_flags, S);
     }
     return check_launch("render_tiles_prefix");
 }

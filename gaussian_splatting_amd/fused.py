@@ -45,6 +45,8 @@ def _cf(x):
 # nearest entries of long tile lists and repair, on the device, the tiles that needed more.  Exact;
 # off only for callers that want the complete sorted lists back (return_aux=True).
 SORT_PREFIX = True
+# Enqueue the render on the speculative tile lists before waiting for the frame's host read.
+EARLY_RENDER = True
 
 last_tile_flags = None   # int32[T] of the latest prefix-mode frame: 1 = the tile was repaired (for tests/tools)
 
@@ -160,6 +162,7 @@ def preprocess_forward(xyz, quaternion, scale, opacity, rgb, sh, camera_T_world,
         read_back(False)
         f.capacity = int(f.host_buf[0])
         f.sorted_buf, f.keys_buf = emit_sort(f.capacity)
+    f.deferred = defer
     if not defer:
         preprocess_finish(f)
     return f
@@ -270,15 +273,30 @@ def _as_slab(g_uv, g_conic, g_opa, g_rgb, V, dev):
 class _Preprocess(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, quaternion, scale, opacity, rgb, sh, camera_T_world, K, width, height, near_thresh,
-                far_thresh, cull_mask_padding, mh_dist, tile_rows, sort_prefix=0):
+                far_thresh, cull_mask_padding, mh_dist, tile_rows, sort_prefix=0, background_rgb=None):
         f = preprocess_forward(xyz, quaternion, scale, opacity, rgb, sh, camera_T_world, K, width, height,
-                               near_thresh, far_thresh, cull_mask_padding, mh_dist, tile_rows, sort_prefix)
+                               near_thresh, far_thresh, cull_mask_padding, mh_dist, tile_rows, sort_prefix,
+                               defer=EARLY_RENDER and background_rgb is not None and sort_prefix != 0)
+        if f.deferred:
+            # the render (the _Render node's forward) is enqueued on the speculative tile lists before
+            # the host waits for the frame's counts, so a short frame leaves no bubble on the GPU;
+            # a too small capacity repeats it
+            def render():
+                return render_forward(f.packed, f.rgb_render, f.ranges, f.sorted_buf, f.keys_buf, background_rgb,
+                                      height, width, tile_rows, sort_prefix)
+
+            # (only gs_render_tiles_prefix takes the capacity and skips segments beyond it)
+            pre = render() if (f.speculative and f.capacity > sort_prefix) else None
+            if preprocess_finish(f) or pre is None:
+                pre = render()
+        else:
+            pre = ()
         V = f.V
         ctx.save_for_backward(xyz, quaternion, scale, camera_T_world, K)
         ctx.set_materialize_grads(False)   # no zero tensors for the auxiliary outputs in backward
         ctx.f = SimpleNamespace(N=f.N, V=V, n_sh=f.n_sh, center=f.center, rank=f.rank, opacity_act=f.opacity_act)
         uv_v, conic_v, opa_v, rgb_v = f.uv[:V], f.conic[:V], f.opacity_act[:V], f.rgb_render[:V]
-        aux = (f.packed, f.xyz_cam[:V], f.culling_mask, f.ranges, f.sorted_g, f.vis_idx[:V], f.keys)
+        aux = (f.packed, f.xyz_cam[:V], f.culling_mask, f.ranges, f.sorted_g, f.vis_idx[:V], f.keys) + tuple(pre)
         ctx.mark_non_differentiable(*aux)
         return (uv_v, conic_v, opa_v, rgb_v) + aux
 
@@ -287,15 +305,16 @@ class _Preprocess(torch.autograd.Function):
         xyz, quaternion, scale, camera_T_world, K = ctx.saved_tensors
         slab = _as_slab(g_uv, g_conic, g_opa, g_rgb, ctx.f.V, xyz.device)
         grads = preprocess_backward(xyz, quaternion, scale, camera_T_world, K, ctx.f, slab)
-        return grads + (None,) * 10
+        return grads + (None,) * 11
 
 
 class _Render(torch.autograd.Function):
     @staticmethod
     def forward(ctx, uv, conic, opacity, rgb, packed, ranges, sorted_g, background_rgb, height, width, tile_rows,
-                slab_sync=None, keys=None, sort_prefix=0):
-        image, nsp, fw = render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, width,
-                                        tile_rows, sort_prefix)
+                slab_sync=None, keys=None, sort_prefix=0, rendered=None):
+        # rendered: (image, nsp, fw) when _Preprocess.forward already enqueued this node's kernels
+        image, nsp, fw = rendered if rendered else render_forward(
+            packed, rgb, ranges, sorted_g, keys, background_rgb, height, width, tile_rows, sort_prefix)
         ctx.save_for_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw)
         ctx.set_materialize_grads(False)
         ctx.dims = (height, width, tile_rows, uv.shape[0])
@@ -307,13 +326,13 @@ class _Render(torch.autograd.Function):
         packed, rgb, ranges, sorted_g, background_rgb, nsp, fw = ctx.saved_tensors
         height, width, tile_rows, V = ctx.dims
         if grad_image is None:
-            return (None,) * 14
+            return (None,) * 15
         slab = render_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, grad_image.contiguous(),
                                height, width, tile_rows, V)
         if ctx.slab_sync is not None:
             ctx.slab_sync(slab.view(-1))   # multi-GPU: sum the partial gradients of all bands in place
         # the four gradients are views of the one slab; _Preprocess.backward recognises that
-        return (slab[:, SLAB_UV], slab[:, SLAB_CONIC], slab[:, SLAB_OPACITY], slab[:, SLAB_RGB]) + (None,) * 10
+        return (slab[:, SLAB_UV], slab[:, SLAB_CONIC], slab[:, SLAB_OPACITY], slab[:, SLAB_RGB]) + (None,) * 11
 
 
 def supported(gaussians, camera_T_world, camera, use_sh_precompute):
@@ -340,10 +359,12 @@ def rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_m
     out = _Preprocess.apply(
         g.xyz.contiguous(), g.quaternion.contiguous(), g.scale.contiguous(), g.opacity.contiguous(),
         g.rgb.contiguous(), sh, camera_T_world.contiguous(), camera.K.contiguous(), int(camera.width),
-        int(camera.height), near_thresh, far_thresh, cull_mask_padding, mh_dist, tile_rows, sort_prefix)
-    uv, conic, opacity, rgb, packed, xyz_cam, culling_mask, ranges, sorted_g, vis_idx, keys = out
+        int(camera.height), near_thresh, far_thresh, cull_mask_padding, mh_dist, tile_rows, sort_prefix,
+        background_rgb.contiguous())
+    uv, conic, opacity, rgb, packed, xyz_cam, culling_mask, ranges, sorted_g, vis_idx, keys = out[:11]
     image = _Render.apply(uv, conic, opacity, rgb, packed, ranges, sorted_g, background_rgb.contiguous(),
-                          int(camera.height), int(camera.width), tile_rows, slab_sync, keys, sort_prefix)
+                          int(camera.height), int(camera.width), tile_rows, slab_sync, keys, sort_prefix,
+                          tuple(out[11:]))
     if return_aux:
         return image, culling_mask, uv, dict(conic=conic, opacity=opacity, rgb=rgb, packed=packed,
                                              xyz_camera_frame=xyz_cam, tile_ranges=ranges,

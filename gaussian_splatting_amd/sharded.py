@@ -287,7 +287,7 @@ class _OwnerFrameFused(torch.autograd.Function):
 
         # the render is enqueued on the speculative tile lists before the host looks at the frame's
         # counts, so the GPU does not wait for the host; a too small capacity repeats it (rare)
-        out = render() if (f.speculative and DEFER_HOST_READ) else None
+        out = render() if (f.speculative and DEFER_HOST_READ and sort_prefix and f.capacity > sort_prefix) else None
         if (DEFER_HOST_READ and fused.preprocess_finish(f)) or out is None:
             out = render()
         image, nsp, fw = out

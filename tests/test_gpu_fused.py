@@ -302,6 +302,22 @@ def test_fused_speculative_capacity_overflow_is_repaired():
     for other in (spec, small, large):
         assert torch.equal(other[0], ref[0]) and torch.equal(other[1], ref[1]) and torch.equal(other[2], ref[2])
 
+    # the default mode (prefix sort, render enqueued on the speculative lists before the host read):
+    # a too small capacity must not be read beyond, and the frame is repeated
+    def run_default():
+        g, cam, T = make_scene(20000, 640, 480, 0, seed=3, device=DEV)
+        g.xyz.requires_grad_(True)
+        img, _, _ = fused.rasterize(g, T, cam, 0.3, 500.0, 100, 3.0, True, bg)
+        img.sum().backward()
+        return img.detach(), g.xyz.grad
+
+    for hint in (None, 100, 1500, 10 * ref[1].numel()):
+        if hint is not None:
+            fused._capacity_hint[key] = hint
+        img, grad = run_default()
+        assert torch.equal(img, ref[0]), hint
+        assert torch.isfinite(grad).all()
+
 
 def test_kernels_run_on_the_current_stream():
     """launches go to torch's current HIP stream, with no hidden device sync the
