@@ -66,6 +66,10 @@ def parse():
                     help="multi-GPU only: 'owner' = every rank produces the parameter gradients of the Gaussians "
                     "it owns (sparse all_to_all of the partial render gradients); 'replicated' = identical dense "
                     "gradients on every rank (all-reduce of the whole render-gradient slab)")
+    ap.add_argument("--train-ops", action="store_true",
+                    help="also time the training-loop operations behind the rasterizer (SURVEY.md 8(f4)) on the "
+                    "workload's parameter set: Adam step (HIP vs torch), densification statistics; reported "
+                    "under train_ops, never part of the headline value")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (ShardedRasterizer over RCCL) even with one rank")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -304,6 +308,10 @@ def main():
         for name in [w for w in args.also.split(",") if w]:
             other[name] = _time_workload(name, fused_mod, dev, steps=max(5, args.steps // 2), warmup=3)
 
+    train_ops = None
+    if args.train_ops and rank == 0 and world == 1:
+        train_ops = time_train_ops(args.workload, dev)
+
     cpu = None
     parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -323,6 +331,8 @@ def main():
                        else f"tile-rows x{world}, {args.grad_mode} gradients"},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "other_workloads": other,
         }
+        if train_ops is not None:
+            line["train_ops"] = train_ops
         print(json.dumps(line))
     if world > 1 or args.force_sharded:
         import torch.distributed as dist
@@ -379,6 +389,74 @@ def parity_check(workload, fused_mod, dev, n_rows=2):
             "grad_max_rel_err": worst, "target": 1e-4,
             "sample": f"workload {workload}, tile rows [{rows[0]},{rows[1]}) rendered by GPU and by the CPU oracle "
                       "from the same per-splat inputs and tile lists"}
+
+
+def time_train_ops(workload, dev, steps=20):
+    """Adam step over the reference's six parameter groups (optimizer_manager.py:15-42) and the
+    densification statistics (trainer.py:378-385) at the workload's size.  Algorithmic bytes: 28 B
+    per parameter element for Adam (p, g, m, v read; p, m, v written)."""
+    from gaussian_splatting_amd.synthetic import WORKLOADS, make_scene
+    from gaussian_splatting_amd.train_ops import Adam, accumulate_grad_stats
+    N, W, H, deg = WORKLOADS[workload]
+    names = ("xyz", "quaternion", "scale", "opacity", "rgb", "sh")
+    lrs = (2e-4, 4e-3, 1e-2, 2e-2, 4e-3, 2e-4)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(steps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / steps
+
+    out = {}
+    n_elem = 0
+    for label, cls, kw in (("hip", Adam, {}), ("torch_foreach", torch.optim.Adam, {"foreach": True}),
+                           ("torch_fused", torch.optim.Adam, {"fused": True})):
+        g, cam, _ = make_scene(N, W, H, deg, seed=0, device=dev)
+        params = [getattr(g, k) for k in names if getattr(g, k) is not None]
+        n_elem = sum(p.numel() for p in params)
+        for p in params:
+            p.requires_grad_(True)
+            p.grad = torch.randn_like(p) * 1e-3
+        try:
+            opt = cls([{"params": p, "lr": lr} for p, lr in zip(params, lrs)], **kw)
+            out[f"adam_{label}_ms"] = round(timed(opt.step), 4)
+        except Exception as e:   # a torch build without the fused / foreach kernels
+            out[f"adam_{label}_ms"] = None
+            out[f"adam_{label}_error"] = str(e)[:80]
+        del opt, params, g
+        torch.cuda.empty_cache()
+    bytes_adam = 28 * n_elem
+    out["adam_algorithmic_bytes"] = bytes_adam
+    out["adam_hip_gbs"] = round(bytes_adam / (out["adam_hip_ms"] * 1e-3) / 1e9, 1)
+    out["adam_hip_frac_of_hbm_peak"] = round(out["adam_hip_gbs"] / HBM_PEAK_GBS, 4)
+
+    g, cam, _ = make_scene(N, W, H, deg, seed=0, device=dev)
+    mask = torch.rand(N, device=dev) < 0.04
+    V = int((~mask).sum())
+    uv_grad = torch.randn(V, 9, device=dev)[:, 4:6]
+    xyz_grad = torch.randn(N, 3, device=dev)
+    acc_uv, acc_xyz = torch.zeros(N, 2, device=dev), torch.zeros(N, 3, device=dev)
+    cnt = torch.zeros(N, dtype=torch.int32, device=dev)
+    out["grad_stats_hip_ms"] = round(timed(lambda: accumulate_grad_stats(uv_grad, mask, xyz_grad, cam, acc_uv,
+                                                                           acc_xyz, cnt)), 4)
+
+    def torch_lines():   # trainer.py:378-385
+        ug = uv_grad.detach().clone()
+        ug[:, 0] = ug[:, 0] * cam.K[0, 0]
+        ug[:, 1] = ug[:, 1] * cam.K[1, 1]
+        acc_uv[~mask] += torch.abs(ug)
+        acc_xyz.add_(torch.abs(xyz_grad))
+        cnt.add_((~mask).int())
+
+    out["grad_stats_torch_ms"] = round(timed(torch_lines), 4)
+    out["workload"] = f"{workload}: {N} Gaussians, {n_elem} parameter elements"
+    return out
 
 
 def _time_workload(name, fused_mod, dev, steps, warmup):

@@ -26,6 +26,7 @@ EXPORTS = [
     "gs_preprocess_workspace_ints", "gs_preprocess_forward", "gs_preprocess_backward",
     "gs_pack_splats", "gs_render_tiles", "gs_render_tiles_prefix", "gs_render_tiles_backward", "gs_render_tiles_backward_slab",
     "gs_render_depth", "gs_halo_workspace_ints", "gs_halo_plan", "gs_halo_gather_sum",
+    "gs_adam_step", "gs_accumulate_grad_stats",
 ]
 
 _lib = None

@@ -268,6 +268,26 @@ int gs_halo_gather_sum(const uint32_t* mask, const int32_t* workspace, int N, in
                        int v_lo, int v_hi, const void* recv, const int32_t* recv_offsets,
                        void* out, void* stream);
 
+/* ---- training-loop operations behind the rasterizer ------------------------------
+ * gs_adam_step: torch.optim.Adam.step() as the reference uses it (splat_py/optimizer_manager.py:15-42
+ * builds the optimizer with one group per parameter tensor and a learning rate each; trainer.py:376
+ * steps it): defaults amsgrad=False, weight_decay=0, maximize=False.  One launch updates up to 8
+ * parameter tensors in place.  params/grads/exp_avg/exp_avg_sq: host arrays of n_groups device
+ * pointers (fp32, numel[k] elements each); lr[k], step[k] (the 1-based step count AFTER the
+ * increment, per tensor as in torch's state["step"]); beta1, beta2, eps as the Python floats.
+ * Update order == torch/optim/adam.py _single_tensor_adam on the ATen CPU kernels. */
+int gs_adam_step(int n_groups, void* const* params, const void* const* grads, void* const* exp_avg,
+                 void* const* exp_avg_sq, const int64_t* numel, const double* lr,
+                 const int64_t* step, double beta1, double beta2, double eps, void* stream);
+/* Densification statistics of trainer.py:378-385 in one pass and without the boolean-mask
+ * index_put: for every Gaussian i with rank[i] >= 0 (its visible index; -1 = culled)
+ *   uv_grad_accum[i] += |uv_grad[rank[i]] * (fx, fy)|,  grad_accum_count[i] += 1
+ * and for every i  xyz_grad_accum[i] += |xyz_grad[i]|  (skipped when xyz_grad is NULL).
+ * uv_grad: rows of 2 floats, uv_row_stride floats apart (9 for the view of the fused path's slab). */
+int gs_accumulate_grad_stats(const void* uv_grad, int uv_row_stride, const int32_t* rank,
+                             const void* xyz_grad, float fx, float fy, int N, void* uv_grad_accum,
+                             void* xyz_grad_accum, int32_t* grad_accum_count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,3 +112,17 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert "gs_oracle" not in src, f
+
+
+def test_train_ops_adam_hands_cpu_tensors_to_torch():
+    """gaussian_splatting_amd.train_ops.Adam covers fp32 device tensors with the HIP kernel; anything
+    else goes through torch.optim.Adam.step itself (never the oracle)"""
+    import torch
+    from gaussian_splatting_amd.train_ops import Adam
+    a = torch.arange(6, dtype=torch.float32).view(2, 3).requires_grad_(True)
+    b = a.detach().clone().requires_grad_(True)
+    a.grad = torch.full_like(a, 0.5)
+    b.grad = torch.full_like(b, 0.5)
+    Adam([a], lr=0.01).step()
+    torch.optim.Adam([b], lr=0.01).step()
+    assert torch.equal(a, b)
