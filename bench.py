@@ -455,6 +455,34 @@ def time_train_ops(workload, dev, steps=20):
         cnt.add_((~mask).int())
 
     out["grad_stats_torch_ms"] = round(timed(torch_lines), 4)
+
+    # training loss (trainer.py:363-374), value + gradient: one HIP launch vs the PyTorch formulation
+    # (grouped conv2d of five maps + elementwise ops + autograd) on the same device
+    from gaussian_splatting_amd.train_ops import ssim_l1_loss
+    import torch.nn.functional as F
+    target = torch.rand(H, W, 3, device=dev)
+    image = (target + 0.1 * torch.randn(H, W, 3, device=dev)).clamp(0, 1).requires_grad_(True)
+
+    def hip_loss():
+        image.grad = None
+        ssim_l1_loss(image, target, 0.2).backward()
+
+    g1 = torch.exp(-((torch.arange(11, device=dev, dtype=torch.float32) - 5) / 1.5) ** 2 / 2)
+    g1 = (g1 / g1.sum()).unsqueeze(0)
+    kernel = (g1.t() @ g1).expand(3, 1, 11, 11).contiguous()
+
+    def torch_loss():
+        image.grad = None
+        x, y = image.permute(2, 0, 1)[None], target.permute(2, 0, 1)[None]
+        xp, yp = F.pad(x, (5, 5, 5, 5), mode="reflect"), F.pad(y, (5, 5, 5, 5), mode="reflect")
+        o = F.conv2d(torch.cat((xp, yp, xp * xp, yp * yp, xp * yp)), kernel, groups=3).split(1)
+        mxx, myy, mxy = o[0] * o[0], o[1] * o[1], o[0] * o[1]
+        full = ((2 * mxy + 1e-4) * (2 * (o[4] - mxy) + 9e-4)) / ((mxx + myy + 1e-4) * (o[2] - mxx + o[3] - myy + 9e-4))
+        loss = 0.8 * F.l1_loss(image, target) + 0.2 * (1 - full[..., 5:-5, 5:-5].mean())
+        loss.backward()
+
+    out["ssim_l1_loss_hip_ms"] = round(timed(hip_loss), 4)
+    out["ssim_l1_loss_torch_ms"] = round(timed(torch_loss), 4)
     out["workload"] = f"{workload}: {N} Gaussians, {n_elem} parameter elements"
     return out
 

@@ -26,7 +26,7 @@ EXPORTS = [
     "gs_preprocess_workspace_ints", "gs_preprocess_forward", "gs_preprocess_backward",
     "gs_pack_splats", "gs_render_tiles", "gs_render_tiles_prefix", "gs_render_tiles_backward", "gs_render_tiles_backward_slab",
     "gs_render_depth", "gs_halo_workspace_ints", "gs_halo_plan", "gs_halo_gather_sum",
-    "gs_adam_step", "gs_accumulate_grad_stats",
+    "gs_adam_step", "gs_accumulate_grad_stats", "gs_ssim_l1_workspace_bytes", "gs_ssim_l1_loss",
 ]
 
 _lib = None
@@ -48,6 +48,7 @@ def lib():
         _lib.gs_preprocess_workspace_ints.restype = ctypes.c_size_t
         _lib.gs_tile_workspace_ints.restype = ctypes.c_size_t
         _lib.gs_halo_workspace_ints.restype = ctypes.c_size_t
+        _lib.gs_ssim_l1_workspace_bytes.restype = ctypes.c_size_t
     return _lib
 
 

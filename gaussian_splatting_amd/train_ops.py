@@ -97,3 +97,44 @@ def accumulate_grad_stats(uv_grad, culling_mask, xyz_grad, camera, uv_grad_accum
     _hip.call("gs_accumulate_grad_stats", p(uv_grad), int(uv_grad.stride(0)) if uv_grad.shape[0] else 2, p(rank),
               p(xyz_grad), ctypes.c_float(fx), ctypes.c_float(fy), N, p(uv_grad_accum), p(xyz_grad_accum),
               p(grad_accum_count), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+
+class _SsimL1Loss(torch.autograd.Function):
+    """value and d loss / d image from one launch; backward scales the stored gradient"""
+
+    @staticmethod
+    def forward(ctx, image, target, ssim_frac):
+        H, W = image.shape[0], image.shape[1]
+        dev = image.device
+        ws = torch.empty(_hip.lib().gs_ssim_l1_workspace_bytes(H, W) // 8, dtype=torch.float64, device=dev)
+        out = torch.empty(3, dtype=torch.float32, device=dev)
+        need_grad = image.requires_grad
+        grad = torch.empty_like(image) if need_grad else None
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        _hip.call("gs_ssim_l1_loss", p(image), p(target), H, W, ctypes.c_float(float(ssim_frac)), p(ws), p(out),
+                  p(grad), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        ctx.grad = grad
+        ctx.mark_non_differentiable(out)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, g_loss, _unused):
+        if ctx.grad is None or g_loss is None:
+            return None, None, None
+        return ctx.grad * g_loss, None, None
+
+
+def ssim_l1_loss(image, target, ssim_frac=0.2, return_terms=False):
+    """The reference's training loss (trainer.py:363-374):
+
+        (1 - ssim_frac) * l1_loss(image, target) + ssim_frac * (1 - SSIM(image, target))
+
+    image, target: [H, W, 3] fp32 device tensors (the rasterizer's layout; the reference permutes
+    them to NCHW for torchmetrics).  -> loss (0-d, differentiable w.r.t. image); with
+    return_terms=True also the detached (loss, l1, ssim) triple."""
+    if not (image.is_cuda and image.dtype == torch.float32 and image.dim() == 3 and image.shape[2] == 3):
+        raise RuntimeError("ssim_l1_loss takes [H, W, 3] float32 device tensors")
+    if target.shape != image.shape or target.dtype != image.dtype or target.device != image.device:
+        raise RuntimeError("ssim_l1_loss: target must match image")
+    loss, terms = _SsimL1Loss.apply(image.contiguous(), target.contiguous(), ssim_frac)
+    return (loss, terms) if return_terms else loss

@@ -288,6 +288,17 @@ int gs_accumulate_grad_stats(const void* uv_grad, int uv_row_stride, const int32
                              const void* xyz_grad, float fx, float fy, int N, void* uv_grad_accum,
                              void* xyz_grad_accum, int32_t* grad_accum_count, void* stream);
 
+/* The training loss of trainer.py:363-374, value and gradient in one call:
+ *   loss = (1 - ssim_frac) * l1_loss(image, target) + ssim_frac * (1 - SSIM(image, target))
+ * SSIM = torchmetrics 1.2.1 StructuralSimilarityIndexMeasure(data_range=1.0) (trainer.py:24): 11x11
+ * Gaussian window (sigma 1.5), k1 0.01, k2 0.03, mean over the pixels whose window lies inside the
+ * image.  image, target: [H, W, 3] fp32 (the rasterizer's layout; H, W > 10).
+ * loss_out: float[3] = (loss, l1, ssim).  grad_image: [H, W, 3] = d loss / d image, or NULL.
+ * workspace: gs_ssim_l1_workspace_bytes(H, W) bytes (per-tile partial sums, reduced in a fixed order). */
+size_t gs_ssim_l1_workspace_bytes(int H, int W);
+int gs_ssim_l1_loss(const void* image, const void* target, int H, int W, float ssim_frac,
+                    void* workspace, void* loss_out, void* grad_image, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

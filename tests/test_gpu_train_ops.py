@@ -95,3 +95,44 @@ def test_accumulate_grad_stats_matches_the_trainer_lines():
     accumulate_grad_stats(uv_grad, culling_mask, xyz_grad, cam, uv_acc, xyz_acc, count)
     assert torch.equal(uv_acc, ref_uv) and torch.equal(xyz_acc, ref_xyz) and torch.equal(count, ref_count)
     assert torch.equal(slab, before)
+
+
+@pytest.mark.parametrize("H,W,frac", [(40, 50, 0.2), (97, 131, 0.2), (16, 11 + 16, 0.5), (840, 1297, 0.2)])
+def test_ssim_l1_loss_matches_the_oracle(H, W, frac):
+    """value and gradient against the plain-PyTorch restatement of trainer.py:363-374 +
+    torchmetrics 1.2.1 SSIM (oracle/loss_oracle.py, CPU, autograd).  Tolerances (fp32, different
+    summation order of the 121-tap windows): loss 1e-5 relative, gradient 1e-4 of its maximum."""
+    from gaussian_splatting_amd.train_ops import ssim_l1_loss
+    from oracle import loss_oracle
+    gen = torch.Generator().manual_seed(H * 1000 + W)
+    target = torch.rand(H, W, 3, generator=gen)
+    image = (target + 0.15 * torch.randn(H, W, 3, generator=gen)).clamp(0, 1)
+    image[: H // 4] = target[: H // 4]          # an exactly matching region: sign(0) = 0, SSIM = 1
+    ref_img = image.clone().requires_grad_(True)
+    ref_loss, ref_l1, ref_ssim = loss_oracle.ssim_l1_loss(ref_img, target, frac)
+    ref_loss.backward()
+    img = image.to(DEV).requires_grad_(True)
+    loss, terms = ssim_l1_loss(img, target.to(DEV), frac, return_terms=True)
+    (2.0 * loss).backward()                      # a non-unit upstream gradient
+    terms = terms.cpu()
+    assert abs(float(loss) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
+    assert abs(float(terms[1]) - float(ref_l1)) <= 1e-5 * abs(float(ref_l1))
+    assert abs(float(terms[2]) - float(ref_ssim)) <= 1e-5
+    err = (img.grad.cpu() / 2.0 - ref_img.grad).abs().max() / ref_img.grad.abs().max()
+    assert float(err) < 1e-4, float(err)
+
+
+def test_ssim_l1_loss_properties():
+    from gaussian_splatting_amd.train_ops import ssim_l1_loss
+    gen = torch.Generator().manual_seed(1)
+    x = torch.rand(64, 80, 3, generator=gen).to(DEV)
+    y = torch.rand(64, 80, 3, generator=gen).to(DEV)
+    _, t_same = ssim_l1_loss(x, x.clone(), 0.2, return_terms=True)
+    assert float(t_same[0]) == 0.0 and float(t_same[1]) == 0.0 and abs(float(t_same[2]) - 1.0) < 1e-6
+    _, t_xy = ssim_l1_loss(x, y, 0.2, return_terms=True)
+    _, t_yx = ssim_l1_loss(y, x, 0.2, return_terms=True)
+    assert torch.equal(t_xy, t_yx)                                   # symmetric, and bit-reproducible
+    _, t_again = ssim_l1_loss(x, y, 0.2, return_terms=True)
+    assert torch.equal(t_xy, t_again)
+    with pytest.raises(RuntimeError):
+        ssim_l1_loss(x[:8], y[:8], 0.2)                              # smaller than the 11x11 window
