@@ -136,3 +136,36 @@ def test_ssim_l1_loss_properties():
     assert torch.equal(t_xy, t_again)
     with pytest.raises(RuntimeError):
         ssim_l1_loss(x[:8], y[:8], 0.2)                              # smaller than the 11x11 window
+
+
+def test_training_iterations_reduce_the_loss():
+    """the pieces of trainer.py:348-385 together: rasterize -> SSIM/L1 loss -> backward -> Adam ->
+    densification statistics, on a small scene fitted to a render of its unperturbed self"""
+    from gaussian_splatting_amd import fused
+    from gaussian_splatting_amd.train_ops import ssim_l1_loss
+    N, W, H = 4000, 192, 128
+    args = dict(near_thresh=0.3, far_thresh=500.0, cull_mask_padding=100, mh_dist=3.0, use_sh_precompute=True,
+                background_rgb=torch.zeros(3, device=DEV))
+    g, cam, T = make_scene(N, W, H, 1, seed=11, device=DEV)
+    with torch.no_grad():
+        target, _, _ = fused.rasterize(g, T, cam, **args)
+        gen = torch.Generator().manual_seed(3)
+        g.rgb.add_(0.5 * torch.randn(g.rgb.shape, generator=gen).to(DEV))
+        g.xyz.add_(0.02 * torch.randn(g.xyz.shape, generator=gen).to(DEV))
+    for k in NAMES:
+        getattr(g, k).requires_grad_(True)
+    opt = build(Adam, g)
+    uv_acc, xyz_acc = torch.zeros(N, 2, device=DEV), torch.zeros(N, 3, device=DEV)
+    count = torch.zeros(N, dtype=torch.int32, device=DEV)
+    losses = []
+    for it in range(40):
+        opt.zero_grad(set_to_none=True)
+        img, culled, uv = fused.rasterize(g, T, cam, **args)
+        uv.retain_grad()
+        loss = ssim_l1_loss(img, target, 0.2)
+        loss.backward()
+        opt.step()
+        accumulate_grad_stats(uv.grad, culled, g.xyz.grad, cam, uv_acc, xyz_acc, count)
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.6 * losses[0], (losses[0], losses[-1])
+    assert int(count.max()) == 40 and float(uv_acc.sum()) > 0 and torch.isfinite(xyz_acc).all()
