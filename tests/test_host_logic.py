@@ -126,3 +126,29 @@ def test_train_ops_adam_hands_cpu_tensors_to_torch():
     Adam([a], lr=0.01).step()
     torch.optim.Adam([b], lr=0.01).step()
     assert torch.equal(a, b)
+
+
+def test_quaternion_to_rotation_and_scale_init():
+    """test/test_utils.py:15-25 (rotation matrices are orthonormal) + the two identities, and the
+    batched KD-tree initial scale against the reference's per-point formula"""
+    import math
+    import numpy as np
+    import torch
+    from scipy.spatial import KDTree
+    from gaussian_splatting_amd.splat_py.utils import (compute_initial_scale_from_sparse_points, inverse_sigmoid,
+                                                       inverse_sigmoid_torch, quaternion_to_rotation_torch)
+    q = torch.tensor([1.0, 0.0, 0.0, 0.0, 0.0, math.sqrt(2) / 2, 0.0, math.sqrt(2) / 2]).reshape(-1, 4)
+    R = quaternion_to_rotation_torch(q)
+    assert R.shape == (2, 3, 3)
+    assert torch.allclose(torch.bmm(R, R.transpose(1, 2)), torch.eye(3).repeat(2, 1, 1), atol=1e-6)
+    assert torch.allclose(R[0], torch.eye(3))
+    assert torch.allclose(R[1], torch.tensor([[0.0, 0.0, 1.0], [0.0, -1.0, 0.0], [1.0, 0.0, 0.0]]), atol=1e-6)
+    x = np.array([0.0, 0.3, 1.0])
+    assert np.allclose(inverse_sigmoid(x), inverse_sigmoid_torch(torch.from_numpy(x)).numpy())
+    pts = torch.rand(50, 3, generator=torch.Generator().manual_seed(0))
+    got = compute_initial_scale_from_sparse_points(pts, 4, 0.5, 0.1)
+    tree = KDTree(pts.numpy())
+    for i in (0, 7, 49):
+        d, _ = tree.query(pts[i].numpy(), k=4)
+        assert np.allclose(got[i].numpy(), np.log(min(np.mean(d), 0.1) * 0.5), atol=1e-6)
+    assert got.shape == (50, 3) and got.dtype == torch.float32
