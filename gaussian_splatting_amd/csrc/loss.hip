@@ -40,7 +40,7 @@ __global__ __launch_bounds__(LT * LT) void k_ssim_l1(const float* __restrict__ i
     __shared__ float s_y[3][LR][LR + 1];
     __shared__ float s_d[3][3][LD][LD + 1];   // [D_mu | D_xx | D_xy][channel]
     __shared__ float s_h[5][LR][LD];          // row-pass sums of one channel (x, y, xx, yy, xy)
-    __shared__ double s_red[2][LT * LT / GS_WAVE];
+    __shared__ double s_red[3][LT * LT / GS_WAVE];
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
 
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(LT * LT) void k_ssim_l1(const float* __restrict__ i
 
     const int ty = tid / LT, tx = tid - ty * LT;
     const int py = y0 + ty, px = x0 + tx;
-    double l1_sum = 0.0;
+    double l1_sum = 0.0, sq_sum = 0.0;
     float (*s_t)[LD][LT] = reinterpret_cast<float (*)[LD][LT]>(&s_h[0][0][0]);   // [3][26][16] row-pass sums
 #pragma unroll 1
     for (int c = 0; c < 3; c++) {
@@ -151,6 +151,7 @@ __global__ __launch_bounds__(LT * LT) void k_ssim_l1(const float* __restrict__ i
             const float x = s_x[c][ty + 2 * LH][tx + 2 * LH], y = s_y[c][ty + 2 * LH][tx + 2 * LH];
             const float diff = x - y;
             l1_sum += (double)__builtin_fabsf(diff);
+            sq_sum += (double)(diff * diff);
             if (grad != nullptr) {
                 const float sgn = diff > 0 ? 1.0f : (diff < 0 ? -1.0f : 0.0f);
                 grad[((size_t)py * W + px) * 3 + c] =
@@ -164,36 +165,40 @@ __global__ __launch_bounds__(LT * LT) void k_ssim_l1(const float* __restrict__ i
     for (int d = 1; d < 64; d <<= 1) {
         ssim_sum += __shfl_xor(ssim_sum, d);
         l1_sum += __shfl_xor(l1_sum, d);
+        sq_sum += __shfl_xor(sq_sum, d);
     }
     if ((tid & 63) == 0) {
         s_red[0][tid >> 6] = ssim_sum;
         s_red[1][tid >> 6] = l1_sum;
+        s_red[2][tid >> 6] = sq_sum;
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < 3) {
         const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-        partial[2 * b + 0] = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
-        partial[2 * b + 1] = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+        partial[3 * b + tid] = s_red[tid][0] + s_red[tid][1] + s_red[tid][2] + s_red[tid][3];
     }
 }
 
-// fixed-order reduction of the per-tile sums -> out = (loss, l1, ssim)
+// fixed-order reduction of the per-tile sums -> out = (loss, l1, ssim, mse)
 __global__ __launch_bounds__(256) void k_loss_finish(const double* __restrict__ partial, int n,
                                                      double inv_l1, double inv_ssim, float ssim_frac,
                                                      float* __restrict__ out) {
-    __shared__ double s[2][256];
-    double a = 0, b = 0;
+    __shared__ double s[3][256];
+    double a = 0, b = 0, c = 0;
     for (int i = threadIdx.x; i < n; i += 256) {
-        a += partial[2 * i];
-        b += partial[2 * i + 1];
+        a += partial[3 * i];
+        b += partial[3 * i + 1];
+        c += partial[3 * i + 2];
     }
     s[0][threadIdx.x] = a;
     s[1][threadIdx.x] = b;
+    s[2][threadIdx.x] = c;
     __syncthreads();
     for (int d = 128; d > 0; d >>= 1) {
         if (threadIdx.x < d) {
             s[0][threadIdx.x] += s[0][threadIdx.x + d];
             s[1][threadIdx.x] += s[1][threadIdx.x + d];
+            s[2][threadIdx.x] += s[2][threadIdx.x + d];
         }
         __syncthreads();
     }
@@ -202,6 +207,7 @@ __global__ __launch_bounds__(256) void k_loss_finish(const double* __restrict__ 
         out[0] = (1.0f - ssim_frac) * l1 + ssim_frac * (1.0f - ssim);
         out[1] = l1;
         out[2] = ssim;
+        out[3] = (float)(s[2][0] * inv_l1);   // mse_loss (trainer.py:366-367: psnr = -10 log10 of it)
     }
 }
 
@@ -212,7 +218,7 @@ using namespace gs;
 extern "C" {
 
 size_t gs_ssim_l1_workspace_bytes(int H, int W) {
-    return (size_t)div_up(W > 0 ? W : 1, LT) * div_up(H > 0 ? H : 1, LT) * 2 * sizeof(double);
+    return (size_t)div_up(W > 0 ? W : 1, LT) * div_up(H > 0 ? H : 1, LT) * 3 * sizeof(double);
 }
 
 int gs_ssim_l1_loss(const void* image, const void* target, int H, int W, float ssim_frac,

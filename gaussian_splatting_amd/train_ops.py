@@ -107,7 +107,7 @@ class _SsimL1Loss(torch.autograd.Function):
         H, W = image.shape[0], image.shape[1]
         dev = image.device
         ws = torch.empty(_hip.lib().gs_ssim_l1_workspace_bytes(H, W) // 8, dtype=torch.float64, device=dev)
-        out = torch.empty(3, dtype=torch.float32, device=dev)
+        out = torch.empty(4, dtype=torch.float32, device=dev)
         need_grad = image.requires_grad
         grad = torch.empty_like(image) if need_grad else None
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
@@ -131,7 +131,8 @@ def ssim_l1_loss(image, target, ssim_frac=0.2, return_terms=False):
 
     image, target: [H, W, 3] fp32 device tensors (the rasterizer's layout; the reference permutes
     them to NCHW for torchmetrics).  -> loss (0-d, differentiable w.r.t. image); with
-    return_terms=True also the detached (loss, l1, ssim) triple."""
+    return_terms=True also the detached (loss, l1, ssim, mse) tensor (psnr = -10 log10(mse),
+    trainer.py:366-367)."""
     if not (image.is_cuda and image.dtype == torch.float32 and image.dim() == 3 and image.shape[2] == 3):
         raise RuntimeError("ssim_l1_loss takes [H, W, 3] float32 device tensors")
     if target.shape != image.shape or target.dtype != image.dtype or target.device != image.device:

@@ -293,7 +293,8 @@ int gs_accumulate_grad_stats(const void* uv_grad, int uv_row_stride, const int32
  * SSIM = torchmetrics 1.2.1 StructuralSimilarityIndexMeasure(data_range=1.0) (trainer.py:24): 11x11
  * Gaussian window (sigma 1.5), k1 0.01, k2 0.03, mean over the pixels whose window lies inside the
  * image.  image, target: [H, W, 3] fp32 (the rasterizer's layout; H, W > 10).
- * loss_out: float[3] = (loss, l1, ssim).  grad_image: [H, W, 3] = d loss / d image, or NULL.
+ * loss_out: float[4] = (loss, l1, ssim, mse) -- mse is the trainer's debug l2_loss (trainer.py:366-367,
+ * psnr = -10 log10(mse)).  grad_image: [H, W, 3] = d loss / d image, or NULL.
  * workspace: gs_ssim_l1_workspace_bytes(H, W) bytes (per-tile partial sums, reduced in a fixed order). */
 size_t gs_ssim_l1_workspace_bytes(int H, int W);
 int gs_ssim_l1_loss(const void* image, const void* target, int H, int W, float ssim_frac,

@@ -118,6 +118,8 @@ def test_ssim_l1_loss_matches_the_oracle(H, W, frac):
     assert abs(float(loss.detach()) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
     assert abs(float(terms[1]) - float(ref_l1)) <= 1e-5 * abs(float(ref_l1))
     assert abs(float(terms[2]) - float(ref_ssim)) <= 1e-5
+    ref_mse = float(torch.nn.functional.mse_loss(image, target))
+    assert abs(float(terms[3]) - ref_mse) <= 1e-5 * ref_mse
     err = (img.grad.cpu() / 2.0 - ref_img.grad).abs().max() / ref_img.grad.abs().max()
     assert float(err) < 1e-4, float(err)
 
