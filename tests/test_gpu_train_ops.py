@@ -115,6 +115,7 @@ def test_ssim_l1_loss_matches_the_oracle(H, W, frac):
     loss, terms = ssim_l1_loss(img, target.to(DEV), frac, return_terms=True)
     (2.0 * loss).backward()                      # a non-unit upstream gradient
     terms = terms.cpu()
+    ref_loss, ref_l1, ref_ssim = ref_loss.detach(), ref_l1.detach(), ref_ssim.detach()
     assert abs(float(loss.detach()) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
     assert abs(float(terms[1]) - float(ref_l1)) <= 1e-5 * abs(float(ref_l1))
     assert abs(float(terms[2]) - float(ref_ssim)) <= 1e-5
