@@ -14,9 +14,14 @@
 //   4. k_bin_emit      same slices, same test; LDS cursors start at ranges[t] + hist[b][t];
 //                      scatters key = (sortable z bits << 32 | gaussian) into the tile's segment
 //                      (a counting sort on the tile digit)
-//   5. k_tile_sort_*   one workgroup per tile sorts its segment in LDS (register-blocked bitonic
-//                      network on unique 64-bit keys -> deterministic) and writes the Gaussian
-//                      indices; see "per-tile sort" below.
+//   5. k_tile_sort*    one workgroup per tile orders its segment on unique 64-bit keys
+//                      (deterministic) and writes the Gaussian indices: wave-level sorts up to
+//                      1024 entries, and above that either the register-blocked bitonic network
+//                      in LDS (full mode, what get_sorted_gaussian_list returns) or a radix select
+//                      + sort of the 1024 nearest entries (prefix mode of the fused renderer, with
+//                      a flag-and-repair pass that keeps it exact); see "per-tile sort",
+//                      "wave-level sorts" and "prefix sort" below.
+// The Gaussians walked can be restricted to an index list (multi-GPU band mode, struct Items).
 // Tile grids too large for an LDS histogram (T > 16384) fall back to global-atomic counters
 // (k_tile_count / k_tile_emit).
 // HBM traffic: 20 B in per Gaussian per pass, 8 B out + 8 B in + 4 B out per instance,

@@ -16,11 +16,15 @@
 // Forward leaves the chunk loop as soon as every pixel of the tile is saturated
 // (result-preserving: a saturated pixel ignores all later splats, render.cu:106).
 //
+// Prefix mode (binning.hip "prefix sort"): a long tile list may have only its 1024 nearest entries
+// ordered; the forward reads no further, raises tile_flags[t] if a pixel is still unsaturated there,
+// and k_render_fwd_flagged renders such tiles again after their full sort -- results are exact.
+//
 // Backward starts at the tile's largest num_splats_per_pixel instead of the end of the list,
 // skips the reduction for waves none of whose lanes the splat reaches, reduces the 6+3*N_SH
-// per-splat gradient sums over the wave with DPP adds, combines the four waves in LDS and issues
-// ONE global atomic per value per (splat, tile) -- the reference issues eight (one per warp),
-// unconditionally.
+// per-splat gradient sums over 16-lane rows with DPP adds, combines rows and waves with LDS float
+// atomics and issues ONE global atomic per value per (splat, tile) -- the reference issues eight
+// (one per warp), unconditionally.  The fused path accumulates into one [V, 9] row per Gaussian.
 //
 // Numerics.  The fp32 forward is bit-identical to the CPU restatement: same operation order and
 // operand precisions as render.cu (including its double-literal promotions), IEEE division,

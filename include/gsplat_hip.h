@@ -1,9 +1,12 @@
 /* gsplat_hip.h -- C ABI of libgsplat_hip.so: the MI355X (gfx950) rasterization hot path.
  *
- * This is the drop-in boundary.  Every entry point replaces one function of the reference's
- * `splat_cuda` extension (joeyan/gaussian_splatting src/bindings.cpp:118-159) and takes plain
- * device pointers + sizes + a hipStream_t (as void*); no torch types, no exceptions, no hidden
- * allocation, no device synchronisation.  Work is enqueued on `stream` and the call returns.
+ * This is the drop-in boundary.  The first group of entry points replaces, one for one, the
+ * functions of the reference's `splat_cuda` extension (joeyan/gaussian_splatting
+ * src/bindings.cpp:118-159); the fused per-Gaussian stage, the prefix-mode renderer, the multi-GPU
+ * bookkeeping and the training-loop operations further down replace the reference's Python glue
+ * around them (cited per function).  All take plain device pointers + sizes + a hipStream_t (as
+ * void*); no torch types, no exceptions, no hidden allocation, no device synchronisation.  Work
+ * is enqueued on `stream` and the call returns.
  *
  * Conventions
  *   dtype      GS_F32 (0) or GS_F64 (1); all floating tensors of one call share it.
