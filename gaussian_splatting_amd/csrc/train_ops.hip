@@ -116,14 +116,16 @@ __global__ __launch_bounds__(256) void k_adam(AdamGroups G, float w1, float beta
 //   grad_accum_count[i] += visible
 __global__ __launch_bounds__(256) void k_grad_stats(const float* __restrict__ uv_grad,
                                                     int uv_row_stride, const int* __restrict__ rank,
-                                                    const float* __restrict__ xyz_grad, float fx,
-                                                    float fy, int N, float* __restrict__ uv_accum,
+                                                    const float* __restrict__ xyz_grad,
+                                                    const float* __restrict__ K, int N,
+                                                    float* __restrict__ uv_accum,
                                                     float* __restrict__ xyz_accum,
                                                     int* __restrict__ count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const int v = rank[i];
     if (v >= 0) {
+        const float fx = K[0], fy = K[4];   // camera.K[0, 0], camera.K[1, 1], read on the device
         const float* gr = uv_grad + (size_t)v * uv_row_stride;
         uv_accum[i * 2 + 0] += __builtin_fabsf(gr[0] * fx);
         uv_accum[i * 2 + 1] += __builtin_fabsf(gr[1] * fy);
@@ -184,12 +186,12 @@ int gs_adam_step(int n_groups, void* const* params, const void* const* grads, vo
 }
 
 int gs_accumulate_grad_stats(const void* uv_grad, int uv_row_stride, const int32_t* rank,
-                             const void* xyz_grad, float fx, float fy, int N, void* uv_grad_accum,
+                             const void* xyz_grad, const void* K, int N, void* uv_grad_accum,
                              void* xyz_grad_accum, int32_t* grad_accum_count, void* stream) {
     GS_REQUIRE(uv_row_stride >= 2, "accumulate_grad_stats: uv_row_stride must be >= 2");
     if (N <= 0) return GS_OK;
     k_grad_stats<<<div_up(N, 256), 256, 0, (hipStream_t)stream>>>(
-        (const float*)uv_grad, uv_row_stride, rank, (const float*)xyz_grad, fx, fy, N,
+        (const float*)uv_grad, uv_row_stride, rank, (const float*)xyz_grad, (const float*)K, N,
         (float*)uv_grad_accum, (float*)xyz_grad_accum, grad_accum_count);
     return check_launch("accumulate_grad_stats");
 }

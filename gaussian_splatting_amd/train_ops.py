@@ -85,17 +85,18 @@ def accumulate_grad_stats(uv_grad, culling_mask, xyz_grad, camera, uv_grad_accum
         grad_accum_count += (~culling_mask).int()
 
     uv_grad: [V, 2] (any row stride, e.g. the view of the fused path's slab); it is NOT modified.
-    The focal lengths are read on the host once per call (they are camera constants)."""
+    The focal lengths are read from camera.K on the device (no host sync)."""
     N = culling_mask.shape[0]
     keep = ~culling_mask
     rank = torch.where(keep, torch.cumsum(keep, 0, dtype=torch.int32) - 1,
                        torch.full((), -1, dtype=torch.int32, device=keep.device)).to(torch.int32)
     if uv_grad.stride(1) != 1:
         uv_grad = uv_grad.contiguous()
-    fx, fy = float(camera.K[0, 0]), float(camera.K[1, 1])
+    K = camera.K if (camera.K.dtype == torch.float32 and camera.K.is_contiguous()) else \
+        camera.K.to(torch.float32).contiguous()
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     _hip.call("gs_accumulate_grad_stats", p(uv_grad), int(uv_grad.stride(0)) if uv_grad.shape[0] else 2, p(rank),
-              p(xyz_grad), ctypes.c_float(fx), ctypes.c_float(fy), N, p(uv_grad_accum), p(xyz_grad_accum),
+              p(xyz_grad), p(K), N, p(uv_grad_accum), p(xyz_grad_accum),
               p(grad_accum_count), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
 
 

@@ -284,11 +284,12 @@ int gs_adam_step(int n_groups, void* const* params, const void* const* grads, vo
                  const int64_t* step, double beta1, double beta2, double eps, void* stream);
 /* Densification statistics of trainer.py:378-385 in one pass and without the boolean-mask
  * index_put: for every Gaussian i with rank[i] >= 0 (its visible index; -1 = culled)
- *   uv_grad_accum[i] += |uv_grad[rank[i]] * (fx, fy)|,  grad_accum_count[i] += 1
+ *   uv_grad_accum[i] += |uv_grad[rank[i]] * (K[0,0], K[1,1])|,  grad_accum_count[i] += 1
+ * (K: the device-resident fp32 3x3 intrinsics, read on the device: no host sync)
  * and for every i  xyz_grad_accum[i] += |xyz_grad[i]|  (skipped when xyz_grad is NULL).
  * uv_grad: rows of 2 floats, uv_row_stride floats apart (9 for the view of the fused path's slab). */
 int gs_accumulate_grad_stats(const void* uv_grad, int uv_row_stride, const int32_t* rank,
-                             const void* xyz_grad, float fx, float fy, int N, void* uv_grad_accum,
+                             const void* xyz_grad, const void* K, int N, void* uv_grad_accum,
                              void* xyz_grad_accum, int32_t* grad_accum_count, void* stream);
 
 /* The training loss of trainer.py:363-374, value and gradient in one call:
