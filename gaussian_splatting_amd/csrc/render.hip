@@ -549,11 +549,48 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
                 }
                 continue;
             }
+            if constexpr (fast && NV == 9 && GS_BWD_GROUP == 16) {
+                // Transposing reduction over each 16-lane row: instead of summing all 9 values in
+                // every lane (36 DPP adds), lanes trade halves -- after the xor-1 step a lane keeps
+                // 4 of the first 8 values, after the xor-2 step 2 -- and the remaining 3 sums per
+                // lane cross the four quads with two row shifts: 26 VALU ops, and the row's sums
+                // end up spread over lanes 12..15, which issue 3 LDS atomics instead of 9.
+                const bool b0 = lane & 1, b1 = lane & 2;
+                float r[4], s2[2];
 #pragma unroll
-            for (int j = 0; j < NV; j++) val[j] = row_sum(val[j]);
-            if (row_leader<T>(lane)) {
+                for (int j = 0; j < 4; j++) {
+                    const float send = b0 ? val[j] : val[j + 4];
+                    const float keep = b0 ? val[j + 4] : val[j];
+                    r[j] = keep + GS_DPP(send, 0xB1, 0xf, true);     // quad_perm [1,0,3,2]
+                }
+                float s8 = val[8] + GS_DPP(val[8], 0xB1, 0xf, true);
 #pragma unroll
-                for (int j = 0; j < NV; j++) lds_add(&s_acc[i * NV + j], val[j]);
+                for (int j = 0; j < 2; j++) {
+                    const float send = b1 ? r[j] : r[j + 2];
+                    const float keep = b1 ? r[j + 2] : r[j];
+                    s2[j] = keep + GS_DPP(send, 0x4E, 0xf, true);    // quad_perm [2,3,0,1]
+                }
+                s8 += GS_DPP(s8, 0x4E, 0xf, true);
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    s2[j] += GS_DPP(s2[j], 0x114, 0xf, true);        // row_shr:4
+                    s2[j] += GS_DPP(s2[j], 0x118, 0xf, true);        // row_shr:8 -> lanes 12..15
+                }
+                s8 += GS_DPP(s8, 0x114, 0xf, true);
+                s8 += GS_DPP(s8, 0x118, 0xf, true);
+                if ((lane & 12) == 12) {
+                    float* dst = &s_acc[i * NV + (b0 ? 4 : 0) + (b1 ? 2 : 0)];
+                    lds_add(dst, s2[0]);
+                    lds_add(dst + 1, s2[1]);
+                    if ((lane & 3) == 3) lds_add(&s_acc[i * NV + 8], s8);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NV; j++) val[j] = row_sum(val[j]);
+                if (row_leader<T>(lane)) {
+#pragma unroll
+                    for (int j = 0; j < NV; j++) lds_add(&s_acc[i * NV + j], val[j]);
+                }
             }
           }
         }
