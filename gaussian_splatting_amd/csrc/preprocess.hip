@@ -150,27 +150,20 @@ struct Band {
 // rank's rows; the others cannot appear in any of the rank's tile lists.  SH rows are then read
 // directly (no LDS staging: most rows are skipped).
 template <int N_SH, bool BAND>
-__global__ __launch_bounds__(PP_BLOCK) void k_preprocess(
+__global__ __launch_bounds__(PP_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_preprocess(
     const float* __restrict__ xyz, const float* __restrict__ quat, const float* __restrict__ scale,
     const float* __restrict__ opacity, const float* __restrict__ rgb, const float* __restrict__ sh,
     const float* __restrict__ M, const float* __restrict__ K, const float* __restrict__ center,
     int N, Frustum fr, const int* __restrict__ block_offsets, PreOut o, Band band) {
     __shared__ int s_cnt[PP_BLOCK / GS_WAVE];
-    // The workgroup's SH coefficients are one contiguous block of 256 * 3 * (N_SH-1) floats: fetch it
+    // The workgroup's SH coefficients are one contiguous block of 256 * 3 * (N_SH-1) floats: fetched
     // with coalesced 16-byte loads into LDS (a per-thread walk over its own 180-byte row makes every
-    // load instruction touch 64 cache lines); rows are then read at an odd word stride (conflict-free).
+    // load instruction touch 64 cache lines); rows are then read at an odd word stride
+    // (conflict-free).  Half of the block at a time: 23 KiB instead of 46 KiB of LDS per workgroup
+    // lets five waves per SIMD stay resident instead of three on this HBM-bound kernel.
     constexpr int SHW = 3 * (N_SH - 1);
-    __shared__ alignas(16) float s_sh[(N_SH > 1 && !BAND) ? PP_BLOCK * SHW : 4];
-    if constexpr (N_SH > 1 && !BAND) {
-        const int g0 = blockIdx.x * PP_BLOCK;
-        const int rows = min(PP_BLOCK, N - g0);
-        const int count = rows * SHW;
-        const float* src = sh + (size_t)g0 * SHW;   // 16-byte aligned: g0 is a multiple of 256
-        const float4* src4 = reinterpret_cast<const float4*>(src);
-        float4* dst4 = reinterpret_cast<float4*>(s_sh);
-        for (int i = threadIdx.x; i < (count >> 2); i += PP_BLOCK) dst4[i] = src4[i];
-        for (int i = (count & ~3) + threadIdx.x; i < count; i += PP_BLOCK) s_sh[i] = src[i];
-    }
+    constexpr int HALF = PP_BLOCK / 2;
+    __shared__ alignas(16) float s_sh[(N_SH > 1 && !BAND) ? HALF * SHW : 4];
     const int g = blockIdx.x * PP_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool vis = false;
@@ -185,66 +178,93 @@ __global__ __launch_bounds__(PP_BLOCK) void k_preprocess(
     __syncthreads();
     int v = block_offsets[blockIdx.x] + __popcll(bal & ((1ull << lane) - 1));
     for (int w = 0; w < wave; w++) v += s_cnt[w];
-    if (g >= N) return;
-    o.culled[g] = vis ? 0 : 1;
-    o.rank[g] = vis ? v : -1;
-    if (!vis) return;
-
-    o.vis_idx[v] = g;
-    o.uv[v * 2 + 0] = uv[0];
-    o.uv[v * 2 + 1] = uv[1];
-    o.xyz_cam[v * 3 + 0] = c[0];
-    o.xyz_cam[v * 3 + 1] = c[1];
-    o.xyz_cam[v * 3 + 2] = c[2];
-
-    const float q4[4] = {quat[g * 4 + 0], quat[g * 4 + 1], quat[g * 4 + 2], quat[g * 4 + 3]};
-    const float s3[3] = {scale[g * 3 + 0], scale[g * 3 + 1], scale[g * 3 + 2]};
-    float S9[9], W[9], J6[6], c3[3];
-    sigma_world_of(q4, s3, S9);
-    load_rotation(M, W);
-    J6[0] = K[0] / c[2];                       // projection.cu:169-174
-    J6[1] = 0;
-    J6[2] = -K[0] * c[0] / (c[2] * c[2]);
-    J6[3] = 0;
-    J6[4] = K[4] / c[2];
-    J6[5] = -K[4] * c[1] / (c[2] * c[2]);
-    conic_of(J6, W, S9, c3);
-    o.conic[v * 3 + 0] = c3[0];
-    o.conic[v * 3 + 1] = c3[1];
-    o.conic[v * 3 + 2] = c3[2];
-
-    const float opa = sigmoid_det(opacity[g]);
-    o.opacity[v] = opa;
-
-    float col[3] = {0, 0, 0};
-    bool in_band = true;
-    if constexpr (BAND) {
-        const float a = c3[0] + 0.25f, b = c3[1] / 2.0f, cc = c3[2] + 0.25f;   // tile_culling.cu:142-144
-        const Obb obb = compute_obb(uv[0], uv[1], a, b, cc, band.mh);
-        const Window w = candidate_window(uv[0], uv[1], obb.radius_tiles, band.ntx, band.nty, band.row0,
-                                          band.row1);
-        in_band = w.sx < w.ex && w.sy < w.ey;
+    if (g < N) {
+        o.culled[g] = vis ? 0 : 1;
+        o.rank[g] = vis ? v : -1;
     }
-    if constexpr (N_SH == 1) {
-        col[0] = rgb[g * 3 + 0]; col[1] = rgb[g * 3 + 1]; col[2] = rgb[g * 3 + 2];
-    } else if (in_band) {
-        // precompute_sh.cu:28-55 with coefficient 0 = rgb and 1.. = sh (rasterize.py:89)
-        float d[3] = {p[0] - center[0], p[1] - center[1], p[2] - center[2]};
-        const float r = 1.0f / __builtin_sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-        d[0] *= r; d[1] *= r; d[2] *= r;
-        float Y[N_SH];
-        sh_basis<float, N_SH>(d, Y);
-        const float* shg = BAND ? sh + (size_t)g * SHW : s_sh + threadIdx.x * SHW;
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            float t = 0;
-            t += Y[0] * rgb[g * 3 + ch];
-#pragma unroll
-            for (int s = 1; s < N_SH; s++) t += Y[s] * shg[(N_SH - 1) * ch + (s - 1)];
-            t *= GS_R_SH_0;
-            col[ch] = t;
+    const bool act = g < N && vis;   // no early return: the SH staging below has workgroup barriers
+
+    float c3[3] = {0, 0, 0}, opa = 0;
+    bool in_band = true;
+    if (act) {
+        o.vis_idx[v] = g;
+        o.uv[v * 2 + 0] = uv[0];
+        o.uv[v * 2 + 1] = uv[1];
+        o.xyz_cam[v * 3 + 0] = c[0];
+        o.xyz_cam[v * 3 + 1] = c[1];
+        o.xyz_cam[v * 3 + 2] = c[2];
+
+        const float q4[4] = {quat[g * 4 + 0], quat[g * 4 + 1], quat[g * 4 + 2], quat[g * 4 + 3]};
+        const float s3[3] = {scale[g * 3 + 0], scale[g * 3 + 1], scale[g * 3 + 2]};
+        float S9[9], W[9], J6[6];
+        sigma_world_of(q4, s3, S9);
+        load_rotation(M, W);
+        J6[0] = K[0] / c[2];                       // projection.cu:169-174
+        J6[1] = 0;
+        J6[2] = -K[0] * c[0] / (c[2] * c[2]);
+        J6[3] = 0;
+        J6[4] = K[4] / c[2];
+        J6[5] = -K[4] * c[1] / (c[2] * c[2]);
+        conic_of(J6, W, S9, c3);
+        o.conic[v * 3 + 0] = c3[0];
+        o.conic[v * 3 + 1] = c3[1];
+        o.conic[v * 3 + 2] = c3[2];
+
+        opa = sigmoid_det(opacity[g]);
+        o.opacity[v] = opa;
+
+        if constexpr (BAND) {
+            const float a = c3[0] + 0.25f, b = c3[1] / 2.0f, cc = c3[2] + 0.25f;   // tile_culling.cu:142-144
+            const Obb obb = compute_obb(uv[0], uv[1], a, b, cc, band.mh);
+            const Window w = candidate_window(uv[0], uv[1], obb.radius_tiles, band.ntx, band.nty, band.row0,
+                                              band.row1);
+            in_band = w.sx < w.ex && w.sy < w.ey;
         }
     }
+
+    float col[3] = {0, 0, 0};
+    if constexpr (N_SH == 1) {
+        if (act) { col[0] = rgb[g * 3 + 0]; col[1] = rgb[g * 3 + 1]; col[2] = rgb[g * 3 + 2]; }
+    } else {
+        // precompute_sh.cu:28-55 with coefficient 0 = rgb and 1.. = sh (rasterize.py:89)
+        float Y[N_SH];
+        if (act && in_band) {
+            float d[3] = {p[0] - center[0], p[1] - center[1], p[2] - center[2]};
+            const float r = 1.0f / __builtin_sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            d[0] *= r; d[1] *= r; d[2] *= r;
+            sh_basis<float, N_SH>(d, Y);
+        }
+        auto colour_from = [&](const float* shg) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                float t = 0;
+                t += Y[0] * rgb[g * 3 + ch];
+#pragma unroll
+                for (int s = 1; s < N_SH; s++) t += Y[s] * shg[(N_SH - 1) * ch + (s - 1)];
+                t *= GS_R_SH_0;
+                col[ch] = t;
+            }
+        };
+        if constexpr (BAND) {
+            if (act && in_band) colour_from(sh + (size_t)g * SHW);
+        } else {
+#pragma unroll 1
+            for (int half = 0; half < 2; half++) {
+                const int g0 = blockIdx.x * PP_BLOCK + half * HALF;
+                const int rows = max(0, min(HALF, N - g0));
+                const int count = rows * SHW;
+                const float* src = sh + (size_t)g0 * SHW;   // 16-byte aligned: g0 is a multiple of 128
+                const float4* src4 = reinterpret_cast<const float4*>(src);
+                float4* dst4 = reinterpret_cast<float4*>(s_sh);
+                if (half) __syncthreads();   // the first half has been consumed
+                for (int i = threadIdx.x; i < (count >> 2); i += PP_BLOCK) dst4[i] = src4[i];
+                for (int i = (count & ~3) + threadIdx.x; i < count; i += PP_BLOCK) s_sh[i] = src[i];
+                __syncthreads();
+                if (act && (threadIdx.x / HALF) == half) colour_from(s_sh + (threadIdx.x % HALF) * SHW);
+            }
+        }
+    }
+    if (!act) return;
     o.rgb[v * 3 + 0] = col[0];
     o.rgb[v * 3 + 1] = col[1];
     o.rgb[v * 3 + 2] = col[2];
@@ -268,26 +288,26 @@ struct PreGrad {
 };
 
 template <int N_SH>
-__global__ __launch_bounds__(PP_BLOCK) void k_preprocess_bwd(
+__global__ __launch_bounds__(PP_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_preprocess_bwd(
     const float* __restrict__ xyz, const float* __restrict__ quat, const float* __restrict__ scale,
     const float* __restrict__ M, const float* __restrict__ K, const float* __restrict__ center,
     const int* __restrict__ rank, const float* __restrict__ opacity_act,
     const float* __restrict__ g_slab, int v_base, int N, PreGrad o) {
     constexpr int SHW = 3 * (N_SH - 1);
     // SH gradients (180 B per Gaussian at degree 3) are staged in LDS and written back as one
-    // contiguous block with coalesced 16-byte stores
-    __shared__ alignas(16) float s_sh[N_SH > 1 ? PP_BLOCK * SHW : 4];
+    // contiguous block with coalesced 16-byte stores -- half of the workgroup's rows at a time
+    // (23 KiB of LDS instead of 46: more resident waves on this HBM-bound kernel)
+    constexpr int HALF = PP_BLOCK / 2;
+    __shared__ alignas(16) float s_sh[N_SH > 1 ? HALF * SHW : 4];
     const int g = blockIdx.x * PP_BLOCK + threadIdx.x;
     const bool in_range = g < N;
     const int v = in_range ? rank[g] : -1;
     float gx[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0}, gs[3] = {0, 0, 0}, go = 0, gc[3] = {0, 0, 0};
-    float* gsh = s_sh + threadIdx.x * SHW;
-    if (v < 0) {
-        if constexpr (N_SH > 1) {
+    float Y[N_SH];
+    float gl3[3] = {0, 0, 0};   // d colour / d(sh row) factors of this Gaussian; 0 for culled rows
 #pragma unroll
-            for (int k = 0; k < 3 * (N_SH - 1); k++) gsh[k] = 0;
-        }
-    } else {
+    for (int s_ = 0; s_ < N_SH; s_++) Y[s_] = 0;
+    if (v >= 0) {
         const float p[3] = {xyz[g * 3 + 0], xyz[g * 3 + 1], xyz[g * 3 + 2]};
         float c[3];
         to_camera(M, p[0], p[1], p[2], c);
@@ -302,14 +322,11 @@ __global__ __launch_bounds__(PP_BLOCK) void k_preprocess_bwd(
             float d[3] = {p[0] - center[0], p[1] - center[1], p[2] - center[2]};
             const float r = 1.0f / __builtin_sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
             d[0] *= r; d[1] *= r; d[2] *= r;
-            float Y[N_SH];
             sh_basis<float, N_SH>(d, Y);
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
-                const float gl = gr[ch] * GS_R_SH_0;
-                gc[ch] = gl * Y[0];
-#pragma unroll
-                for (int s = 1; s < N_SH; s++) gsh[(N_SH - 1) * ch + (s - 1)] = gl * Y[s];
+                gl3[ch] = gr[ch] * GS_R_SH_0;
+                gc[ch] = gl3[ch] * Y[0];
             }
         }
         // opacity: d sigmoid = y (1 - y)
@@ -348,14 +365,25 @@ __global__ __launch_bounds__(PP_BLOCK) void k_preprocess_bwd(
         gx[2] = M[2] * gcam[0] + M[6] * gcam[1] + M[10] * gcam[2];
     }
     if constexpr (N_SH > 1) {
-        __syncthreads();
-        const int g0 = blockIdx.x * PP_BLOCK;
-        const int count = min(PP_BLOCK, N - g0) * SHW;
-        float* dst = o.sh + (size_t)g0 * SHW;
-        float4* dst4 = reinterpret_cast<float4*>(dst);
-        const float4* src4 = reinterpret_cast<const float4*>(s_sh);
-        for (int i = threadIdx.x; i < (count >> 2); i += PP_BLOCK) dst4[i] = src4[i];
-        for (int i = (count & ~3) + threadIdx.x; i < count; i += PP_BLOCK) dst[i] = s_sh[i];
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            if (half) __syncthreads();   // the first half has been written out
+            if ((int)(threadIdx.x / HALF) == half) {
+                float* gsh = s_sh + (threadIdx.x % HALF) * SHW;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+                    for (int s = 1; s < N_SH; s++) gsh[(N_SH - 1) * ch + (s - 1)] = gl3[ch] * Y[s];
+            }
+            __syncthreads();
+            const int g0 = blockIdx.x * PP_BLOCK + half * HALF;
+            const int count = max(0, min(HALF, N - g0)) * SHW;
+            float* dst = o.sh + (size_t)g0 * SHW;   // 16-byte aligned: g0 is a multiple of 128
+            float4* dst4 = reinterpret_cast<float4*>(dst);
+            const float4* src4 = reinterpret_cast<const float4*>(s_sh);
+            for (int i = threadIdx.x; i < (count >> 2); i += PP_BLOCK) dst4[i] = src4[i];
+            for (int i = (count & ~3) + threadIdx.x; i < count; i += PP_BLOCK) dst[i] = s_sh[i];
+        }
     }
     if (!in_range) return;
     o.xyz[g * 3 + 0] = gx[0]; o.xyz[g * 3 + 1] = gx[1]; o.xyz[g * 3 + 2] = gx[2];
