@@ -188,7 +188,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const int* __restrict__ cou
 // ---- privatized (LDS histogram) count / emit -----------------------------------------------------
 constexpr int PRIV_BLOCK = 512;
 constexpr int PRIV_MAX_TILES = 16384;   // 64 KiB of LDS
-constexpr int PRIV_NB = 512;            // workgroups (two per CU)
+constexpr int PRIV_NB = 1024;           // workgroups (four per CU)
 
 __device__ inline void slice_of(int b, int V, int& g0, int& g1) {
     const int chunk = (V + PRIV_NB - 1) / PRIV_NB;
