@@ -44,6 +44,16 @@ __device__ inline void adam_update(float& p, float g, float& m, float& v, float 
     p = p + (neg_step * m) / denom;
 }
 
+typedef float vfloat4 __attribute__((ext_vector_type(4)));
+__device__ inline float4 nt_load4(const float* p) {
+    const vfloat4 v = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ inline void nt_store4(float* p, const float4& a) {
+    vfloat4 v = {a.x, a.y, a.z, a.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(p));
+}
+
 // one float4 chunk (or the scalar tail of a tensor)
 struct AdamChunk {
     int k;
@@ -62,10 +72,10 @@ __device__ inline void adam_locate(const AdamGroups& G, long long c, AdamChunk& 
 
 __device__ inline void adam_load(const AdamGroups& G, AdamChunk& ch) {
     if (!ch.vec) return;
-    ch.p = *reinterpret_cast<const float4*>(G.p[ch.k] + ch.i);
-    ch.g = *reinterpret_cast<const float4*>(G.g[ch.k] + ch.i);
-    ch.m = *reinterpret_cast<const float4*>(G.m[ch.k] + ch.i);
-    ch.v = *reinterpret_cast<const float4*>(G.v[ch.k] + ch.i);
+    ch.p = nt_load4(G.p[ch.k] + ch.i);
+    ch.g = nt_load4(G.g[ch.k] + ch.i);
+    ch.m = nt_load4(G.m[ch.k] + ch.i);
+    ch.v = nt_load4(G.v[ch.k] + ch.i);
 }
 
 __device__ inline void adam_finish(const AdamGroups& G, AdamChunk& ch, float w1, float beta2,
@@ -77,9 +87,9 @@ __device__ inline void adam_finish(const AdamGroups& G, AdamChunk& ch, float w1,
         adam_update(ch.p.y, ch.g.y, ch.m.y, ch.v.y, w1, beta2, w2, bc2, eps, neg_step);
         adam_update(ch.p.z, ch.g.z, ch.m.z, ch.v.z, w1, beta2, w2, bc2, eps, neg_step);
         adam_update(ch.p.w, ch.g.w, ch.m.w, ch.v.w, w1, beta2, w2, bc2, eps, neg_step);
-        *reinterpret_cast<float4*>(G.p[k] + ch.i) = ch.p;
-        *reinterpret_cast<float4*>(G.m[k] + ch.i) = ch.m;
-        *reinterpret_cast<float4*>(G.v[k] + ch.i) = ch.v;
+        nt_store4(G.p[k] + ch.i, ch.p);
+        nt_store4(G.m[k] + ch.i, ch.m);
+        nt_store4(G.v[k] + ch.i, ch.v);
     } else {
         for (long long j = ch.i; j < ch.i + 4 && j < G.numel[k]; j++) {
             float p = G.p[k][j], m = G.m[k][j], v = G.v[k][j];
