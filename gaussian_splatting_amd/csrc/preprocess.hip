@@ -379,9 +379,11 @@ __global__ __launch_bounds__(PP_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
             const int g0 = blockIdx.x * PP_BLOCK + half * HALF;
             const int count = max(0, min(HALF, N - g0)) * SHW;
             float* dst = o.sh + (size_t)g0 * SHW;   // 16-byte aligned: g0 is a multiple of 128
-            float4* dst4 = reinterpret_cast<float4*>(dst);
-            const float4* src4 = reinterpret_cast<const float4*>(s_sh);
-            for (int i = threadIdx.x; i < (count >> 2); i += PP_BLOCK) dst4[i] = src4[i];
+            // streamed out once (the optimizer reads it much later): non-temporal 16-byte stores
+            typedef float vfloat4 __attribute__((ext_vector_type(4)));
+            vfloat4* dst4 = reinterpret_cast<vfloat4*>(dst);
+            const vfloat4* src4 = reinterpret_cast<const vfloat4*>(s_sh);
+            for (int i = threadIdx.x; i < (count >> 2); i += PP_BLOCK) __builtin_nontemporal_store(src4[i], dst4 + i);
             for (int i = (count & ~3) + threadIdx.x; i < count; i += PP_BLOCK) dst[i] = s_sh[i];
         }
     }
