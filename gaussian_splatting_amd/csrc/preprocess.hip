@@ -254,10 +254,13 @@ __global__ __launch_bounds__(PP_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))
                 const int rows = max(0, min(HALF, N - g0));
                 const int count = rows * SHW;
                 const float* src = sh + (size_t)g0 * SHW;   // 16-byte aligned: g0 is a multiple of 128
-                const float4* src4 = reinterpret_cast<const float4*>(src);
-                float4* dst4 = reinterpret_cast<float4*>(s_sh);
+                // read once per frame: non-temporal, so that the 0.5 GB stream does not push the
+                // records this kernel writes (and the render gathers) out of the caches
+                typedef float vfloat4 __attribute__((ext_vector_type(4)));
+                const vfloat4* src4 = reinterpret_cast<const vfloat4*>(src);
+                vfloat4* dst4 = reinterpret_cast<vfloat4*>(s_sh);
                 if (half) __syncthreads();   // the first half has been consumed
-                for (int i = threadIdx.x; i < (count >> 2); i += PP_BLOCK) dst4[i] = src4[i];
+                for (int i = threadIdx.x; i < (count >> 2); i += PP_BLOCK) dst4[i] = __builtin_nontemporal_load(src4 + i);
                 for (int i = (count & ~3) + threadIdx.x; i < count; i += PP_BLOCK) s_sh[i] = src[i];
                 __syncthreads();
                 if (act && (threadIdx.x / HALF) == half) colour_from(s_sh + (threadIdx.x % HALF) * SHW);
