@@ -80,6 +80,22 @@ def collect_timing():
     return out
 
 
+def timed_region(name, fn):
+    """run fn() and, when timing is enabled, book its GPU time (events on the current stream) under
+    `name` next to the C-ABI entry points -- used for the RCCL collectives of the multi-GPU frame"""
+    if _timers is None:
+        return fn()
+    import torch
+
+    a = torch.cuda.Event(enable_timing=True)
+    b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    out = fn()
+    b.record()
+    _timers.setdefault(name, []).append((a, b))
+    return out
+
+
 def call(name, *args):
     fn = getattr(lib(), name)
     if _timers is None:

@@ -146,6 +146,10 @@ class HaloPlan:
         recv = torch.empty(sum(self.recv_splits), SLAB_WIDTH, dtype=slab.dtype, device=slab.device)
         if all_to_all is not None:
             all_to_all(recv, send, self.recv_splits, self.send_splits)
+        elif slab.is_cuda:
+            from . import _hip
+            _hip.timed_region("rccl_all_to_all_grad_rows", lambda: dist.all_to_all_single(
+                recv, send, self.recv_splits, self.send_splits, group=group))
         else:
             dist.all_to_all_single(recv, send, self.recv_splits, self.send_splits, group=group)
         return self.unpack(recv)
@@ -196,7 +200,11 @@ def gather_bands(image, band_pixels, world_size, rank, group=None):
     the own band out, the rest in -- 1/8 of an all-reduce's traffic at 8 ranks)."""
     flat = image.view(-1)[:world_size * band_pixels]
     mine = flat[rank * band_pixels:(rank + 1) * band_pixels].clone()
-    dist.all_gather_into_tensor(flat, mine, group=group)
+    if image.is_cuda:
+        from . import _hip
+        _hip.timed_region("rccl_all_gather_image", lambda: dist.all_gather_into_tensor(flat, mine, group=group))
+    else:
+        dist.all_gather_into_tensor(flat, mine, group=group)
     return image
 
 
@@ -414,7 +422,12 @@ class ShardedRasterizer:
         return _SumGradsAcrossRanks.apply(self.group, *tensors)
 
     def _slab_sync(self, flat):
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        if flat.is_cuda:
+            from . import _hip
+            _hip.timed_region("rccl_all_reduce_grad_slab",
+                              lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group))
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
 
     def rasterize(self, gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_mask_padding, mh_dist,
                   use_sh_precompute, background_rgb, owned=None):
