@@ -278,7 +278,8 @@ def main():
     alg = algorithmic_bytes(N, V, S, P, n_coeff)
     per_entry = {k: (sum(v) / len(v), len(v) / args.steps) for k, v in timing.items() if v}
     # dominant entry point = largest GPU time per step
-    dom = max(per_entry, key=lambda k: per_entry[k][0] * per_entry[k][1]) if per_entry else None
+    kernels_only = [k for k in per_entry if k.startswith("gs_")]   # rccl_* regions are reported, not ranked
+    dom = max(kernels_only, key=lambda k: per_entry[k][0] * per_entry[k][1]) if kernels_only else None
     # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in their own
     # rocprofv3 runs and corrected for gfx950: scripts/pmc_passes.sh, scripts/make_traffic_json.py)
     traffic = {}
