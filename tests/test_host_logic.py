@@ -152,3 +152,35 @@ def test_quaternion_to_rotation_and_scale_init():
         d, _ = tree.query(pts[i].numpy(), k=4)
         assert np.allclose(got[i].numpy(), np.log(min(np.mean(d), 0.1) * 0.5), atol=1e-6)
     assert got.shape == (50, 3) and got.dtype == torch.float32
+
+
+def test_fused_slab_detection_and_arena():
+    """fused._as_slab: gradients that are the four views of one [V, 9] slab are passed through without a
+    copy; anything else (missing outputs, foreign tensors) is packed into a fresh slab.  _Arena: blocks
+    are disjoint, 16-byte aligned and sized as asked."""
+    import torch
+    from gaussian_splatting_amd import fused
+    V = 7
+    slab = torch.arange(V * 9, dtype=torch.float32).view(V, 9)
+    views = (slab[:, fused.SLAB_UV], slab[:, fused.SLAB_CONIC], slab[:, fused.SLAB_OPACITY], slab[:, fused.SLAB_RGB])
+    assert fused._as_slab(*views, V, slab.device) is slab
+    # the prefix view render_backward hands out (slab allocated with max(V, 1) rows)
+    big = torch.zeros(V + 3, 9)
+    pre = big[:V]
+    got = fused._as_slab(pre[:, fused.SLAB_UV], pre[:, fused.SLAB_CONIC], pre[:, fused.SLAB_OPACITY],
+                         pre[:, fused.SLAB_RGB], V, big.device)
+    assert got is big
+    # a consumer replaced one gradient, another output was never used
+    g_uv = torch.ones(V, 2)
+    packed = fused._as_slab(g_uv, views[1], None, views[3], V, slab.device)
+    assert packed is not slab and packed.shape == (V, 9)
+    assert torch.equal(packed[:, 4:6], g_uv) and torch.equal(packed[:, 6:9], slab[:, 6:9])
+    assert torch.equal(packed[:, 3], torch.zeros(V)) and torch.equal(packed[:, 0:3], slab[:, 0:3])
+
+    ar = fused._Arena(torch.float32, torch.device("cpu"), (3, 10, 0, 5))
+    blocks = ar.blocks()
+    assert [b.numel() for b in blocks] == [3, 10, 0, 5]
+    starts = [b.data_ptr() for b in blocks]
+    assert all(p % 16 == 0 for p in starts)
+    blocks[0].fill_(1.0); blocks[1].fill_(2.0); blocks[3].fill_(3.0)
+    assert float(blocks[0].sum()) == 3 and float(blocks[1].sum()) == 20 and float(blocks[3].sum()) == 15
