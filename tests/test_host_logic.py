@@ -161,7 +161,7 @@ def test_fused_slab_detection_and_arena():
     import torch
     from gaussian_splatting_amd import fused
     V = 7
-    slab = torch.arange(V * 9, dtype=torch.float32).view(V, 9)
+    slab = torch.arange(V * 9, dtype=torch.float32).view(V, 9).clone()   # a base tensor, as torch.zeros gives
     views = (slab[:, fused.SLAB_UV], slab[:, fused.SLAB_CONIC], slab[:, fused.SLAB_OPACITY], slab[:, fused.SLAB_RGB])
     assert fused._as_slab(*views, V, slab.device) is slab
     # the prefix view render_backward hands out (slab allocated with max(V, 1) rows)
