@@ -342,3 +342,25 @@ def test_kernels_run_on_the_current_stream():
     side.synchronize()
     assert torch.equal(img, ref_img)
     assert scaled_err(grad, ref_grad) < 1e-5
+
+
+def test_backward_hands_the_slab_through_without_a_copy(monkeypatch):
+    """_Render.backward returns four views of one [V, 9] slab; _Preprocess.backward must recognise them
+    (also with uv.retain_grad(), as the trainer does) and read the slab in place"""
+    seen = []
+    real = fused._as_slab
+
+    def spy(g_uv, g_conic, g_opa, g_rgb, V, dev):
+        out = real(g_uv, g_conic, g_opa, g_rgb, V, dev)
+        seen.append(g_rgb is not None and g_rgb._base is not None and out is g_rgb._base)
+        return out
+
+    monkeypatch.setattr(fused, "_as_slab", spy)
+    g, cam, T = make_scene(5000, 320, 240, 3, seed=5, device=DEV)
+    for k in PARAMS:
+        getattr(g, k).requires_grad_(True)
+    img, _, uv = fused.rasterize(g, T, cam, 0.3, 500.0, 100, 3.0, True, torch.zeros(3, device=DEV))
+    uv.retain_grad()
+    img.backward(make_grad_image(320, 240, seed=1, device=DEV))
+    assert seen == [True]
+    assert uv.grad is not None and uv.grad.shape == uv.shape and torch.isfinite(uv.grad).all()
