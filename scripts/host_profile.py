@@ -15,12 +15,24 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--workload", default="D")
 ap.add_argument("--steps", type=int, default=50)
+ap.add_argument("--rccl", action="store_true", help="world size 1 over real RCCL collectives instead of the local fills")
 a = ap.parse_args()
 N, W, H, deg = WORKLOADS[a.workload]
 g, cam, T = make_scene(N, W, H, deg, seed=0, device="cuda")
 gi = make_grad_image(W, H, seed=1, device="cuda")
 bg = torch.zeros(3, device="cuda")
-if a.world > 1:
+if a.rccl:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    owned = sharded.owned_slice(g, 1, 0)
+    rast = sharded.ShardedRasterizer(H, 1, 0, grad_mode="owner")
+    holders = owned
+
+    def fwd():
+        return rast.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, owned=owned, **DEFAULTS)
+elif a.world > 1:
     rank = a.world // 2
     owned = sharded.owned_slice(g, a.world, rank)
     rast = sharded.ShardedRasterizer(H, a.world, rank, grad_mode="owner", all_to_all=lambda r, s, rs, ss: r.zero_())

@@ -17,10 +17,14 @@ from gaussian_splatting_amd.synthetic import make_grad_image, make_scene
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=30)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--workload", default="", help="run ONE frame of this bench workload (e.g. D) instead of random scenes")
+ap.add_argument("--world", type=int, default=8)
 a = ap.parse_args()
 rng = random.Random(a.seed)
 NAMES = ("xyz", "rgb", "opacity", "scale", "quaternion", "sh")
 rows_moved = 0
+if a.workload:
+    a.n = 1
 for it in range(a.n):
     G = rng.choice([2, 3, 4, 5, 8])
     N = int(10 ** rng.uniform(2.5, 4.6))
@@ -29,6 +33,11 @@ for it in range(a.n):
     seed = rng.randint(0, 10 ** 6)
     shift = rng.choice([0.0, -3.0, 2.0])
     args = rng.choice([(0.3, 500.0, 100, 3.0), (2.0, 25.0, 20, 3.0), (5.0, 12.0, 0, 3.0)])
+    if a.workload:
+        from gaussian_splatting_amd.synthetic import DEFAULTS, WORKLOADS
+        N, W, H, deg = WORKLOADS[a.workload]
+        G, seed, shift = a.world, 0, 0.0
+        args = (DEFAULTS["near_thresh"], DEFAULTS["far_thresh"], DEFAULTS["cull_mask_padding"], DEFAULTS["mh_dist"])
     bg = torch.full((3,), rng.choice([0.0, 0.5]), device="cuda")
     gi = make_grad_image(W, H, seed=seed % 89, device="cuda")
 
