@@ -7,6 +7,9 @@ parameter gradients.  Inputs (Gaussian parameters, camera, grad
 in HBM before the timed region.  One rank per GPU; for N > 1 the frame is sharded by tile rows
 (strong scaling: the same frame on more GPUs) and rank 0 prints the line.
 
+`metric` is BASELINE.json's string verbatim; `value` is its first half (Mpixels/s), the second half
+("grad max-rel-err vs ref") is reported in the `parity` object.
+
 Prints ONE JSON line with the contract fields plus
   roofline      dominant entry point: algorithmic bytes / its mean GPU duration (events on the launch
                 stream, recorded inside the timed region) against the 8 TB/s HBM peak
@@ -322,7 +325,7 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "forward+backward Mpixels/s @ ~1MP, N Gaussians", "value": round(value, 3),
+            "metric": "forward+backward Mpixels/s @ ~1MP, N Gaussians; grad max-rel-err vs ref", "value": round(value, 3),
             "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
