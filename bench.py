@@ -5,7 +5,10 @@
 A step = one pass of the hot path over one frame: rasterize() forward + full backward to dense
 parameter gradients.  Inputs (Gaussian parameters, camera, grad_image) are resident
 in HBM before the timed region.  One rank per GPU; for N > 1 the frame is sharded by tile rows
-(strong scaling: the same frame on more GPUs) and rank 0 prints the line.
+(strong scaling: the same frame on more GPUs), every rank ends with the full image and -- by default,
+--grad-mode owner -- with the parameter gradients of the Gaussians it owns (the whole job holds every
+gradient row exactly once; --grad-mode replicated gives identical dense gradients on every rank at the
+price of an all-reduce of the whole render-gradient slab); rank 0 prints the line.
 
 `metric` is BASELINE.json's string verbatim; `value` is its first half (Mpixels/s), the second half
 ("grad max-rel-err vs ref") is reported in the `parity` object.
