@@ -83,3 +83,17 @@ def test_fuzz_fused_vs_oracle(case):
         assert scaled_err(uv.grad.cpu(), gr[2]) < 1e-5
     for k in ("xyz", "rgb", "opacity", "scale", "quaternion"):
         assert torch.isfinite(getattr(gd, k).grad).all(), k
+
+
+@pytest.mark.parametrize("script,args", [("stress_fused.py", ["--n", "16", "--seed", "5"]),
+                                         ("stress_sharded.py", ["--n", "6", "--seed", "5"])])
+def test_randomised_stress_scripts(script, args):
+    """a short run of the randomised checks under scripts/ (prefix-sort vs full-sort frames; owner-mode
+    frames with simulated ranks) so that every GPU test run covers fresh shapes of both"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", script)] + args, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]
