@@ -172,3 +172,23 @@ def test_training_iterations_reduce_the_loss():
         losses.append(float(loss.detach()))
     assert losses[-1] < 0.6 * losses[0], (losses[0], losses[-1])
     assert int(count.max()) == 40 and float(uv_acc.sum()) > 0 and torch.isfinite(xyz_acc).all()
+
+
+def test_adam_step_unaligned_views_take_the_scalar_path():
+    """parameters that are views at a 4-byte offset (not 16-byte aligned) and of odd length"""
+    base = torch.randn(1003, generator=torch.Generator().manual_seed(9))
+    grads = torch.randn(1002, generator=torch.Generator().manual_seed(10))
+    p_ref = base[1:].clone().requires_grad_(True)
+    p_ref.grad = grads.clone()
+    ref = torch.optim.Adam([p_ref], lr=1e-2)
+    store = base.to(DEV)
+    p_hip = store[1:].detach().requires_grad_(True)      # data_ptr is 4 bytes past a 16-byte boundary
+    assert p_hip.data_ptr() % 16 != 0
+    p_hip.grad = grads.to(DEV)
+    hip = Adam([p_hip], lr=1e-2)
+    for _ in range(3):
+        ref.step()
+        hip.step()
+    err = (p_hip.detach().cpu() - p_ref.detach()).abs().max() / p_ref.detach().abs().max()
+    assert float(err) < 2e-6
+    assert float(store[0]) == float(base[0])             # the element before the view is untouched
