@@ -10,7 +10,9 @@ in HBM before the timed region.  One rank per GPU; for N > 1 the frame is sharde
 gradient row exactly once; --grad-mode replicated gives identical dense gradients on every rank at the
 price of an all-reduce of the whole render-gradient slab); rank 0 prints the line.
 
-`metric` is BASELINE.json's string verbatim; `value` is its first half (Mpixels/s), the second half
+Before the W warm-up steps the bench runs --spinup-steps untimed frames (default 100, ~0.2 s) so that the
+measurement does not depend on what ran on the box before (clocks, allocator, capacity hints); the timed region
+is exactly K steps between barriers, as the contract asks.  `metric` is BASELINE.json's string verbatim; `value` is its first half (Mpixels/s), the second half
 ("grad max-rel-err vs ref") is reported in the `parity` object.
 
 Prints ONE JSON line with the contract fields plus
@@ -72,6 +74,10 @@ def parse():
                     help="multi-GPU only: 'owner' = every rank produces the parameter gradients of the Gaussians "
                     "it owns (sparse all_to_all of the partial render gradients); 'replicated' = identical dense "
                     "gradients on every rank (all-reduce of the whole render-gradient slab)")
+    ap.add_argument("--spinup-steps", type=int, default=100,
+                    help="untimed frames run BEFORE the W warm-up steps (the same count on every rank), so that "
+                    "allocator caches, capacity hints and GPU clocks are in steady state whatever ran on the box "
+                    "before; ~0.2 s at the default workload")
     ap.add_argument("--train-ops", action="store_true",
                     help="also time the training-loop operations behind the rasterizer (SURVEY.md 8(f4)) on the "
                     "workload's parameter set: Adam step (HIP vs torch), densification statistics; reported "
@@ -255,6 +261,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for i in range(args.spinup_steps):
+        step()
+        if i % 10 == 9:
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     barrier()
