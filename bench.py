@@ -261,6 +261,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Multi-GPU: one trial frame of the owner-sliced mode; if it raises on any rank, every rank falls
+    # back to replicated gradients (all-reduce only) and the line says so -- a number beats no number.
+    grad_mode_used = args.grad_mode
+    if (world > 1 or args.force_sharded) and args.grad_mode == "owner":
+        import torch.distributed as dist
+        ok = torch.ones(1, device=dev)
+        try:
+            step()
+            torch.cuda.synchronize()
+        except Exception as e:   # noqa: BLE001
+            print(f"[bench] rank {rank}: owner-mode trial frame failed: {e!r}", file=sys.stderr)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok) == 0.0:
+            grad_mode_used = "replicated (owner mode failed, see stderr)"
+            for name in PARAM_NAMES:
+                if getattr(g, name) is not None:
+                    getattr(g, name).requires_grad_(True)
+            owned, grad_holder = None, g
+            rast = ShardedRasterizer(cam.height, world, rank, fused=(path == "fused"), grad_mode="replicated")
+
     for i in range(args.spinup_steps):
         step()
         if i % 10 == 9:
@@ -349,7 +370,7 @@ def main():
             "config": {"workload": f"{args.workload}: {N} Gaussians, {W}x{H}, SH degree {deg}, seed 0",
                        "N": N, "V": V, "S": S, "P": P, "path": path,
                        "parallelism": "single" if world == 1 and not args.force_sharded
-                       else f"tile-rows x{world}, {args.grad_mode} gradients"},
+                       else f"tile-rows x{world}, {grad_mode_used} gradients"},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "other_workloads": other,
         }
         if train_ops is not None:
