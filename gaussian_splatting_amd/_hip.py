@@ -62,6 +62,21 @@ def check(status):
 # stream the kernels are launched on -- so the elapsed time of one entry point is the GPU time of
 # the kernels it enqueues.
 _timers = None
+_event_pool = []   # timing events are recycled: creating one costs ~5 us of host time per call
+
+
+def _event():
+    import torch
+
+    return _event_pool.pop() if _event_pool else torch.cuda.Event(enable_timing=True)
+
+
+def reserve_events(n):
+    """create the timing events ahead of the timed region"""
+    import torch
+
+    while len(_event_pool) < n:
+        _event_pool.append(torch.cuda.Event(enable_timing=True))
 
 
 def enable_timing(on=True):
@@ -74,7 +89,12 @@ def collect_timing():
     import torch
 
     torch.cuda.synchronize()
-    out = {name: [a.elapsed_time(b) for a, b in pairs] for name, pairs in (_timers or {}).items()}
+    out = {}
+    for name, pairs in (_timers or {}).items():
+        out[name] = [a.elapsed_time(b) for a, b in pairs]
+        for a, b in pairs:
+            _event_pool.append(a)
+            _event_pool.append(b)
     if _timers is not None:
         _timers.clear()
     return out
@@ -85,10 +105,7 @@ def timed_region(name, fn):
     `name` next to the C-ABI entry points -- used for the RCCL collectives of the multi-GPU frame"""
     if _timers is None:
         return fn()
-    import torch
-
-    a = torch.cuda.Event(enable_timing=True)
-    b = torch.cuda.Event(enable_timing=True)
+    a, b = _event(), _event()
     a.record()
     out = fn()
     b.record()
@@ -101,10 +118,7 @@ def call(name, *args):
     if _timers is None:
         check(fn(*args))
         return
-    import torch
-
-    a = torch.cuda.Event(enable_timing=True)
-    b = torch.cuda.Event(enable_timing=True)
+    a, b = _event(), _event()
     a.record()
     check(fn(*args))
     b.record()
