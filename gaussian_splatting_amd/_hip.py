@@ -8,7 +8,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsplat_hip.so")
+# GSPLAT_HIP_LIB selects another build of the same library (tools only: the instrumented
+# libgsplat_hip_stats.so of `make stats`); there is still no fallback if it is missing
+LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(_HERE, "libgsplat_hip.so")
 
 GS_F32 = 0
 GS_F64 = 1

@@ -34,6 +34,28 @@
 
 namespace gs {
 
+// Instrumented build only (make stats: -DGS_STATS -> libgsplat_hip_stats.so, scripts/render_stats.py):
+// per-wave event counts of the render kernels, summed into g_render_stats.  Expands to nothing in
+// the product library.
+#ifdef GS_STATS
+__device__ unsigned long long g_render_stats[32];
+#define GS_STAT_DECL unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define GS_STAT(i, v) st_[i] += (unsigned long long)(v)
+#define GS_STAT_FLAG(name) bool name = false
+#define GS_STAT_SET(name) name = true
+#define GS_STAT_FLUSH(base)                                                                        \
+    if ((threadIdx.x & 63) == 0) {                                                                 \
+        for (int q_ = 0; q_ < 16; q_++)                                                            \
+            if (st_[q_]) atomicAdd(&g_render_stats[(base) + q_], st_[q_]);                         \
+    }
+#else
+#define GS_STAT_DECL
+#define GS_STAT(i, v)
+#define GS_STAT_FLAG(name)
+#define GS_STAT_SET(name)
+#define GS_STAT_FLUSH(base)
+#endif
+
 #ifndef GS_BWD_GROUP
 #define GS_BWD_GROUP 16   // lanes summed with DPP before the LDS atomic (measured: 16 -> 0.90 ms, 64 -> 1.03, 8 -> 1.52)
 #endif
@@ -247,8 +269,13 @@ __device__ __forceinline__ void render_tile_fwd(
     __shared__ unsigned long long s_mask[4][NW];
 
     bool all_done = false;
+    GS_STAT_DECL;
+    GS_STAT(0, 1);          // waves
+    GS_STAT(7, n_tile);     // list entries of the wave's tile
     for (int base = 0; base < n_list; base += RCHUNK) {
         const int cnt = min(RCHUNK, n_list - base);
+        GS_STAT(1, 1);      // chunks
+        GS_STAT(8, cnt);    // list entries staged
         stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, nullptr);
         __syncthreads();
         build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
@@ -259,18 +286,24 @@ __device__ __forceinline__ void render_tile_fwd(
             while (m) {
                 const int i = word * 64 + __builtin_ctzll(m);
                 m &= m - 1;
+                GS_STAT(2, 1);                        // visits (touch-mask bits walked)
+                GS_STAT(6, __popcll(__ballot(!done)));   // live lanes at the visit
+                GS_STAT_FLAG(st_in);
+                GS_STAT_FLAG(st_hit);
                 if (!done) {
                     const T* rec = s_geom + i * GS_PACKED_WIDTH;
                     const Vec4<T> g0 = *reinterpret_cast<const Vec4<T>*>(rec);   // u v r2 opacity
                     const T du = pu - g0.x, dv = pv - g0.y;
                     // beyond the cutoff radius alpha < 1/255 is certain: same outcome as :145-148
                     if (!(fast && du * du + dv * dv > g0.z)) {
+                        GS_STAT_SET(st_in);
                         const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(rec + 4);   // a b c det
                         const T a = g1.x, b = g1.y, c = g1.z, det = g1.w;
                         const T mh = (c * du * du - (b + b) * du * dv + a * dv * dv) / det;
                         T alpha = g0.w * gexp<T>(T(-0.5) * mh);
                         alpha = (mh > T(0)) ? alpha : T(0);                 // render.cu:133
                         if (!(fast && alpha < Thr<T>::alpha_min())) {       // render.cu:145
+                            GS_STAT_SET(st_hit);
                             fw = 1.0 - acc;
                             const T weight = alpha * (1.0 - acc);           // double, narrowed
                             T col[3];
@@ -285,11 +318,15 @@ __device__ __forceinline__ void render_tile_fwd(
                         }
                     }
                 }
+                GS_STAT(3, __ballot(st_in) != 0);           // visits with a lane inside the cutoff circle
+                GS_STAT(4, __ballot(st_hit) != 0);          // visits with a contributing lane
+                GS_STAT(5, __popcll(__ballot(st_hit)));     // contributing (pixel, splat) pairs
             }
         }
         all_done = __syncthreads_and(done);
         if (all_done) break;
     }
+    GS_STAT_FLUSH(0);
     // an unsaturated pixel at the end of the prefix: the tile is redone from its full list
     if (tile_flags != nullptr && !flagged_only && tid == 0) tile_flags[tile] = prefix_only && !all_done;
 
@@ -456,10 +493,15 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
     bool bg_init = false;
     const T bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
+    GS_STAT_DECL;
+    GS_STAT(0, 1);          // waves
+    GS_STAT(7, n_tile);
+    GS_STAT(8, n_used);
     const int last_chunk = (n_used - 1) / RCHUNK;
     for (int chunk = last_chunk; chunk >= 0; chunk--) {
         const int base = chunk * RCHUNK;
         const int cnt = min(RCHUNK, n_used - base);
+        GS_STAT(1, 1);
         __syncthreads();   // previous chunk fully flushed
         stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, s_idx);
         for (int k = tid; k < cnt * NV; k += RB) s_acc[k] = 0;
@@ -476,7 +518,11 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
             const int i = (word << 6) + bit;
             const int k = base + i;
             const bool reach = valid && k < nsp;   // render_backward.cu:131
+            GS_STAT(2, 1);                          // visits
             if (__ballot(reach) == 0) continue;    // wave-uniform: no lane reaches this splat
+            GS_STAT(9, 1);                          // visits with a reaching lane
+            GS_STAT(6, __popcll(__ballot(reach)));
+            GS_STAT_FLAG(st_in);
             T val[NV];
 #pragma unroll
             for (int j = 0; j < NV; j++) val[j] = 0;
@@ -489,6 +535,7 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
                 const T a = g1.x, b = g1.y, c = g1.z, rdet = rec[8], opa = g0.w;
                 T norm_prob = 0, alpha = 0, mh = 0;
                 if (!(fast && du * du + dv * dv > g0.z)) {   // inside the cutoff radius
+                    GS_STAT_SET(st_in);
                     // render_backward.cu:153-165 (multiplies by 1/det; forward divides)
                     mh = (c * du * du - (b + b) * du * dv + a * dv * dv) * rdet;
                     if (mh > T(0)) norm_prob = gexp<T>(T(-0.5) * mh);
@@ -539,7 +586,11 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
                 }
             }
             const unsigned long long cmask = __ballot(contrib);
+            GS_STAT(3, __ballot(st_in) != 0);
+            GS_STAT(4, cmask != 0);
+            GS_STAT(5, __popcll(cmask));
             if (cmask == 0) continue;   // every reaching lane skipped the splat
+            GS_STAT(10, __popcll(cmask) <= 4);
             if (fast && __popcll(cmask) <= 4) {
                 // few contributors: they add their own values (<= 4 lanes per LDS atomic, the same
                 // conflict degree as the row-leader form) and the DPP reduction is skipped
@@ -602,6 +653,7 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
             bool any = false;
 #pragma unroll
             for (int j = 0; j < NV; j++) any |= (a[j] != T(0));
+            GS_STAT(11, __popcll(__ballot(any)));   // flushed rows
             if (any && slab) {
                 // one [V, 9] row per Gaussian (rgb 3 | opacity 1 | uv 2 | conic 3): the order of a[]
 #pragma unroll
@@ -618,6 +670,7 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
             }
         }
     }
+    GS_STAT_FLUSH(16);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -718,6 +771,20 @@ static int check_rows(int H, int row0, int row1) {
 }
 
 extern "C" {
+
+#ifdef GS_STATS
+// instrumented build only: copies the 32 counters to the host (and clears them when reset != 0)
+int gs_debug_render_stats(unsigned long long* out, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return GS_EHIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gs::g_render_stats), 32 * sizeof(unsigned long long)) != hipSuccess)
+        return GS_EHIP;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(gs::g_render_stats), z, sizeof(z)) != hipSuccess) return GS_EHIP;
+    }
+    return GS_OK;
+}
+#endif
 
 int gs_render_tiles(const void* packed, const void* rgb, const void* view_dir_by_pixel,
                     const int32_t* tile_ranges, const int32_t* sorted_gaussians,

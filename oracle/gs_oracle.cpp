@@ -47,6 +47,15 @@ int g_trig_mode = 0;  // 0 algebraic, 1 libm (literal)
 // test/test_rasterize.py:85-92,124-131 were generated with.  Mode 1 exists only
 // to pin the rest of the SH machinery against those constants.
 int g_sh_band1_mode = 0;
+// Checker aids (no reference counterpart):
+// g_bwd_abs: render_tiles_backward accumulates |term| instead of term, i.e. returns, per gradient
+//   element, the sum of the magnitudes of its per-pixel terms -- the scale against which fp32
+//   summation-order noise of that element is measured (tests/helpers.py: noise_normalised_err).
+// g_contrib_count: render_tiles additionally writes, per pixel, how many splats passed the
+//   alpha >= 1/255 test before the pixel saturated (render.cu:145-163) -- two runs whose inputs differ
+//   in the last ulp took the same decisions at a pixel iff this count and num_splats agree.
+int g_bwd_abs = 0;
+int* g_contrib_count = nullptr;
 
 // ---------------------------------------------------------------------------------------
 // deterministic exp for fp32 (IEEE ops only; explicit fma)
@@ -526,6 +535,8 @@ void orc_set_modes(int exp_mode, int trig_mode) {
     g_trig_mode = trig_mode;
 }
 void orc_set_sh_band1_mode(int m) { g_sh_band1_mode = m; }
+void orc_set_backward_abs(int on) { g_bwd_abs = on; }
+void orc_set_contrib_count(int* per_pixel) { g_contrib_count = per_pixel; }
 int orc_num_threads() {
 #ifdef _OPENMP
     return omp_get_max_threads();
@@ -716,7 +727,7 @@ void render_tiles(const T* uvs, const T* opacity, const T* rgb, const T* conic, 
                     if (n_sh > 1) sh_basis(view_dir + ((size_t)v_px * W + u_px) * 3, n_sh, Y);
                     else Y[0] = T(SH_0);
                     T alpha_accum = 0.0, alpha_weight = 0.0;
-                    int num_splats = 0;
+                    int num_splats = 0, n_contrib = 0;
                     T img[3] = {0.0, 0.0, 0.0};
                     for (int k = 0; k < n_tile; k++) {
                         if (alpha_accum > 0.9999) break;
@@ -752,11 +763,13 @@ void render_tiles(const T* uvs, const T* opacity, const T* rgb, const T* conic, 
                         for (int ch = 0; ch < 3; ch++) img[ch] += col[ch] * weight;
                         alpha_accum += weight;
                         num_splats++;
+                        n_contrib++;
                     }
                     if (alpha_accum < 0.999)
                         for (int ch = 0; ch < 3; ch++) img[ch] += background[ch] * (1.0 - alpha_accum);
                     const size_t p = (size_t)v_px * W + u_px;
                     num_splats_px[p] = num_splats;
+                    if (g_contrib_count) g_contrib_count[p] = n_contrib;
                     final_weight_px[p] = alpha_weight;
                     for (int ch = 0; ch < 3; ch++) image[p * 3 + ch] = img[ch];
                 }
@@ -782,6 +795,8 @@ void render_tiles_backward(const T* uvs, const T* opacity, const T* rgb, const T
                            const T* grad_image, int W, int H, int n_sh, int V, T* g_rgb,
                            T* g_opacity, T* g_uv, T* g_conic, int tile_y0, int tile_y1) {
     const bool fast = RenderMode<T>::fast;
+    const bool abs_mode = g_bwd_abs != 0;
+    auto mag = [abs_mode](double x) { return abs_mode ? std::fabs(x) : x; };
     const int CH = ref_chunk<T>(n_sh);
     const int ntx = (W + 15) / 16;
     const int nty = (H + 15) / 16;
@@ -856,7 +871,7 @@ void render_tiles_backward(const T* uvs, const T* opacity, const T* rgb, const T
                             double* L = &loc[(size_t)k * RW];
                             for (int s = 0; s < n_sh; s++)
                                 for (int ch = 0; ch < 3; ch++)
-                                    L[n_sh * ch + s] += (double)(T)(Y[s] * grl[ch]);
+                                    L[n_sh * ch + s] += mag((double)(T)(Y[s] * grl[ch]));
                             T grad_alpha = 0.0;
                             for (int ch = 0; ch < 3; ch++)
                                 grad_alpha += (col[ch] * weight - color_accum[ch] * r1ma) * gi[ch];
@@ -873,12 +888,12 @@ void render_tiles_backward(const T* uvs, const T* opacity, const T* rgb, const T
                             const T gc0 = (-c * cf + v_diff * v_diff * rdet) * grad_mh;
                             const T gc1 = (b * cf - u_diff * v_diff * rdet) * grad_mh;
                             const T gc2 = (-a * cf + u_diff * u_diff * rdet) * grad_mh;
-                            L[C + 0] += (double)grad_opa;
-                            L[C + 1] += (double)grad_u;
-                            L[C + 2] += (double)grad_v;
-                            L[C + 3] += (double)gc0;
-                            L[C + 4] += (double)gc1;
-                            L[C + 5] += (double)gc2;
+                            L[C + 0] += mag((double)grad_opa);
+                            L[C + 1] += mag((double)grad_u);
+                            L[C + 2] += mag((double)grad_v);
+                            L[C + 3] += mag((double)gc0);
+                            L[C + 4] += mag((double)gc1);
+                            L[C + 5] += mag((double)gc2);
                             for (int ch = 0; ch < 3; ch++) color_accum[ch] += col[ch] * alpha * weight;
                         }
                     }

@@ -221,6 +221,30 @@ def render_tiles_backward_cuda(uvs, opacity, rgb, conic, view_dir_by_pixel, spla
         _p(grad_rgb), _p(grad_opacity), _p(grad_uv), _p(grad_conic), y0, y1)
 
 
+def render_tiles_backward_abs(*args, **kw):
+    """render_tiles_backward_cuda with |term| accumulated instead of term: per gradient element the sum
+    of the magnitudes of its per-pixel terms (checker aid, no reference counterpart)."""
+    lib().orc_set_backward_abs(1)
+    try:
+        render_tiles_backward_cuda(*args, **kw)
+    finally:
+        lib().orc_set_backward_abs(0)
+
+
+def render_tiles_with_contrib_count(*args, **kw):
+    """render_tiles_cuda that also returns int32[H, W]: splats that passed the alpha >= 1/255 test at
+    each pixel before it saturated (checker aid: decision fingerprint of a pixel)."""
+    import torch
+    img = args[10] if len(args) > 10 else kw["rendered_image"]
+    count = torch.zeros(img.shape[0], img.shape[1], dtype=torch.int32)
+    lib().orc_set_contrib_count(_p(count))
+    try:
+        render_tiles_cuda(*args, **kw)
+    finally:
+        lib().orc_set_contrib_count(None)
+    return count
+
+
 def render_depth_cuda(xyz_camera_frame, uvs, opacity, conic, splat_start_end_idx_by_tile_idx,
                       gaussian_idx_by_splat_idx, alpha_threshold, depth_image):
     _check(xyz_camera_frame, uvs, opacity, conic, splat_start_end_idx_by_tile_idx,

@@ -12,6 +12,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_terminal_summary(terminalreporter):
+    """prints what the GPU parity tests measured (tests/helpers.py: report) and keeps it as JSON"""
+    import json
+
+    from tests import helpers
+    if not helpers.REPORT:
+        return
+    terminalreporter.section("parity report (measured errors)")
+    for row in helpers.REPORT:
+        terminalreporter.write_line(json.dumps(row))
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_report.json"), "w") as fh:
+            json.dump(helpers.REPORT, fh, indent=1)
+    except OSError:
+        pass
+
+
 @pytest.fixture
 def oracle_backend():
     """Routes the host-side mirror to the CPU oracle for the duration of one test (test-only:

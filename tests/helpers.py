@@ -64,3 +64,43 @@ def scaled_err(g, ref):
     if ref.numel() == 0:
         return 0.0
     return ((g - ref).abs().max() / ref.abs().max().clamp(min=1e-300)).item()
+
+
+def noise_normalised_err(g, ref, abs_sum):
+    """max over ALL elements (no floor) of |g - ref| / sum_pixels |term|.
+
+    `abs_sum` is the oracle's sum of the magnitudes of the per-pixel terms of each gradient element
+    (oracle.gs_oracle.render_tiles_backward_abs).  fp32 accumulation of n terms in any order deviates
+    from the exactly rounded sum (`ref`: the oracle accumulates in double and rounds once) by at most
+    ~n * 2^-24 * sum|term|, and the kernel's per-term values differ from the oracle's by a few ulp
+    (reciprocal instead of division, factored formulas), so a correct kernel stays within ~1e-5 of every
+    element's own scale -- including the small, cancelling elements that `rel_err`'s floor lets through."""
+    g = g.detach().double().cpu().reshape(-1)
+    ref = ref.detach().double().cpu().reshape(-1)
+    a = abs_sum.detach().double().cpu().reshape(-1)
+    if ref.numel() == 0:
+        return 0.0
+    touched = a > 0
+    assert not g[~touched].any(), "gradient on an element that no pixel contributes to"
+    if not touched.any():
+        return 0.0
+    return ((g - ref).abs()[touched] / a[touched]).max().item()
+
+
+# ---- parity report: numbers the GPU tests measured, printed at the end of the run and written to
+# gpurun_out/parity_report.json (tests/conftest.py) -------------------------------------------------------
+REPORT = []
+
+
+def report(test, **values):
+    REPORT.append(dict(test=test, **{k: (float(v) if isinstance(v, (int, float)) else v) for k, v in values.items()}))
+
+
+def grad_errors(g, ref, abs_sum=None):
+    """the three error measures of one gradient tensor: SURVEY.md 8(d)'s (floor 1e-6 of the max), the
+    1 %-floor form the assertions use, the error relative to the tensor's scale, and -- when the oracle's
+    abs-sums are given -- the floor-free noise-normalised error"""
+    out = {"rel_floor_1e-6": rel_err(g, ref, 1e-6), "rel_floor_1e-2": rel_err(g, ref, 1e-2), "scaled": scaled_err(g, ref)}
+    if abs_sum is not None:
+        out["noise_normalised"] = noise_normalised_err(g, ref, abs_sum)
+    return out
