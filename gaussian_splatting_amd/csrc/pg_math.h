@@ -138,9 +138,11 @@ __device__ inline void pack_record(T u, T v, const T* conic3, T opa, const T* co
     p[0] = u; p[1] = v; p[2] = cutoff_r2_t<T>(a, b, c, det, opa); p[3] = opa;
     p[4] = a; p[5] = b; p[6] = c; p[7] = det;
     p[8] = rdet;
-    p[9] = col3 ? col3[0] : T(0);
-    p[10] = col3 ? col3[1] : T(0);
-    p[11] = col3 ? col3[2] : T(0);
+    // the splat's colour as the render loops use it with one coefficient per channel: sh_to_rgb's
+    // Y0 * coefficient (spherical_harmonics.cuh:83), the same product formed once per splat
+    p[9] = col3 ? T(GS_SH_0) * col3[0] : T(0);
+    p[10] = col3 ? T(GS_SH_0) * col3[1] : T(0);
+    p[11] = col3 ? T(GS_SH_0) * col3[2] : T(0);
 }
 
 // projection_backward.cu:174-315

@@ -59,6 +59,9 @@ __device__ unsigned long long g_render_stats[32];
 #ifndef GS_BWD_GROUP
 #define GS_BWD_GROUP 16   // lanes summed with DPP before the LDS atomic (measured: 16 -> 0.90 ms, 64 -> 1.03, 8 -> 1.52)
 #endif
+#ifndef GS_BWD_CHUNK
+#define GS_BWD_CHUNK 128   // splats staged per step by the fused renderer's backward (LDS: 25 KB -> 6 workgroups per CU)
+#endif
 constexpr int RB = 256;      // workgroup size = pixels per tile
 
 // splats staged in LDS per step (at most one per thread); smaller for the wide test-only
@@ -121,6 +124,44 @@ __device__ inline void stage_chunk(const T* __restrict__ packed, const T* __rest
 }
 
 template <typename T> __device__ constexpr bool fast_mode() { return sizeof(T) == 4; }
+
+// wave ballot straight from the comparison's lane mask (HIP's __ballot first materialises the
+// predicate as an integer: v_cndmask + v_cmp per call)
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// exp(-0.5 * mh) of the render loops (render.cu:134, render_backward.cu:160), fp32: det_expf without
+// its range selects.  -0.5 * mh is exact, so t below is the same single rounding as det_expf's; for
+// t > -125 the remaining operations are det_expf's own, bit for bit.  Below that both values are
+// < 2^-100, and in fp32 the callers only use such a value through `opacity * value < 1/255`
+// (render.cu:145, render_backward.cu:170), which it fails either way.  mh > 0 and not NaN here.
+__device__ __forceinline__ float exp_neg_half(float mh) {
+    const float t = mh * (-0.5f * 1.44269504088896341f);
+    const float n = __builtin_rintf(t);
+    const float f = t - n;
+    float p = 1.54035303933816e-4f;
+    p = __builtin_fmaf(p, f, 1.33335581464284e-3f);
+    p = __builtin_fmaf(p, f, 9.61812910762848e-3f);
+    p = __builtin_fmaf(p, f, 5.55041086648216e-2f);
+    p = __builtin_fmaf(p, f, 2.40226506959101e-1f);
+    p = __builtin_fmaf(p, f, 6.93147180559945e-1f);
+    p = __builtin_fmaf(p, f, 1.0f);
+    return __builtin_ldexpf(p, (int)n);
+}
+__device__ __forceinline__ double exp_neg_half(double mh) { return exp(-0.5 * mh); }
+
+// q / det, correctly rounded, from the correctly rounded reciprocal r = RN(1 / det) of the packed
+// record ((float)(1.0 / (double)det) equals 1.0f / det for every float): y = RN(q r),
+// e = q - det y (exact in one fma), RN(y + e r) is the IEEE quotient (Markstein) for every normal
+// q, det with a normal quotient -- 3 instructions instead of the 10 of the division expansion.
+// Checked against `/` on 3.2e9 random and edge-mantissa pairs.  Where the quotient
+// overflows or det is 0 the result is NaN instead of +-inf; `mh > 0` is then false where the
+// reference finds exp(-inf) = 0: alpha = 0 either way.
+__device__ __forceinline__ float div_by_reciprocal(float q, float det, float r) {
+    const float y = q * r;
+    const float e = __builtin_fmaf(-det, y, q);
+    return __builtin_fmaf(e, r, y);
+}
+__device__ __forceinline__ double div_by_reciprocal(double q, double det, double) { return q / det; }
 template <typename T> __device__ inline T tmin(T a, T b) { return b < a ? b : a; }
 template <typename T> __device__ inline T tmax(T a, T b) { return b > a ? b : a; }
 
@@ -204,11 +245,12 @@ __device__ inline void build_touch_masks(const T* s_geom, int cnt, int tid, int 
 template <typename T, int N_SH>
 __device__ inline void splat_colour(const T* s_geom, const T* s_col, int i, const T* Y, T* col) {
     if constexpr (N_SH == 1) {
-        // sh_to_rgb with one coefficient per channel (spherical_harmonics.cuh:83)
+        // sh_to_rgb with one coefficient per channel (spherical_harmonics.cuh:83): the record holds
+        // Y0 * coefficient
         const Vec4<T> g2 = *reinterpret_cast<const Vec4<T>*>(s_geom + i * GS_PACKED_WIDTH + 8);
-        col[0] = Y[0] * g2.y;
-        col[1] = Y[0] * g2.z;
-        col[2] = Y[0] * g2.w;
+        col[0] = g2.y;
+        col[1] = g2.z;
+        col[2] = g2.w;
     } else {
         sh_to_rgb<T, N_SH>(s_col + i * ColW<N_SH>::value, Y, col);
     }
@@ -281,13 +323,13 @@ __device__ __forceinline__ void render_tile_fwd(
         build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
         __syncthreads();
         for (int word = 0; word < NW && word * 64 < cnt; word++) {
-            if (__ballot(!done) == 0) break;   // wave-uniform: every pixel of the patch saturated
+            if (ballot(!done) == 0) break;   // wave-uniform: every pixel of the patch saturated
             unsigned long long m = wave_uniform(s_mask[wave][word]);
             while (m) {
                 const int i = word * 64 + __builtin_ctzll(m);
                 m &= m - 1;
                 GS_STAT(2, 1);                        // visits (touch-mask bits walked)
-                GS_STAT(6, __popcll(__ballot(!done)));   // live lanes at the visit
+                GS_STAT(6, __popcll(ballot(!done)));   // live lanes at the visit
                 GS_STAT_FLAG(st_in);
                 GS_STAT_FLAG(st_hit);
                 if (!done) {
@@ -298,9 +340,10 @@ __device__ __forceinline__ void render_tile_fwd(
                     if (!(fast && du * du + dv * dv > g0.z)) {
                         GS_STAT_SET(st_in);
                         const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(rec + 4);   // a b c det
+                        const Vec4<T> g2 = *reinterpret_cast<const Vec4<T>*>(rec + 8);   // 1/det, colour
                         const T a = g1.x, b = g1.y, c = g1.z, det = g1.w;
-                        const T mh = (c * du * du - (b + b) * du * dv + a * dv * dv) / det;
-                        T alpha = g0.w * gexp<T>(T(-0.5) * mh);
+                        const T mh = div_by_reciprocal(c * du * du - (b + b) * du * dv + a * dv * dv, det, g2.x);
+                        T alpha = g0.w * exp_neg_half(mh);
                         alpha = (mh > T(0)) ? alpha : T(0);                 // render.cu:133
                         if (!(fast && alpha < Thr<T>::alpha_min())) {       // render.cu:145
                             GS_STAT_SET(st_hit);
@@ -318,9 +361,9 @@ __device__ __forceinline__ void render_tile_fwd(
                         }
                     }
                 }
-                GS_STAT(3, __ballot(st_in) != 0);           // visits with a lane inside the cutoff circle
-                GS_STAT(4, __ballot(st_hit) != 0);          // visits with a contributing lane
-                GS_STAT(5, __popcll(__ballot(st_hit)));     // contributing (pixel, splat) pairs
+                GS_STAT(3, ballot(st_in) != 0);           // visits with a lane inside the cutoff circle
+                GS_STAT(4, ballot(st_hit) != 0);          // visits with a contributing lane
+                GS_STAT(5, __popcll(ballot(st_hit)));     // contributing (pixel, splat) pairs
             }
         }
         all_done = __syncthreads_and(done);
@@ -426,6 +469,72 @@ template <typename T> __device__ inline void lds_add(T* p, T v) {
 }
 template <typename T> __device__ inline void global_add(T* p, T v) { unsafeAtomicAdd(p, v); }
 
+
+// v_permlane16_swap_b32 a, b: rows 1 and 3 (16-lane rows) of a are exchanged with rows 0 and 2 of b;
+// v_permlane32_swap_b32 a, b: lanes 32..63 of a with lanes 0..31 of b (gfx950).  Inline assembly: this
+// toolchain's builtin hands back its first result twice (scripts/ubench/permlane_test.hip checks the
+// semantics on the device).  Must run with all 64 lanes enabled.
+__device__ __forceinline__ void permlane16_swap(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void permlane32_swap(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+
+// Sums nine per-lane values over the 64 lanes of the wave and stores the nine totals to slot[0..8]
+// (LDS, owned by this wave for this splat: plain stores, no atomics -- an LDS float atomic costs
+// ~3.5 cycles PER ACTIVE LANE on gfx950, which made the accumulators the bound of the kernel).
+// A TRANSPOSING reduction: instead of summing all 9 values in every lane (54 cross-lane adds), lanes
+// trade halves of the value set -- after the xor-1 step a lane keeps 4 of the first 8 values, after the
+// xor-2 step 2 -- two row shifts finish the 16-lane rows (sums of values 2q, 2q+1 in lane 12+q', the
+// ninth in all of 12..15), one v_permlane16_swap puts the even values' row pairs in rows 0/2 and the
+// odd values' in rows 1/3, one v_permlane32_swap joins the halves: totals of the even values end in
+// lanes 12..15, of the odd values in lanes 28..31, the ninth in lane 47; those nine lanes store with
+// ONE ds_write_b32 (slot_lane_offset gives each its element, -1 elsewhere).
+// Lanes that do not contribute must hold zeros.
+__device__ __forceinline__ int slot_lane_offset(int lane) {
+    const int e = ((lane & 1) ? 4 : 0) + ((lane & 2) ? 2 : 0);   // the element pair the lane's quad position keeps
+    if ((lane & 12) != 12 || lane >= 48) return -1;
+    if (lane < 16) return e;
+    if (lane < 32) return e + 1;
+    return lane == 47 ? 8 : -1;
+}
+__device__ __forceinline__ void reduce9_to_slot(const float* val, int lane, int lane_offset, float* slot) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float r[4], s2[2];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float send = b0 ? val[j] : val[j + 4];
+        const float keep = b0 ? val[j + 4] : val[j];
+        r[j] = keep + GS_DPP(send, 0xB1, 0xf, true);     // quad_perm [1,0,3,2]
+    }
+    float s8 = val[8] + GS_DPP(val[8], 0xB1, 0xf, true);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const float send = b1 ? r[j] : r[j + 2];
+        const float keep = b1 ? r[j + 2] : r[j];
+        s2[j] = keep + GS_DPP(send, 0x4E, 0xf, true);    // quad_perm [2,3,0,1]
+    }
+    s8 += GS_DPP(s8, 0x4E, 0xf, true);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        s2[j] += GS_DPP(s2[j], 0x114, 0xf, true);        // row_shr:4
+        s2[j] += GS_DPP(s2[j], 0x118, 0xf, true);        // row_shr:8 -> lanes 12..15 of every row
+    }
+    s8 += GS_DPP(s8, 0x114, 0xf, true);
+    s8 += GS_DPP(s8, 0x118, 0xf, true);
+    // rows -> wave
+    float x = s2[0], y = s2[1];
+    permlane16_swap(x, y);           // x: rows (x0, y0, x2, y2); y: rows (x1, y1, x3, y3)
+    float z = x + y;                 // rows 0, 2: even values of row pairs (0,1), (2,3); rows 1, 3: odd values
+    float t = s8, u = s8;
+    permlane16_swap(t, u);
+    float e = t + u;                 // ninth value: rows 0, 1 hold rows 0+1, rows 2, 3 hold rows 2+3
+    permlane32_swap(z, e);           // z: (z.lo, e.lo); e: (z.hi, e.hi)
+    const float total = z + e;       // lanes 0..31: even / odd values' totals; lanes 32..63: the ninth
+    if (lane_offset >= 0) slot[lane_offset] = total;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------
@@ -441,13 +550,20 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
     constexpr int C = 3 * N_SH;
     constexpr int NV = C + 6;   // rgb coeffs, opacity, u, v, conic x3
     constexpr int REF_CH = ref_chunk<T>(N_SH);
-    constexpr int RCHUNK = Chunk<T, N_SH>::value;
+    // SLOTS: the fp32 one-coefficient kernel of the fused renderer.  Every wave owns a slot of nine sums
+    // per staged splat and writes it once (plain store after a full-wave reduction), the flush adds the
+    // slots of the waves that wrote -- no LDS atomics, no zero fill.  The other instantiations
+    // (per-pixel SH, fp64: tests and gradcheck) keep one shared accumulator row per splat.
+    constexpr bool SLOTS = fast && N_SH == 1;
+    constexpr int RCHUNK = SLOTS ? GS_BWD_CHUNK : Chunk<T, N_SH>::value;
+    constexpr int NWORD = RCHUNK / 64 > 0 ? RCHUNK / 64 : 1;
     __shared__ alignas(16) T s_geom[RCHUNK * GS_PACKED_WIDTH];
     __shared__ alignas(16) T s_col[N_SH > 1 ? RCHUNK * CW : 4];
     __shared__ int s_idx[RCHUNK];
-    __shared__ T s_acc[RCHUNK * NV];
+    __shared__ T s_acc[SLOTS ? 4 * RCHUNK * NV : RCHUNK * NV];   // SLOTS: [wave][splat][9]
     __shared__ int s_max[4];
-    __shared__ unsigned long long s_mask[4][RCHUNK / 64 > 0 ? RCHUNK / 64 : 1];
+    __shared__ unsigned long long s_mask[4][NWORD];
+    __shared__ unsigned long long s_hit[SLOTS ? 4 : 1][NWORD];   // SLOTS: slots written by each wave
 
     const int t_local = tile_of_block(blockIdx.x, nt);
     if (t_local >= nt) return;
@@ -489,6 +605,8 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
     if (n_used <= 0) return;
 
     const T pu = T(px.u), pv = T(px.v);
+    const T ygi[3] = {Y[0] * gi[0], Y[0] * gi[1], Y[0] * gi[2]};
+    const int slot_off = slot_lane_offset(lane);
     T color_accum[3] = {0, 0, 0};
     bool bg_init = false;
     const T bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
@@ -504,7 +622,8 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
         GS_STAT(1, 1);
         __syncthreads();   // previous chunk fully flushed
         stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, s_idx);
-        for (int k = tid; k < cnt * NV; k += RB) s_acc[k] = 0;
+        if constexpr (!SLOTS)
+            for (int k = tid; k < cnt * NV; k += RB) s_acc[k] = 0;
         __syncthreads();
         build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
         __syncthreads();
@@ -512,17 +631,90 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
         for (int word = (cnt - 1) >> 6; word >= 0; word--) {
           unsigned long long m = s_mask[wave][word];
           m = wave_uniform(m);
+          unsigned long long hit = 0;   // SLOTS: the splats of this word whose slot the wave wrote
           while (m) {
             const int bit = 63 - __builtin_clzll(m);
             m &= ~(1ull << bit);
             const int i = (word << 6) + bit;
             const int k = base + i;
-            const bool reach = valid && k < nsp;   // render_backward.cu:131
+            const bool reach = k < nsp;   // render_backward.cu:131 (nsp == 0 outside the image)
             GS_STAT(2, 1);                          // visits
-            if (__ballot(reach) == 0) continue;    // wave-uniform: no lane reaches this splat
+            if (ballot(reach) == 0) continue;      // wave-uniform: no lane reaches this splat
             GS_STAT(9, 1);                          // visits with a reaching lane
-            GS_STAT(6, __popcll(__ballot(reach)));
+            GS_STAT(6, __popcll(ballot(reach)));
             GS_STAT_FLAG(st_in);
+            if constexpr (SLOTS) {
+                // ---- fp32, one colour coefficient per channel: the fused renderer's kernel -------------
+                // Per lane: aw = alpha * weight (colour gradient = aw * Y0 grad_image[ch]),
+                // w = norm_prob * grad_alpha (the opacity gradient term), and with t = k w,
+                // k = -0.5 opacity / det a per-splat constant applied in the flush:
+                //   grad_u = -2 (c du - b dv) t, grad_v = -2 (a dv - b du) t     (render_backward.cu:216-219)
+                //   grad_conic = (dv^2 - c mh, b mh - du dv, du^2 - a mh) t      (:221-229, cf = mh / det)
+                // The uv pair only needs the sums of w du and w dv (the flush forms the combinations);
+                // the conic terms are formed per pixel as the reference does -- their cancellation is
+                // benign there and would not be after the sum.  All nine are 0 for a lane that does not
+                // contribute, so the reduction needs no zero-filled value array.
+                const T* rec = s_geom + i * GS_PACKED_WIDTH;
+                const Vec4<T> g0 = *reinterpret_cast<const Vec4<T>*>(rec);       // u v r2 opacity
+                const T du = pu - g0.x, dv = pv - g0.y;
+                const T du2 = du * du, dv2 = dv * dv;
+                T aw = 0, w = 0, q0 = 0, q1 = 0, q2 = 0;
+                if (reach && !(du2 + dv2 > g0.z)) {   // inside the cutoff radius
+                    GS_STAT_SET(st_in);
+                    const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(rec + 4);   // a b c det
+                    const Vec4<T> g2 = *reinterpret_cast<const Vec4<T>*>(rec + 8);   // 1/det, colour
+                    // render_backward.cu:153-165 (multiplies by 1/det; the forward divides)
+                    const T duv = du * dv;
+                    const T mh = (g1.z * du * du - (g1.y + g1.y) * du * dv + g1.x * dv * dv) * g2.x;
+                    T norm_prob = 0;
+                    if (mh > T(0)) norm_prob = exp_neg_half(mh);
+                    T alpha = g0.w * norm_prob;
+                    if (alpha > Thr<T>::sat_gt()) alpha = Thr<T>::alpha_cap();   // min(0.9999, .)
+                    if (alpha >= Thr<T>::alpha_min()) {
+                        if (!bg_init) {   // render_backward.cu:172-181
+                            const T bw = 1.0 - (alpha * weight + 1.0 - weight);
+                            if (bw > Thr<T>::bgw_gt()) {
+                                color_accum[0] += bg0 * bw;
+                                color_accum[1] += bg1 * bw;
+                                color_accum[2] += bg2 * bw;
+                            }
+                            bg_init = true;
+                        }
+                        // values only from here on (no threshold depends on them): contraction allowed
+                        {
+#pragma clang fp contract(fast)
+                            const T r1ma = fast_rcp(T(1) - alpha);
+                            if ((k % REF_CH) < nsp - 1) weight = weight * r1ma;   // Q1 (chunk-local index)
+                            aw = alpha * weight;
+                            // grad_alpha (render_backward.cu:196-203); the record's colour is Y0 * coefficient
+                            const T c0 = g2.y, c1 = g2.z, c2 = g2.w;
+                            const T ga = (c0 * weight - color_accum[0] * r1ma) * gi[0] +
+                                         (c1 * weight - color_accum[1] * r1ma) * gi[1] +
+                                         (c2 * weight - color_accum[2] * r1ma) * gi[2];
+                            color_accum[0] += c0 * aw;
+                            color_accum[1] += c1 * aw;
+                            color_accum[2] += c2 * aw;
+                            w = norm_prob * ga;
+                            q0 = (dv2 - g1.z * mh) * w;
+                            q1 = (g1.y * mh - duv) * w;
+                            q2 = (du2 - g1.x * mh) * w;
+                        }
+                    }
+                }
+                // a lane contributes iff it passed the alpha test; aw > 0 there (alpha >= 1/255, weight > 0)
+                const unsigned long long cmask = ballot(aw != T(0));
+                GS_STAT(3, ballot(st_in) != 0);
+                GS_STAT(4, cmask != 0);
+                GS_STAT(5, __popcll(cmask));
+                if (cmask == 0) continue;   // every reaching lane skipped the splat
+                T val[9];
+                val[0] = aw * ygi[0]; val[1] = aw * ygi[1]; val[2] = aw * ygi[2];
+                val[3] = w; val[4] = w * du; val[5] = w * dv;
+                val[6] = q0; val[7] = q1; val[8] = q2;
+                reduce9_to_slot(val, lane, slot_off, &s_acc[(wave * RCHUNK + i) * NV]);
+                hit |= 1ull << bit;
+                continue;
+            }
             T val[NV];
 #pragma unroll
             for (int j = 0; j < NV; j++) val[j] = 0;
@@ -600,42 +792,7 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
                 }
                 continue;
             }
-            if constexpr (fast && NV == 9 && GS_BWD_GROUP == 16) {
-                // Transposing reduction over each 16-lane row: instead of summing all 9 values in
-                // every lane (36 DPP adds), lanes trade halves -- after the xor-1 step a lane keeps
-                // 4 of the first 8 values, after the xor-2 step 2 -- and the remaining 3 sums per
-                // lane cross the four quads with two row shifts: 26 VALU ops, and the row's sums
-                // end up spread over lanes 12..15, which issue 3 LDS atomics instead of 9.
-                const bool b0 = lane & 1, b1 = lane & 2;
-                float r[4], s2[2];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const float send = b0 ? val[j] : val[j + 4];
-                    const float keep = b0 ? val[j + 4] : val[j];
-                    r[j] = keep + GS_DPP(send, 0xB1, 0xf, true);     // quad_perm [1,0,3,2]
-                }
-                float s8 = val[8] + GS_DPP(val[8], 0xB1, 0xf, true);
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const float send = b1 ? r[j] : r[j + 2];
-                    const float keep = b1 ? r[j + 2] : r[j];
-                    s2[j] = keep + GS_DPP(send, 0x4E, 0xf, true);    // quad_perm [2,3,0,1]
-                }
-                s8 += GS_DPP(s8, 0x4E, 0xf, true);
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    s2[j] += GS_DPP(s2[j], 0x114, 0xf, true);        // row_shr:4
-                    s2[j] += GS_DPP(s2[j], 0x118, 0xf, true);        // row_shr:8 -> lanes 12..15
-                }
-                s8 += GS_DPP(s8, 0x114, 0xf, true);
-                s8 += GS_DPP(s8, 0x118, 0xf, true);
-                if ((lane & 12) == 12) {
-                    float* dst = &s_acc[i * NV + (b0 ? 4 : 0) + (b1 ? 2 : 0)];
-                    lds_add(dst, s2[0]);
-                    lds_add(dst + 1, s2[1]);
-                    if ((lane & 3) == 3) lds_add(&s_acc[i * NV + 8], s8);
-                }
-            } else {
+            {
 #pragma unroll
                 for (int j = 0; j < NV; j++) val[j] = row_sum(val[j]);
                 if (row_leader<T>(lane)) {
@@ -644,12 +801,38 @@ __global__ __launch_bounds__(RB) void k_render_bwd(
                 }
             }
           }
+          if constexpr (SLOTS)
+              if (lane == 0) s_hit[wave][word] = hit;
         }
         __syncthreads();
         // one global atomic per value per (splat, tile)
         if (tid < cnt) {
             const int g = s_idx[tid];
-            const T* a = s_acc + tid * NV;
+            T acc_row[NV];
+            T* a = SLOTS ? acc_row : s_acc + tid * NV;
+            if constexpr (SLOTS) {
+                // the slots of the waves that wrote this splat, in wave order (deterministic per tile)
+#pragma unroll
+                for (int j = 0; j < NV; j++) a[j] = 0;
+#pragma unroll
+                for (int w4 = 0; w4 < 4; w4++) {
+                    if ((s_hit[w4][tid >> 6] >> (tid & 63)) & 1ull) {
+                        const T* sl = s_acc + (w4 * RCHUNK + tid) * NV;
+#pragma unroll
+                        for (int j = 0; j < NV; j++) a[j] += sl[j];
+                    }
+                }
+                // sums of (w, w du, w dv) and of the per-pixel conic terms -> gradients (see the loop)
+                const T* rec = s_geom + tid * GS_PACKED_WIDTH;
+                const T ca = rec[4], cb = rec[5], cc = rec[6];
+                const T k = T(-0.5) * rec[3] * rec[8];
+                const T Mu = a[4], Mv = a[5];
+                a[4] = T(-2) * k * (cc * Mu - cb * Mv);
+                a[5] = T(-2) * k * (ca * Mv - cb * Mu);
+                a[6] *= k;
+                a[7] *= k;
+                a[8] *= k;
+            }
             bool any = false;
 #pragma unroll
             for (int j = 0; j < NV; j++) any |= (a[j] != T(0));

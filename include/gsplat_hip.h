@@ -184,12 +184,13 @@ int gs_preprocess_backward(const void* xyz, const void* quaternion, const void* 
 
 /* ---- tile renderer ---------------------------------------------------------------------------- */
 /* Packs what the render kernels read per splat into one 48-byte (fp32) record per visible Gaussian:
- *   packed[V][12] = (u, v, r2, opacity | a, b, c, det | 1/det, col0, col1, col2)
+ *   packed[V][12] = (u, v, r2, opacity | a, b, c, det | 1/det, SH_0*col0, SH_0*col1, SH_0*col2)
  * a/b/c as render.cu:117-128 forms them (+0.25 dilation for fp32, none for fp64); r2 is a
  * conservative squared cutoff radius: a pixel farther than sqrt(r2) from (u, v) provably has
  * alpha < 1/255 and is skipped exactly as render.cu:145-148 would skip it (+inf for fp64, which
- * has no alpha threshold); col = rgb[V,3] when rgb is given with n_sh == 1 (else unused: the
- * kernels then gather the [3, n_sh] coefficients from `rgb` directly).
+ * has no alpha threshold); col = rgb[V,3] when rgb is given with n_sh == 1, stored as the product
+ * SH_0 * col that sh_to_rgb forms per pixel (spherical_harmonics.cuh:83) (else unused: the kernels
+ * then gather the [3, n_sh] coefficients from `rgb` directly).
  * uvs[V,2], opacity[V,1], conic[V,3], rgb[V,3] or NULL. */
 int gs_pack_splats(const void* uvs, const void* opacity, const void* conic, const void* rgb, int V,
                    void* packed, int dtype, void* stream);

@@ -48,9 +48,10 @@ int g_trig_mode = 0;  // 0 algebraic, 1 libm (literal)
 // to pin the rest of the SH machinery against those constants.
 int g_sh_band1_mode = 0;
 // Checker aids (no reference counterpart):
-// g_bwd_abs: render_tiles_backward accumulates |term| instead of term, i.e. returns, per gradient
-//   element, the sum of the magnitudes of its per-pixel terms -- the scale against which fp32
-//   summation-order noise of that element is measured (tests/helpers.py: noise_normalised_err).
+// g_bwd_abs: render_tiles_backward returns, per gradient element, the sum over pixels of the magnitudes
+//   of the LEAF terms of its formula (every product entering a sum or difference) -- the scale against
+//   which an fp32 evaluation's rounding + summation-order noise is measured
+//   (tests/helpers.py: noise_normalised_err).
 // g_contrib_count: render_tiles additionally writes, per pixel, how many splats passed the
 //   alpha >= 1/255 test before the pixel saturated (render.cu:145-163) -- two runs whose inputs differ
 //   in the last ulp took the same decisions at a pixel iff this count and num_splats agree.
@@ -796,7 +797,6 @@ void render_tiles_backward(const T* uvs, const T* opacity, const T* rgb, const T
                            T* g_opacity, T* g_uv, T* g_conic, int tile_y0, int tile_y1) {
     const bool fast = RenderMode<T>::fast;
     const bool abs_mode = g_bwd_abs != 0;
-    auto mag = [abs_mode](double x) { return abs_mode ? std::fabs(x) : x; };
     const int CH = ref_chunk<T>(n_sh);
     const int ntx = (W + 15) / 16;
     const int nty = (H + 15) / 16;
@@ -869,9 +869,34 @@ void render_tiles_backward(const T* uvs, const T* opacity, const T* rgb, const T
                             T col[3];
                             sh_to_rgb(rgb + (size_t)g * C, Y, n_sh, col);
                             double* L = &loc[(size_t)k * RW];
+                            if (abs_mode) {
+                                // checker aid: per element the sum of the magnitudes of the LEAF terms
+                                // of the formulas below (every product that enters a sum or difference),
+                                // the scale of an fp32 evaluation's rounding and summation-order noise
+                                double ga = 0.0;   // leaf magnitude of grad_alpha
+                                for (int ch = 0; ch < 3; ch++)
+                                    ga += (std::fabs((double)col[ch] * weight) +
+                                           std::fabs((double)color_accum[ch] * r1ma)) *
+                                          std::fabs((double)gi[ch]);
+                                for (int s = 0; s < n_sh; s++)
+                                    for (int ch = 0; ch < 3; ch++)
+                                        L[n_sh * ch + s] += std::fabs((double)Y[s] * grl[ch]);
+                                const double gm = 0.5 * (double)norm_prob * std::fabs((double)opacity[g]) * ga;
+                                const double u = u_diff, v = v_diff, rd = rdet;
+                                const double cfm = (std::fabs((double)a) * v * v + 2 * std::fabs((double)b * u * v) +
+                                                    std::fabs((double)c) * u * u) * rd * rd;
+                                L[C + 0] += (double)norm_prob * ga;
+                                L[C + 1] += (2 * std::fabs((double)b * v) + 2 * std::fabs((double)c * u)) * rd * gm;
+                                L[C + 2] += (2 * std::fabs((double)a * v) + 2 * std::fabs((double)b * u)) * rd * gm;
+                                L[C + 3] += (std::fabs((double)c) * cfm + v * v * rd) * gm;
+                                L[C + 4] += (std::fabs((double)b) * cfm + std::fabs(u * v) * rd) * gm;
+                                L[C + 5] += (std::fabs((double)a) * cfm + u * u * rd) * gm;
+                                for (int ch = 0; ch < 3; ch++) color_accum[ch] += col[ch] * alpha * weight;
+                                continue;
+                            }
                             for (int s = 0; s < n_sh; s++)
                                 for (int ch = 0; ch < 3; ch++)
-                                    L[n_sh * ch + s] += mag((double)(T)(Y[s] * grl[ch]));
+                                    L[n_sh * ch + s] += (double)(T)(Y[s] * grl[ch]);
                             T grad_alpha = 0.0;
                             for (int ch = 0; ch < 3; ch++)
                                 grad_alpha += (col[ch] * weight - color_accum[ch] * r1ma) * gi[ch];
@@ -888,12 +913,12 @@ void render_tiles_backward(const T* uvs, const T* opacity, const T* rgb, const T
                             const T gc0 = (-c * cf + v_diff * v_diff * rdet) * grad_mh;
                             const T gc1 = (b * cf - u_diff * v_diff * rdet) * grad_mh;
                             const T gc2 = (-a * cf + u_diff * u_diff * rdet) * grad_mh;
-                            L[C + 0] += mag((double)grad_opa);
-                            L[C + 1] += mag((double)grad_u);
-                            L[C + 2] += mag((double)grad_v);
-                            L[C + 3] += mag((double)gc0);
-                            L[C + 4] += mag((double)gc1);
-                            L[C + 5] += mag((double)gc2);
+                            L[C + 0] += (double)grad_opa;
+                            L[C + 1] += (double)grad_u;
+                            L[C + 2] += (double)grad_v;
+                            L[C + 3] += (double)gc0;
+                            L[C + 4] += (double)gc1;
+                            L[C + 5] += (double)gc2;
                             for (int ch = 0; ch < 3; ch++) color_accum[ch] += col[ch] * alpha * weight;
                         }
                     }

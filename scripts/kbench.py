@@ -1,0 +1,92 @@
+"""Kernel-level A/B harness: times the entry points of ONE build of the library on one frame.
+
+    GSPLAT_HIP_LIB=<path to a libgsplat_hip*.so> python scripts/kbench.py --workload D [--save ref.pt | --check ref.pt]
+
+Runs the per-Gaussian stage, binning and sort once, then `--reps` x (render forward, render backward,
+[--full: the whole stage chain]) with events around every C-ABI call; prints the median GPU time per entry
+point.  --save keeps the image and the render-gradient slab of this build; --check compares this build's
+against a saved one (image: bit equality; slab: error relative to the tensor's scale), so that several
+variant builds can be compared in one GPU call.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from gaussian_splatting_amd import _hip, fused  # noqa: E402
+from gaussian_splatting_amd.synthetic import DEFAULTS, WORKLOADS, make_grad_image, make_scene  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="D")
+    ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--save", default="")
+    ap.add_argument("--check", default="")
+    ap.add_argument("--full", action="store_true", help="also time preprocess / binning / per-Gaussian backward")
+    ap.add_argument("--tag", default="")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    _hip.lib()
+    N, W, H, deg = WORKLOADS[args.workload]
+    g, cam, T = make_scene(N, W, H, deg, seed=0, device=dev)
+    gi = make_grad_image(W, H, seed=1, device=dev)
+    bg = torch.zeros(3, device=dev)
+    d = DEFAULTS
+
+    def stage1():
+        return fused.preprocess_forward(g.xyz, g.quaternion, g.scale, g.opacity, g.rgb, g.sh, T, cam.K, W, H,
+                                        d["near_thresh"], d["far_thresh"], d["cull_mask_padding"], d["mh_dist"], None,
+                                        _hip.GS_SORT_PREFIX)
+
+    f = stage1()
+    V = f.V
+    rgb_v = f.rgb_render[:V]
+
+    def fwd():
+        return fused.render_forward(f.packed, rgb_v, f.ranges, f.sorted_g, f.keys, bg, H, W, None, _hip.GS_SORT_PREFIX)
+
+    def bwd(nsp, fw):
+        return fused.render_backward(f.packed, rgb_v, f.ranges, f.sorted_g, bg, nsp, fw, gi, H, W, None, V)
+
+    image, nsp, fw = fwd()
+    slab = bwd(nsp, fw)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        image, nsp, fw = fwd()
+        slab = bwd(nsp, fw)
+    torch.cuda.synchronize()
+    _hip.reserve_events(2 * 16 * args.reps)
+    _hip.enable_timing(True)
+    for _ in range(args.reps):
+        if args.full:
+            f2 = stage1()
+        image, nsp, fw = fwd()
+        slab = bwd(nsp, fw)
+        if args.full:
+            fused.preprocess_backward(g.xyz, g.quaternion, g.scale, T, cam.K, f, slab)
+    timing = _hip.collect_timing()
+    _hip.enable_timing(False)
+    out = {"lib": os.path.basename(_hip.LIB_PATH), "tag": args.tag, "workload": args.workload, "V": V, "S": f.S,
+           "median_ms": {k: round(statistics.median(v), 4) for k, v in sorted(timing.items())},
+           "min_ms": {k: round(min(v), 4) for k, v in sorted(timing.items())}}
+    if args.save:
+        torch.save({"image": image.cpu(), "slab": slab.cpu(), "nsp": nsp.cpu()}, args.save)
+    if args.check:
+        ref = torch.load(args.check)
+        out["image_equal"] = bool(torch.equal(image.cpu(), ref["image"]))
+        out["nsp_equal"] = bool(torch.equal(nsp.cpu(), ref["nsp"]))
+        a, b = slab.cpu().double(), ref["slab"].double()
+        out["slab_scaled_err_per_column"] = [float(((a[:, j] - b[:, j]).abs().max() / b[:, j].abs().max().clamp(min=1e-300)))
+                                             for j in range(a.shape[1])]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

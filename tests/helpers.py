@@ -67,14 +67,16 @@ def scaled_err(g, ref):
 
 
 def noise_normalised_err(g, ref, abs_sum):
-    """max over ALL elements (no floor) of |g - ref| / sum_pixels |term|.
+    """max over ALL elements (no floor) of |g - ref| / abs_sum.
 
-    `abs_sum` is the oracle's sum of the magnitudes of the per-pixel terms of each gradient element
-    (oracle.gs_oracle.render_tiles_backward_abs).  fp32 accumulation of n terms in any order deviates
-    from the exactly rounded sum (`ref`: the oracle accumulates in double and rounds once) by at most
-    ~n * 2^-24 * sum|term|, and the kernel's per-term values differ from the oracle's by a few ulp
-    (reciprocal instead of division, factored formulas), so a correct kernel stays within ~1e-5 of every
-    element's own scale -- including the small, cancelling elements that `rel_err`'s floor lets through."""
+    `abs_sum` is the oracle's sum, over the pixels that contribute to a gradient element, of the
+    magnitudes of the LEAF terms of its formula -- every product that enters a sum or a difference
+    (oracle.gs_oracle.render_tiles_backward_abs).  It is the scale of the unavoidable fp32 noise of that
+    element: a different but equally valid fp32 evaluation (other factoring, reciprocal instead of
+    division, another summation order -- the reference's own warp reduce + atomicAdd has that freedom)
+    deviates from the oracle's value by a few 2^-24 of it, whatever cancels afterwards.  A correct kernel
+    therefore stays within ~1e-5 of every element's own scale, including the small, cancelling elements
+    that `rel_err`'s floor lets through."""
     g = g.detach().double().cpu().reshape(-1)
     ref = ref.detach().double().cpu().reshape(-1)
     a = abs_sum.detach().double().cpu().reshape(-1)
