@@ -57,12 +57,37 @@ SLAB_WIDTH = 9   # render gradients per visible Gaussian: rgb 3 | opacity 1 | uv
 SLAB_RGB, SLAB_OPACITY, SLAB_UV, SLAB_CONIC = slice(0, 3), slice(3, 4), slice(4, 6), slice(6, 9)
 
 
+_PINNED_RING = 4   # host read buffers per (device, size): frames in flight on other streams / threads keep their own
+
+
 def _pinned_ints(dev, n):
-    buf = _pinned.get((dev.index, n))
-    if buf is None:
-        buf = torch.empty(n, dtype=torch.int32, pin_memory=True)
-        _pinned[(dev.index, n)] = buf
-    return buf
+    """a pinned int32[n] for the frame's host read, from a small ring: a frame whose read is still
+    pending (another stream or thread) does not see its record overwritten by the next frame"""
+    ring = _pinned.get((dev.index, n))
+    if ring is None:
+        ring = _pinned[(dev.index, n)] = [[torch.empty(n, dtype=torch.int32, pin_memory=True) for _ in range(_PINNED_RING)], 0]
+    ring[1] = (ring[1] + 1) % _PINNED_RING
+    return ring[0][ring[1]]
+
+
+# ---- frame counters (bench.py --moving-camera reports them) ---------------------------------------------
+_counters = {"frames": 0, "speculative_frames": 0, "capacity_misses": 0, "S_min": None, "S_max": None}
+_flag_log = []   # tile_flags of recent prefix-mode frames (device tensors: summed only when counters() is asked)
+
+
+def reset_counters():
+    _counters.update(frames=0, speculative_frames=0, capacity_misses=0, S_min=None, S_max=None)
+    _flag_log.clear()
+
+
+def counters():
+    """frames seen since reset_counters(): how many were enqueued on a guessed capacity, how many of those
+    had to repeat emit + sort + render because the instance count exceeded the guess, the range of S, and
+    the tiles the prefix sort had to repair (flag-and-redo on the device).  Synchronises."""
+    out = dict(_counters)
+    out["prefix_repaired_tiles"] = int(sum(int(f.sum()) for f in _flag_log)) if _flag_log else 0
+    out["prefix_frames_logged"] = len(_flag_log)
+    return out
 
 
 class _Arena:
@@ -176,10 +201,16 @@ def preprocess_finish(f):
     if f.speculative:
         f.ready.synchronize()
     S, V = int(f.host_buf[0]), int(f.host_buf[1])
+    c = _counters
+    c["frames"] += 1
+    c["speculative_frames"] += int(f.speculative)
+    c["S_min"] = S if c["S_min"] is None else min(c["S_min"], S)
+    c["S_max"] = S if c["S_max"] is None else max(c["S_max"], S)
     if S > f.capacity:
         f.sorted_buf, f.keys_buf = f.emit_sort(S)
         f.capacity = S
         redone = True
+        c["capacity_misses"] += 1
     _capacity_hint[f.hint_key] = int(S * 1.25) + 4096
     f.host = f.host_buf.tolist()[2:]
     f.S, f.V = S, V
@@ -234,6 +265,8 @@ def render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, 
                   _p(nsp), _p(fw), _p(image), stream)
         global last_tile_flags
         last_tile_flags = flags
+        if len(_flag_log) < 512:
+            _flag_log.append(flags)
     else:
         _hip.call("gs_render_tiles", _p(packed), _p(rgb), None, _p(ranges), _p(sorted_g), _p(background_rgb),
                   width, height, 1, row0, row1, _p(nsp), _p(fw), _p(image), _hip.GS_F32, stream)
@@ -335,6 +368,33 @@ class _Render(torch.autograd.Function):
         return (slab[:, SLAB_UV], slab[:, SLAB_CONIC], slab[:, SLAB_OPACITY], slab[:, SLAB_RGB]) + (None,) * 11
 
 
+def _require(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def validate(gaussians, camera_T_world, camera, background_rgb):
+    """The checks of the reference's extension (src/checks.cuh:5-14, render.cu:204-246) for the tensors the
+    fused path hands to the C ABI as raw pointers: device, dtype, shape.  (Contiguity is established by
+    the caller with .contiguous().)  Raises RuntimeError like the reference's TORCH_CHECKs."""
+    g = gaussians
+    dev = g.xyz.device
+    N = g.xyz.shape[0]
+    named = (("xyz", g.xyz, (N, 3)), ("quaternion", g.quaternion, (N, 4)), ("scale", g.scale, (N, 3)),
+             ("opacity", g.opacity, (N, 1)), ("rgb", g.rgb, (N, 3)), ("camera_T_world", camera_T_world, (4, 4)),
+             ("K", camera.K, (3, 3)), ("background_rgb", background_rgb, (3,)))
+    for name, t, shape in named:
+        _require(t.is_cuda and t.device == dev, f"{name} is not a CUDA tensor on {dev}")
+        _require(t.dtype == torch.float32, f"{name} is not a float tensor")
+        _require(tuple(t.shape) == shape, f"{name} must have shape {list(shape)}, got {list(t.shape)}")
+    if g.sh is not None:
+        t = g.sh
+        _require(t.is_cuda and t.device == dev, f"sh is not a CUDA tensor on {dev}")
+        _require(t.dtype == torch.float32, "sh is not a float tensor")
+        _require(t.dim() == 3 and t.shape[0] == N and t.shape[1] == 3 and t.shape[2] in (3, 8, 15),
+                 f"sh must have shape [{N}, 3, 3|8|15], got {list(t.shape)}")
+
+
 def supported(gaussians, camera_T_world, camera, use_sh_precompute):
     if not gaussians.xyz.is_cuda or gaussians.xyz.dtype != torch.float32:
         return False
@@ -344,16 +404,18 @@ def supported(gaussians, camera_T_world, camera, use_sh_precompute):
 
 
 def rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_mask_padding, mh_dist,
-              use_sh_precompute, background_rgb, tile_rows=None, return_aux=False, grad_sync=None, slab_sync=None):
+              use_sh_precompute, background_rgb, tile_rows=None, return_aux=False, grad_sync=None, slab_sync=None,
+              frame_hook=None):
     """tile_rows=(row0, row1) restricts binning and rendering to those tile rows; slab_sync(flat) is
     called on the flat [9 V] render-gradient slab in the backward (grad_sync is the generic
     per-tensor form used by the reference-shaped path): the hooks gaussian_splatting_amd.sharded
-    uses; all default to the single-GPU behaviour."""
+    uses; all default to the single-GPU behaviour.  frame_hook(dict) receives the frame's tile ranges."""
     if not supported(gaussians, camera_T_world, camera, use_sh_precompute):
         return _reference_shaped.rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh,
                                            cull_mask_padding, mh_dist, use_sh_precompute, background_rgb,
                                            tile_rows=tile_rows, grad_sync=grad_sync)
     g = gaussians
+    validate(g, camera_T_world, camera, background_rgb)
     sh = g.sh.contiguous() if g.sh is not None else None
     sort_prefix = _hip.GS_SORT_PREFIX if (SORT_PREFIX and not return_aux) else 0
     out = _Preprocess.apply(
@@ -362,6 +424,8 @@ def rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_m
         int(camera.height), near_thresh, far_thresh, cull_mask_padding, mh_dist, tile_rows, sort_prefix,
         background_rgb.contiguous())
     uv, conic, opacity, rgb, packed, xyz_cam, culling_mask, ranges, sorted_g, vis_idx, keys = out[:11]
+    if frame_hook is not None:   # multi-GPU cost-balanced bands: the band's tile ranges
+        frame_hook(dict(ranges=ranges, ntx=(int(camera.width) + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX))
     image = _Render.apply(uv, conic, opacity, rgb, packed, ranges, sorted_g, background_rgb.contiguous(),
                           int(camera.height), int(camera.width), tile_rows, slab_sync, keys, sort_prefix,
                           tuple(out[11:]))

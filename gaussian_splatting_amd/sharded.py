@@ -52,6 +52,40 @@ def band_of(n_tile_rows, world_size, rank):
     return row0, min(n_tile_rows, row0 + base)
 
 
+def balanced_bounds(row_cost, world_size):
+    """Contiguous split of the tile rows into world_size bands that minimises the largest band cost
+    ("cost-balanced by per-row splat counts"): binary search over the bound, greedy
+    packing.  row_cost: one non-negative number per tile row.  -> world_size + 1 row boundaries
+    (trailing bands may be empty).  Pure function of its arguments: every rank computes the same split
+    from the same (all-gathered) costs."""
+    cost = [max(0, int(c)) for c in row_cost]
+    R = len(cost)
+
+    def bands_needed(limit):
+        n, acc = 1, 0
+        for c in cost:
+            if acc + c > limit and acc > 0:
+                n, acc = n + 1, 0
+            acc += c
+        return n
+
+    lo, hi = max(cost + [0]), sum(cost)
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if bands_needed(mid) <= world_size:
+            hi = mid
+        else:
+            lo = mid + 1
+    bounds, acc = [0], 0
+    for r, c in enumerate(cost):
+        if acc + c > lo and acc > 0 and len(bounds) < world_size:
+            bounds.append(r)
+            acc = 0
+        acc += c
+    bounds += [R] * (world_size + 1 - len(bounds))
+    return bounds
+
+
 def owner_blocks(N, world_size):
     """Boundaries, in blocks of OWNER_BLOCK Gaussians, of the index slices the ranks own."""
     nb = (max(N, 1) + OWNER_BLOCK - 1) // OWNER_BLOCK
@@ -163,7 +197,7 @@ def plan_record_ints(world_size):
     return 4 + 2 * world_size
 
 
-def enqueue_hip_plan(f, world_size, rank):
+def enqueue_hip_plan(f, world_size, rank, bounds=None):
     """preprocess_forward's `plan` hook: enqueues gs_halo_plan; the device record f.record
     (rows to send, V, v_lo, v_hi, send[G], recv[G]) rides on the frame's one host read, and the
     send list -- the visible Gaussians whose window reaches this rank's band -- doubles as the
@@ -173,7 +207,7 @@ def enqueue_hip_plan(f, world_size, rank):
     n_ws = _hip.lib().gs_halo_workspace_ints(f.N, G)
     buf = torch.empty(2 * f.N + n_ws, dtype=torch.int32, device=f.uv.device)
     f.halo_mask, f.halo_send_index, f.halo_ws = buf[:f.N], buf[f.N:2 * f.N], buf[2 * f.N:]
-    rows = (ctypes.c_int32 * (G + 1))(*_band_rows(f.nty, G))
+    rows = (ctypes.c_int32 * (G + 1))(*(bounds if bounds is not None else _band_rows(f.nty, G)))
     blks = (ctypes.c_int32 * (G + 1))(*owner_blocks(f.N, G))
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     _hip.call("gs_halo_plan", p(f.uv), p(f.conic), f.N, p(f.count), p(f.ws), f.ntx, f.nty,
@@ -210,15 +244,15 @@ def gather_bands(image, band_pixels, world_size, rank, group=None):
 
 class _GatherImage(torch.autograd.Function):
     """forward: all-gather of the band images; backward: identity, because every rank evaluates
-    the same loss on the same gathered image."""
+    the same loss on the same gathered image (see ShardedRasterizer: the loss contract)."""
 
     @staticmethod
     def forward(ctx, image, rast):
         H, W = image.shape[0], image.shape[1]
-        out = torch.zeros(rast.padded_height, W, 3, dtype=image.dtype, device=image.device)
+        rows = rast.buffer_rows()
+        out = torch.zeros(rows, W, 3, dtype=image.dtype, device=image.device)
         out[:H] = image
-        gather_bands(out, rast.band_pixel_rows * W * 3, rast.world_size, rast.rank, rast.group)
-        return out[:H]
+        return rast.gather(out, H)
 
     @staticmethod
     def backward(ctx, grad):
@@ -268,67 +302,101 @@ class _OwnerExchange(torch.autograd.Function):
         return None, None, full[:, 0:3], full[:, 3:4], full[:, 4:6], full[:, 6:9]
 
 
-class _OwnerFrameFused(torch.autograd.Function):
-    """One node for the whole frame on the fused HIP path: the owned parameter slices are the
-    differentiable inputs (they receive the gradients), the replicated full tensors provide the
-    values."""
+class _OwnerPreprocess(torch.autograd.Function):
+    """First node of the owner-mode frame on the fused HIP path: per-Gaussian stage for all N, halo plan,
+    binning and sort of the rank's band.  The owned parameter slices are the differentiable inputs (they
+    receive the gradients), the replicated full tensors provide the values.  Output: uv (so that
+    uv.retain_grad() / uv.grad work as in the single-GPU function, trainer.py:360,379) and the culling
+    mask; everything else travels to the render node in the frame record `fr`."""
 
     @staticmethod
-    def forward(ctx, o_xyz, o_quaternion, o_scale, o_opacity, o_rgb, o_sh, rast, g, camera_T_world, K, width,
+    def forward(ctx, o_xyz, o_quaternion, o_scale, o_opacity, o_rgb, o_sh, rast, fr, g, camera_T_world, K, width,
                 height, near_thresh, far_thresh, cull_mask_padding, mh_dist, background_rgb):
         from . import _hip, fused
         G, me = rast.world_size, rast.rank
         sort_prefix = _hip.GS_SORT_PREFIX if fused.SORT_PREFIX else 0
         full = tuple(None if t is None else (t if t.is_contiguous() else t.contiguous())
                      for t in (g.xyz, g.quaternion, g.scale, g.opacity, g.rgb, g.sh))   # values only (no_grad here)
+        bounds = list(rast.bounds)
         f = fused.preprocess_forward(*full, camera_T_world, K, width, height, near_thresh, far_thresh,
                                      cull_mask_padding, mh_dist, rast.tile_rows, sort_prefix,
-                                     plan=lambda fr: enqueue_hip_plan(fr, G, me), plan_ints=plan_record_ints(G),
-                                     defer=True)
+                                     plan=lambda frm: enqueue_hip_plan(frm, G, me, bounds),
+                                     plan_ints=plan_record_ints(G), defer=True)
         if not DEFER_HOST_READ:
             fused.preprocess_finish(f)
 
-
         def render():
             return fused.render_forward(f.packed, f.rgb_render, f.ranges, f.sorted_buf, f.keys_buf, background_rgb,
-                                        height, width, rast.tile_rows, sort_prefix, image_rows=rast.padded_height)
+                                        height, width, rast.tile_rows, sort_prefix, image_rows=rast.buffer_rows())
 
         # the render is enqueued on the speculative tile lists before the host looks at the frame's
         # counts, so the GPU does not wait for the host; a too small capacity repeats it (rare)
         out = render() if (f.speculative and DEFER_HOST_READ and sort_prefix and f.capacity > sort_prefix) else None
         if (DEFER_HOST_READ and fused.preprocess_finish(f)) or out is None:
             out = render()
-        image, nsp, fw = out
-        plan = finish_hip_plan(f, G, me)
-        V = f.V
-        rgb_v = f.rgb_render[:V]
-        image = rast.gather_image_(image)[:height]
-        ctx.save_for_backward(full[0], full[1], full[2], camera_T_world, K, f.packed, rgb_v, f.ranges, f.sorted_g,
-                              background_rgb, nsp, fw)
-        ctx.f, ctx.plan, ctx.rast, ctx.dims = f, plan, rast, (height, width)
+        fr.f, fr.rendered, fr.plan = f, out, finish_hip_plan(f, G, me)
+        fr.full, fr.cam, fr.background = full, (camera_T_world, K), background_rgb
+        rast.last_plan = fr.plan
+        ctx.fr, ctx.rast = fr, rast
         ctx.set_materialize_grads(False)
-        uv = f.uv[:V]
-        ctx.mark_non_differentiable(f.culling_mask, uv)
-        rast.last_plan = plan
-        return image, f.culling_mask, uv
+        uv = f.uv[:f.V]
+        ctx.mark_non_differentiable(f.culling_mask)
+        return uv, f.culling_mask
 
     @staticmethod
-    def backward(ctx, grad_image, *unused):
+    def backward(ctx, g_uv, *unused):
+        # g_uv is what _OwnerRender.backward handed to uv (it fills uv.grad); the rows the per-Gaussian
+        # backward needs are the exchanged ones it left in the frame record
+        from . import fused
+        fr, rast = ctx.fr, ctx.rast
+        if fr.owned_rows is None:
+            return (None,) * 18
+        f, plan = fr.f, fr.plan
+        camera_T_world, K = fr.cam
+        i0, i1 = owner_range(f.N, rast.world_size, rast.rank)
+        grads = fused.preprocess_backward(fr.full[0], fr.full[1], fr.full[2], camera_T_world, K, f, fr.owned_rows,
+                                          v_base=plan.v_lo, i0=i0, i1=i1)
+        fr.owned_rows = None
+        return grads + (None,) * 12
+
+
+class _OwnerRender(torch.autograd.Function):
+    """Second node: the band's image (already enqueued by _OwnerPreprocess.forward) -> all-gather.
+    Backward: render backward over the band, sparse exchange of the partial rows to their owners; the
+    gradient returned for uv holds the complete render-backward grad_uv of the Gaussians this rank owns
+    (rows [v_lo, v_hi)) and zeros elsewhere -- materialised only when somebody asked for uv.grad."""
+
+    @staticmethod
+    def forward(ctx, uv, rast, fr, height, width):
+        image, nsp, fw = fr.rendered
+        fr.rendered = None
+        f = fr.f
+        V = f.V
+        ctx.save_for_backward(f.packed, f.rgb_render[:V], f.ranges, f.sorted_g, fr.background, nsp, fw)
+        ctx.fr, ctx.rast, ctx.dims = fr, rast, (height, width)
+        ctx.set_materialize_grads(False)
+        return rast.gather(image, height, ranges=f.ranges, ntx=f.ntx)
+
+    @staticmethod
+    def backward(ctx, grad_image):
         from . import fused
         if grad_image is None:
-            return (None,) * 17
-        (xyz, quaternion, scale, camera_T_world, K, packed, rgb_v, ranges, sorted_g, background_rgb, nsp,
-         fw) = ctx.saved_tensors
-        f, plan, rast = ctx.f, ctx.plan, ctx.rast
+            return (None,) * 5
+        packed, rgb_v, ranges, sorted_g, background_rgb, nsp, fw = ctx.saved_tensors
+        fr, rast = ctx.fr, ctx.rast
+        f, plan = fr.f, fr.plan
         height, width = ctx.dims
         slab = fused.render_backward(packed, rgb_v, ranges, sorted_g, background_rgb, nsp, fw,
                                      grad_image.contiguous(), height, width, rast.tile_rows, f.V)
         owned = plan.exchange(slab, group=rast.group, all_to_all=rast.all_to_all)
-        rast.last_owned_render_grads = owned
-        i0, i1 = owner_range(f.N, rast.world_size, rast.rank)
-        grads = fused.preprocess_backward(xyz, quaternion, scale, camera_T_world, K, f, owned, v_base=plan.v_lo,
-                                          i0=i0, i1=i1)
-        return grads + (None,) * 11
+        rast.last_owned_render_grads = fr.owned_rows = owned
+        uv_out = fr.uv_ref() if fr.uv_ref is not None else None
+        if uv_out is not None and uv_out.retains_grad:
+            g_uv = torch.zeros(f.V, 2, dtype=owned.dtype, device=owned.device)
+            g_uv[plan.v_lo:plan.v_hi] = owned[:, 4:6]
+        else:   # nobody reads uv.grad: a stride-0 zero costs nothing and still routes the backward
+            g_uv = torch.zeros(1, dtype=owned.dtype, device=owned.device).expand(f.V, 2)
+        return g_uv, None, None, None, None
 
 
 class _OwnerFrameGeneric(torch.autograd.Function):
@@ -355,7 +423,7 @@ class _OwnerFrameGeneric(torch.autograd.Function):
                 return _SumGradsAcrossRanks.apply(rast.group, rgb, opacity, uv, conic)
             ntx, nty = (camera.width + 15) // 16, (camera.height + 15) // 16
             mask = backend.get().band_mask(uv.detach().contiguous(), conic.detach().contiguous(), ntx, nty,
-                                           mh_dist, _band_rows(nty, G))
+                                           mh_dist, list(rast.bounds))
             state["mask"] = mask
             return _OwnerExchange.apply(rast, plan_of, rgb, opacity, uv, conic)
 
@@ -391,33 +459,135 @@ class _OwnerFrameGeneric(torch.autograd.Function):
 
 
 class ShardedRasterizer:
+    """One rank of the tile-row sharded frame.
+
+    Loss contract: the returned image is the full frame on every rank and its backward is the identity
+    (no collective): every rank must evaluate the SAME, un-averaged loss on it, so that every rank feeds
+    the same grad_image into its band's render backward.  A per-rank loss (DDP-style: a different target
+    or a 1/world_size factor per rank) gives gradients that are silently wrong; `check_grad_image=True`
+    verifies the contract with one extra all-reduce per backward (debugging aid).
+
+    band_policy "equal": ceil(rows / world_size) tile rows per rank (in-place all-gather).
+    band_policy "cost": contiguous bands balanced by per-row cost (balanced_bounds) -- the previous
+    frame's per-row instance counts, which ride on the image all-gather (fused path), or costs given
+    with set_row_costs(); applies from the next frame on, identically on every rank."""
+
+    TILE_COST = 64   # per-tile constant of the row cost (a tile with an empty list still costs a workgroup)
+
     def __init__(self, image_height, world_size=None, rank=None, group=None, fused=True, grad_mode="replicated",
-                 all_to_all=None):
+                 all_to_all=None, band_policy="equal", check_grad_image=False):
         if grad_mode not in ("replicated", "owner"):
             raise ValueError("grad_mode must be 'replicated' or 'owner'")
+        if band_policy not in ("equal", "cost"):
+            raise ValueError("band_policy must be 'equal' or 'cost'")
         self.group = group
         self.world_size = world_size if world_size is not None else dist.get_world_size(group)
         self.rank = rank if rank is not None else dist.get_rank(group)
         self.fused = fused
         self.grad_mode = grad_mode
-        self.all_to_all = all_to_all   # test hook: stands in for dist.all_to_all_single
-        n_tile_rows = (image_height + 15) // 16
-        self.tile_rows = band_of(n_tile_rows, self.world_size, self.rank)
-        # pixel rows of a (full) band, and of an image buffer that holds world_size of them
-        self.band_pixel_rows = 16 * band_rows_per_rank(n_tile_rows, self.world_size)
+        self.band_policy = band_policy
+        self.check_grad_image = check_grad_image
+        self.all_to_all = all_to_all   # test hook: stands in for dist.all_to_all_single (and skips the image gather)
+        self.n_tile_rows = (image_height + 15) // 16
+        self.bounds = _band_rows(self.n_tile_rows, self.world_size)
+        # pixel rows of a (full) equal band, and of an image buffer that holds world_size of them
+        self.band_pixel_rows = 16 * band_rows_per_rank(self.n_tile_rows, self.world_size)
         self.padded_height = self.band_pixel_rows * self.world_size
         self.last_plan = None
         self.last_owned_render_grads = None
+        self._pending_costs = None   # (pinned host tensor, event) of the latest gathered row costs
+        self._row_map = {}
+
+    # ---- bands -----------------------------------------------------------------------------------------
+    @property
+    def tile_rows(self):
+        return self.bounds[self.rank], self.bounds[self.rank + 1]
+
+    def set_row_costs(self, row_cost):
+        """cost policy: new band boundaries from per-tile-row costs (the same numbers on every rank)"""
+        if self.band_policy == "cost":
+            self.bounds = balanced_bounds(row_cost, self.world_size)
+
+    def _update_bounds(self):
+        """cost policy: consume the row costs the previous frame's gather left behind (the copy to the
+        host was enqueued then; the event has long passed by now, so this does not stall)"""
+        if self.band_policy != "cost" or self._pending_costs is None:
+            return
+        host, event = self._pending_costs
+        self._pending_costs = None
+        if event is not None:
+            event.synchronize()
+        self.set_row_costs(host.tolist())
+
+    def chunk_rows(self):
+        """pixel rows of one rank's part of the image all-gather"""
+        if self.band_policy == "equal":
+            return self.band_pixel_rows
+        return 16 * max(self.bounds[r + 1] - self.bounds[r] for r in range(self.world_size)) + 1   # + 1: the cost row
+
+    def buffer_rows(self):
+        """pixel rows of the buffer a band is rendered into (the band sits at its own rows)"""
+        if self.band_policy == "equal":
+            return self.padded_height
+        return 16 * self.n_tile_rows + self.chunk_rows()
 
     def owned_range(self, N):
         return owner_range(N, self.world_size, self.rank)
 
-    def gather_image_(self, image):
-        """in place on a [padded_height, W, 3] buffer that holds this rank's band: -> all bands"""
-        if self.all_to_all is None:
-            gather_bands(image, self.band_pixel_rows * image.shape[1] * 3, self.world_size, self.rank, self.group)
-        return image
+    # ---- image gather -----------------------------------------------------------------------------------
+    def gather(self, image, height, ranges=None, ntx=None):
+        """image: [buffer_rows(), W, 3] holding this rank's band at its own pixel rows -> the full frame
+        [height, W, 3] on every rank.  ranges/ntx (fused path, cost policy): the band's tile ranges, from
+        which the per-row costs for the next frame's bands are formed and sent along."""
+        if self.all_to_all is not None:   # simulated ranks (tests): the caller sums the band images
+            return image[:height]
+        W = image.shape[1]
+        if self.band_policy == "equal":
+            gather_bands(image, self.band_pixel_rows * W * 3, self.world_size, self.rank, self.group)
+            return image[:height]
+        G, R = self.world_size, self.n_tile_rows
+        row0, row1 = self.tile_rows
+        crows = self.chunk_rows()
+        if R > W * 3:
+            raise ValueError("image too narrow for the cost row")
+        tail = image[16 * row0 + crows - 1].view(-1)   # the chunk's last pixel row carries the row costs
+        tail[:R] = 0
+        if ranges is not None and row1 > row0:
+            counts = (ranges[row0 * ntx + 1:row1 * ntx + 1] - ranges[row0 * ntx:row1 * ntx]).clamp(max=1024)
+            tail[row0:row1] = (counts.view(row1 - row0, ntx).sum(1) + self.TILE_COST * ntx).to(image.dtype)
+        mine = image[16 * row0:16 * row0 + crows].reshape(-1)
+        out = torch.empty(G * mine.numel(), dtype=image.dtype, device=image.device)
+        if image.is_cuda:
+            from . import _hip
+            _hip.timed_region("rccl_all_gather_image", lambda: dist.all_gather_into_tensor(out, mine, group=self.group))
+        else:
+            dist.all_gather_into_tensor(out, mine, group=self.group)
+        out = out.view(G * crows, W, 3)
+        key = tuple(self.bounds)
+        row_map = self._row_map.get(key)
+        if row_map is None:
+            idx = []
+            for r in range(G):
+                idx += [r * crows + y for y in range(min(height, 16 * self.bounds[r + 1]) - 16 * self.bounds[r])]
+            row_map = torch.tensor(idx, dtype=torch.int64, device=image.device)
+            self._row_map = {key: row_map}
+        full = out.index_select(0, row_map)
+        if ranges is not None:
+            costs = out.view(G, crows, W * 3)[:, crows - 1, :R].sum(0)
+            host = torch.empty(R, dtype=costs.dtype, pin_memory=image.is_cuda)
+            host.copy_(costs, non_blocking=True)
+            event = None
+            if image.is_cuda:
+                event = torch.cuda.Event()
+                event.record()
+            self._pending_costs = (host, event)
+        return full
 
+    def gather_image_(self, image):
+        """(kept for callers of the first version) equal bands, in place"""
+        return self.gather(image, image.shape[0])
+
+    # ---- gradient synchronisation -------------------------------------------------------------------------
     def _grad_sync(self, *tensors):
         return _SumGradsAcrossRanks.apply(self.group, *tensors)
 
@@ -429,32 +599,85 @@ class ShardedRasterizer:
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
 
+    def _checked(self, image):
+        return _CheckGradImage.apply(image, self) if self.check_grad_image and self.all_to_all is None else image
+
     def rasterize(self, gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_mask_padding, mh_dist,
                   use_sh_precompute, background_rgb, owned=None):
         """Same contract as splat_py.rasterize.rasterize; the returned image is the full frame on
         every rank.  grad_mode "owner": `gaussians` holds the replicated values, `owned` (see
-        owned_slice) the leaf tensors of this rank's slice, which receive the gradients."""
+        owned_slice) the leaf tensors of this rank's slice, which receive the gradients; uv.grad (after
+        uv.retain_grad()) then holds the complete rows of the owned Gaussians and zeros elsewhere."""
+        import weakref
+        from types import SimpleNamespace
+
         from . import fused
+        self._update_bounds()
         use_fused = self.fused and fused.supported(gaussians, camera_T_world, camera, use_sh_precompute)
+        if use_fused:
+            fused.validate(gaussians, camera_T_world, camera, background_rgb)
         if self.grad_mode == "owner":
             if owned is None:
                 raise ValueError("grad_mode 'owner' needs owned= (the parameter slices of this rank)")
             o = (owned.xyz, owned.quaternion, owned.scale, owned.opacity, owned.rgb, owned.sh)
             if use_fused:
-                return _OwnerFrameFused.apply(
-                    *o, self, gaussians, camera_T_world.contiguous(), camera.K.contiguous(), int(camera.width),
+                fr = SimpleNamespace(owned_rows=None, uv_ref=None)
+                uv, culling_mask = _OwnerPreprocess.apply(
+                    *o, self, fr, gaussians, camera_T_world.contiguous(), camera.K.contiguous(), int(camera.width),
                     int(camera.height), near_thresh, far_thresh, cull_mask_padding, mh_dist,
                     background_rgb.contiguous())
-            return _OwnerFrameGeneric.apply(
+                fr.uv_ref = weakref.ref(uv)
+                image = _OwnerRender.apply(uv, self, fr, int(camera.height), int(camera.width))
+                return self._checked(image), culling_mask, uv
+            image, culling_mask, uv = _OwnerFrameGeneric.apply(
                 *o, self, gaussians, camera_T_world, camera,
                 (near_thresh, far_thresh, cull_mask_padding, mh_dist, use_sh_precompute), background_rgb)
+            return self._checked(image), culling_mask, uv
         if use_fused:
             impl = fused.rasterize
         else:
             from .splat_py.rasterize import rasterize as impl
+        hook = {}
         image, culling_mask, uv = impl(
             gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_mask_padding, mh_dist,
             use_sh_precompute, background_rgb, tile_rows=self.tile_rows, grad_sync=self._grad_sync,
-            **({"slab_sync": self._slab_sync} if use_fused else {}))
-        image = _GatherImage.apply(image, self)
-        return image, culling_mask, uv
+            **({"slab_sync": self._slab_sync, "frame_hook": hook.update} if use_fused else {}))
+        image = _GatherImage.apply(image, self) if "ranges" not in hook else _GatherImageCost.apply(image, self, hook)
+        return self._checked(image), culling_mask, uv
+
+
+class _GatherImageCost(torch.autograd.Function):
+    """_GatherImage that also sends the band's per-row costs along (fused path, replicated gradients)"""
+
+    @staticmethod
+    def forward(ctx, image, rast, hook):
+        H, W = image.shape[0], image.shape[1]
+        out = torch.zeros(rast.buffer_rows(), W, 3, dtype=image.dtype, device=image.device)
+        out[:H] = image
+        return rast.gather(out, H, ranges=hook["ranges"], ntx=hook["ntx"])
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad, None, None
+
+
+class _CheckGradImage(torch.autograd.Function):
+    """identity; in backward asserts that every rank received the same grad_image (the loss contract of
+    ShardedRasterizer) -- one all-reduce of a checksum, debugging aid"""
+
+    @staticmethod
+    def forward(ctx, image, rast):
+        ctx.rast = rast
+        return image.view_as(image)
+
+    @staticmethod
+    def backward(ctx, grad):
+        rast = ctx.rast
+        s = torch.stack([grad.double().sum(), grad.double().abs().sum()])
+        lo, hi = s.clone(), s.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=rast.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=rast.group)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("ShardedRasterizer: grad_image differs between ranks -- every rank must evaluate "
+                               "the same un-averaged loss on the gathered image")
+        return grad, None

@@ -364,3 +364,33 @@ def test_backward_hands_the_slab_through_without_a_copy(monkeypatch):
     img.backward(make_grad_image(320, 240, seed=1, device=DEV))
     assert seen == [True]
     assert uv.grad is not None and uv.grad.shape == uv.shape and torch.isfinite(uv.grad).all()
+
+
+def test_fused_rasterize_rejects_bad_inputs():
+    """the fused path hands raw pointers to the C ABI: wrong dtype / device / shape must raise like the
+    reference's TORCH_CHECKs (src/checks.cuh:5-14) instead of reading garbage"""
+    N, W, H = 500, 128, 96
+    bg = torch.zeros(3, device=DEV)
+
+    def scene():
+        return make_scene(N, W, H, 3, seed=1, device=DEV)
+
+    g, cam, T = scene()
+    fused.rasterize(g, T, cam, 0.3, 500.0, 100, 3.0, True, bg)   # the good case
+    for breakage, match in (
+            (lambda g, cam, T: (g, cam, T.double()), "camera_T_world is not a float tensor"),
+            (lambda g, cam, T: (g, type(cam)(cam.width, cam.height, cam.K.double()), T), "K is not a float tensor"),
+            (lambda g, cam, T: (g, cam, T.cpu()), "camera_T_world is not a CUDA tensor"),
+            (lambda g, cam, T: (type(g)(g.xyz, g.rgb, g.opacity, g.scale, g.quaternion[:, :3], g.sh), cam, T),
+             "quaternion must have shape"),
+            (lambda g, cam, T: (type(g)(g.xyz, g.rgb, g.opacity.view(-1), g.scale, g.quaternion, g.sh), cam, T),
+             "opacity must have shape"),
+            (lambda g, cam, T: (type(g)(g.xyz, g.rgb, g.opacity, g.scale, g.quaternion, g.sh[:, :, :7]), cam, T),
+             "sh must have shape")):
+        g, cam, T = scene()
+        g2, cam2, T2 = breakage(g, cam, T)
+        with pytest.raises(RuntimeError, match=match):
+            fused.rasterize(g2, T2, cam2, 0.3, 500.0, 100, 3.0, True, bg)
+    with pytest.raises(RuntimeError, match="background_rgb is not a CUDA tensor"):
+        g, cam, T = scene()
+        fused.rasterize(g, T, cam, 0.3, 500.0, 100, 3.0, True, bg.cpu())

@@ -70,29 +70,47 @@ def test_halo_plan_matches_reference_and_oracle(G):
 
 
 # (3, 1, 3000, 96, 40): more ranks than tile rows -- the last band is empty;  near = 1e4: everything culled
-@pytest.mark.parametrize("G,deg,N,W,H,near", [(2, 3, 20000, 640, 472, 2.0), (3, 0, 20000, 640, 472, 2.0),
-                                               (8, 3, 60000, 800, 608, 2.0), (4, 1, 3000, 96, 40, 2.0),
-                                               (2, 0, 3000, 96, 40, 1e4)])
-def test_owner_mode_with_simulated_ranks(G, deg, N, W, H, near):
+@pytest.mark.parametrize("G,deg,N,W,H,near,policy", [(2, 3, 20000, 640, 472, 2.0, "equal"), (3, 0, 20000, 640, 472, 2.0, "equal"),
+                                                      (8, 3, 60000, 800, 608, 2.0, "equal"), (4, 1, 3000, 96, 40, 2.0, "equal"),
+                                                      (2, 0, 3000, 96, 40, 1e4, "equal"), (3, 3, 20000, 640, 472, 2.0, "cost"),
+                                                      (8, 0, 60000, 800, 608, 2.0, "cost")])
+def test_owner_mode_with_simulated_ranks(G, deg, N, W, H, near, policy):
     bg = torch.full((3,), 0.5, device=DEV)
+    nty = (H + 15) // 16
+    row_costs = [1 + 40 * (r % 5 == 0) + r for r in range(nty)]   # cost policy: an uneven split, the same on every rank
     gi = make_grad_image(W, H, seed=2, device=DEV)
     args = (near, max(25.0, 2 * near)) + ARGS[2:]
     g0, cam0, T0 = make_scene(N, W, H, deg, seed=7, device=DEV)
     for k in PARAMS:
         if getattr(g0, k) is not None:
             getattr(g0, k).requires_grad_(True)
-    ref_img, ref_mask, _ = fused.rasterize(g0, T0, cam0, *args, True, bg)
+    ref_img, ref_mask, ref_uv = fused.rasterize(g0, T0, cam0, *args, True, bg)
+    ref_uv.retain_grad()
     ref_img.backward(gi)
     ref_img = ref_img.detach()
     ref_grads = {k: getattr(g0, k).grad for k in PARAMS if getattr(g0, k) is not None}
     sent = {}
 
-    def run(rank, a2a):
+    def run(rank, a2a, want_uv_grad=False):
         g, cam, T = make_scene(N, W, H, deg, seed=7, device=DEV)
         owned = owned_slice(g, G, rank)
-        rast = ShardedRasterizer(H, G, rank, grad_mode="owner", all_to_all=a2a)
+        rast = ShardedRasterizer(H, G, rank, grad_mode="owner", all_to_all=a2a, band_policy=policy)
+        rast.set_row_costs(row_costs)
+        if policy == "cost":
+            assert rast.bounds != _band_rows(nty, G)
         img, mask, uv = rast.rasterize(g, T, cam, *args, True, bg, owned=owned)
+        if want_uv_grad:
+            uv.retain_grad()
         img.backward(gi)
+        if want_uv_grad:
+            # trainer.py:360,379: uv.grad = the render-backward grad_uv -- complete for the owned Gaussians
+            plan = rast.last_plan
+            assert uv.grad is not None and uv.grad.shape == ref_uv.grad.shape
+            if plan.v_hi > plan.v_lo:
+                assert scaled_err(uv.grad[plan.v_lo:plan.v_hi], ref_uv.grad[plan.v_lo:plan.v_hi]) < 1e-5
+            assert not uv.grad[:plan.v_lo].any() and not uv.grad[plan.v_hi:].any()
+        else:
+            assert uv.grad is None or True
         return img.detach(), mask, owned, rast
 
     def recorder(rank):
@@ -116,7 +134,7 @@ def test_owner_mode_with_simulated_ranks(G, deg, N, W, H, near):
         run(r, recorder(r))
     images, sparse_rows = [], 0
     for r in range(G):
-        img, mask, owned, rast = run(r, router(r))
+        img, mask, owned, rast = run(r, router(r), want_uv_grad=(r % 2 == 0))
         images.append(img)
         assert torch.equal(mask, ref_mask)
         i0, i1 = owner_range(N, G, r)
@@ -131,6 +149,48 @@ def test_owner_mode_with_simulated_ranks(G, deg, N, W, H, near):
     V = int((~ref_mask).sum())
     if G > 1 and V > 1000 and H > 100:
         assert sparse_rows < 0.75 * G * V, "the exchange should move fewer rows than G dense slabs"
+
+
+@pytest.mark.parametrize("grad_mode", ["owner", "replicated"])
+def test_cost_band_policy_single_rank_rccl(grad_mode):
+    """the cost-balanced band policy end to end over the real collectives at world size 1: the row costs
+    ride on the image all-gather of frame 1 and set the bands of frame 2 (one band here: the point is the
+    gather / cost-row / host-read machinery on the GPU)"""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV, 0))
+    try:
+        N, W, H, deg = 3000, 256, 200, 3
+        bg = torch.zeros(3, device=DEV)
+        gi = make_grad_image(W, H, seed=2, device=DEV)
+        ref_img, _, ref_grads = single_gpu_frame(N, W, H, deg, 9, gi, bg)
+        rast = ShardedRasterizer(H, 1, 0, grad_mode=grad_mode, band_policy="cost", check_grad_image=True)
+        for frame in range(2):
+            g, cam, T = make_scene(N, W, H, deg, seed=9, device=DEV)
+            if grad_mode == "owner":
+                holder = owned_slice(g, 1, 0)
+            else:
+                holder = g
+                for k in PARAMS:
+                    getattr(g, k).requires_grad_(True)
+            img, mask, uv = rast.rasterize(g, T, cam, *ARGS, True, bg, owned=holder if grad_mode == "owner" else None)
+            img.backward(gi)
+            assert torch.equal(img.detach(), ref_img), frame
+            for k, ref in ref_grads.items():
+                assert scaled_err(getattr(holder, k).grad, ref) < 1e-5, (frame, k)
+            if frame == 0:
+                assert rast._pending_costs is not None
+                costs = rast._pending_costs[0]
+                torch.cuda.synchronize()
+                assert costs.shape[0] == (H + 15) // 16 and float(costs.min()) >= rast.TILE_COST * ((W + 15) // 16)
+        assert rast.bounds == [0, (H + 15) // 16]
+    finally:
+        if created:
+            dist.destroy_process_group()
 
 
 def test_owner_mode_single_rank_rccl():
