@@ -65,6 +65,9 @@ def check(status):
 # the kernels it enqueues.
 _timers = None
 _event_pool = []   # timing events are recycled: creating one costs ~5 us of host time per call
+# modules that time their own C-ABI calls the same way (the native frame orchestration,
+# csrc/frame_hip.cpp): enable_timing / reserve_events / collect_timing are forwarded to them
+timing_providers = []
 
 
 def _event():
@@ -79,11 +82,15 @@ def reserve_events(n):
 
     while len(_event_pool) < n:
         _event_pool.append(torch.cuda.Event(enable_timing=True))
+    for p in timing_providers:
+        p.reserve_events(n)
 
 
 def enable_timing(on=True):
     global _timers
     _timers = {} if on else None
+    for p in timing_providers:
+        p.enable_timing(bool(on))
 
 
 def collect_timing():
@@ -99,6 +106,9 @@ def collect_timing():
             _event_pool.append(b)
     if _timers is not None:
         _timers.clear()
+    for p in timing_providers:
+        for name, ms in p.collect_timing().items():
+            out.setdefault(name, []).extend(ms)
     return out
 
 

@@ -1,0 +1,505 @@
+// frame_hip.cpp -- native orchestration of one fused frame: the Python module `gsplat_frame`.
+//
+// gaussian_splatting_amd/fused.py in C++: the same two autograd nodes (per-Gaussian stage + binning +
+// sort | render), the same C-ABI calls in the same order on torch's current HIP stream, the same single
+// 8-byte host read per frame with the speculative emit / sort / render enqueued before it -- but the
+// frame costs one Python call and the backward runs inside the C++ autograd engine, so that a 0.5 ms
+// frame (workload B, or one band of a multi-GPU frame) is no longer bound by ~0.5 ms of interpreter
+// time.  Contract of rasterize(): splat_py.rasterize.rasterize (reference:
+// splat_py/rasterize.py:18-112) -> (image, culling_mask, uv); `uv` is an output of the first node and an
+// input of the second, so uv.retain_grad() / uv.grad work as the trainer expects (trainer.py:360,379).
+// fp32, SH-precompute colour mode (what fused.supported() accepts); everything else stays on the
+// reference-shaped path.
+#include <ATen/hip/HIPContext.h>
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
+#include <torch/extension.h>
+
+#include <map>
+#include <string>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "../../include/gsplat_hip.h"
+
+namespace {
+
+using torch::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+void ok(int status) { TORCH_CHECK(status == GS_OK, gs_last_error()); }
+void hip_ok(hipError_t e) { TORCH_CHECK(e == hipSuccess, "HIP: ", hipGetErrorString(e)); }
+void* cur_stream() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
+
+constexpr int SLAB_WIDTH = 9;   // rgb 3 | opacity 1 | uv 2 | conic 3
+
+// ---- per-process state: capacity guesses, pinned read buffers, counters ---------------------------------
+struct HintKey {
+    int dev, N, T, row0, row1;
+    bool operator<(const HintKey& o) const {
+        return std::tie(dev, N, T, row0, row1) < std::tie(o.dev, o.N, o.T, o.row0, o.row1);
+    }
+};
+std::mutex g_mutex;
+std::map<HintKey, int64_t> g_capacity;
+struct PinnedRing {
+    std::vector<Tensor> bufs;
+    std::vector<hipEvent_t> events;
+    size_t next = 0;
+};
+std::map<int, PinnedRing> g_pinned;   // per device
+struct Counters {
+    int64_t frames = 0, speculative = 0, misses = 0, s_min = -1, s_max = -1, slab_copies = 0;
+} g_counters;
+std::vector<Tensor> g_flag_log;
+Tensor g_last_flags;   // tile_flags of the latest prefix-mode render (tests / tools)
+bool g_sort_prefix = true, g_early_render = true;
+
+// optional per-entry-point timing (bench.py): events on the launch stream around every C-ABI call, so the
+// elapsed time of one entry point is the GPU time of the kernels it enqueues
+struct Timing {
+    bool on = false;
+    std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> spans;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        hip_ok(hipEventCreate(&e));
+        return e;
+    }
+} g_timing;
+
+template <typename F> void timed(const char* name, void* stream, F&& call) {
+    if (!g_timing.on) {
+        ok(call());
+        return;
+    }
+    hipEvent_t a, b;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        a = g_timing.get();
+        b = g_timing.get();
+    }
+    hip_ok(hipEventRecord(a, (hipStream_t)stream));
+    ok(call());
+    hip_ok(hipEventRecord(b, (hipStream_t)stream));
+    std::lock_guard<std::mutex> lock(g_mutex);
+    g_timing.spans[name].push_back({a, b});
+}
+
+std::pair<int32_t*, hipEvent_t> pinned_slot(int dev) {
+    PinnedRing& ring = g_pinned[dev];
+    if (ring.bufs.empty()) {
+        for (int i = 0; i < 4; i++) {
+            ring.bufs.push_back(torch::empty({4}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true)));
+            hipEvent_t ev;
+            hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            ring.events.push_back(ev);
+        }
+    }
+    ring.next = (ring.next + 1) % ring.bufs.size();
+    return {ring.bufs[ring.next].data_ptr<int32_t>(), ring.events[ring.next]};
+}
+
+// one allocation cut into 1-D blocks, each starting 16-byte aligned
+struct Arena {
+    Tensor buf;
+    std::vector<int64_t> offsets;
+    Arena(c10::ScalarType dtype, c10::Device dev, std::initializer_list<int64_t> sizes) {
+        int64_t off = 0;
+        for (int64_t n : sizes) {
+            offsets.push_back(off);
+            off += (n + 3) & ~int64_t(3);
+        }
+        buf = torch::empty({off}, torch::TensorOptions().dtype(dtype).device(dev));
+    }
+    template <typename T> T* ptr(size_t i) { return buf.data_ptr<T>() + offsets[i]; }
+    Tensor block(size_t i, int64_t n) { return buf.narrow(0, offsets[i], n); }
+};
+
+void require_f32_cuda(const Tensor& t, const char* name, c10::Device dev, std::initializer_list<int64_t> shape) {
+    TORCH_CHECK(t.is_cuda() && t.device() == dev, name, " is not a CUDA tensor on ", dev);
+    TORCH_CHECK(t.scalar_type() == torch::kFloat32, name, " is not a float tensor");
+    bool same = t.dim() == (int64_t)shape.size();
+    int64_t d = 0;
+    for (int64_t s : shape) same = same && t.size(d++) == s;
+    TORCH_CHECK(same, name, " has the wrong shape ", t.sizes());
+}
+
+struct RenderOut {
+    Tensor buf, image, fw, nsp;
+};
+
+RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* ranges, Tensor& sorted, Tensor& keys,
+                         const Tensor& bg, int W, int H, int row0, int row1, bool whole, int sort_prefix, void* stream) {
+    const int64_t P = (int64_t)W * H;
+    auto opt = torch::TensorOptions().dtype(torch::kFloat32).device(bg.device());
+    RenderOut r;
+    // one allocation: image [H,W,3] | final weight [H,W] | splat count [H,W] (int32 view).  Rows outside
+    // [row0, row1) are not written by the kernel: zero-fill only when restricted
+    r.buf = whole ? torch::empty({5 * P}, opt) : torch::zeros({5 * P}, opt);
+    r.image = r.buf.narrow(0, 0, 3 * P).view({H, W, 3});
+    r.fw = r.buf.narrow(0, 3 * P, P).view({H, W});
+    r.nsp = r.buf.narrow(0, 4 * P, P).view(torch::kInt32).view({H, W});
+    const int ntx = (W + 15) / 16, nty = (H + 15) / 16;
+    if (sort_prefix && sorted.size(0) > sort_prefix) {
+        Tensor flags = torch::empty({(int64_t)ntx * nty}, opt.dtype(torch::kInt32));
+        timed("gs_render_tiles_prefix", stream, [&] {
+            return gs_render_tiles_prefix(packed, rgbr, ranges, sorted.data_ptr<int32_t>(),
+                                          (const uint64_t*)keys.data_ptr<int64_t>(), sorted.size(0), bg.data_ptr(), W, H, row0,
+                                          row1, flags.data_ptr<int32_t>(), r.nsp.data_ptr<int32_t>(), r.fw.data_ptr(),
+                                          r.image.data_ptr(), stream);
+        });
+        std::lock_guard<std::mutex> lock(g_mutex);
+        if (g_flag_log.size() < 512) g_flag_log.push_back(flags);
+        g_last_flags = flags;
+    } else {
+        timed("gs_render_tiles", stream, [&] {
+            return gs_render_tiles(packed, rgbr, nullptr, ranges, sorted.data_ptr<int32_t>(), bg.data_ptr(), W, H, 1, row0, row1,
+                                   r.nsp.data_ptr<int32_t>(), r.fw.data_ptr(), r.image.data_ptr(), GS_F32, stream);
+        });
+    }
+    return r;
+}
+
+// ---- node 1: parameters -> uv, conic, opacity, colour (+ the frame's lists and, early, its image) --------
+struct Preprocess : public torch::autograd::Function<Preprocess> {
+    static variable_list forward(AutogradContext* ctx, Tensor xyz, Tensor quaternion, Tensor scale, Tensor opacity,
+                                 Tensor rgb, c10::optional<Tensor> sh_opt, Tensor camera_T_world, Tensor K, Tensor bg,
+                                 int64_t W, int64_t H, double near_thresh, double far_thresh, double padding,
+                                 double mh_dist, int64_t row0, int64_t row1) {
+        const auto dev = xyz.device();
+        const int N = (int)xyz.size(0);
+        const bool has_sh = sh_opt.has_value() && sh_opt->defined();
+        Tensor sh = has_sh ? sh_opt->contiguous() : Tensor();
+        const int n_sh = has_sh ? (int)sh.size(2) + 1 : 1;
+        const int ntx = ((int)W + 15) / 16, nty = ((int)H + 15) / 16, T = ntx * nty;
+        const bool whole = row0 == 0 && row1 == nty;
+        const int sort_prefix = g_sort_prefix ? GS_SORT_PREFIX : 0;
+        void* stream = cur_stream();
+
+        const int64_t n_ws = (int64_t)gs_preprocess_workspace_ints(N), n_tc = (int64_t)gs_tile_workspace_ints(T);
+        Arena iar(torch::kInt32, dev, {n_ws, 1, N, N, n_tc, T + 2, (N + 3) / 4});
+        Arena far(torch::kFloat32, dev, {3, 2 * (int64_t)N, 3 * (int64_t)N, 3 * (int64_t)N, N, 3 * (int64_t)N, 12 * (int64_t)N});
+        int32_t *ws = iar.ptr<int32_t>(0), *count = iar.ptr<int32_t>(1), *rank = iar.ptr<int32_t>(2),
+                *vis_idx = iar.ptr<int32_t>(3), *tile_counts = iar.ptr<int32_t>(4), *ranges_buf = iar.ptr<int32_t>(5);
+        uint8_t* mask = (uint8_t*)iar.ptr<int32_t>(6);
+        float *center = far.ptr<float>(0), *uv = far.ptr<float>(1), *xyz_cam = far.ptr<float>(2), *conic = far.ptr<float>(3),
+              *opa = far.ptr<float>(4), *rgbr = far.ptr<float>(5), *packed = far.ptr<float>(6);
+        timed("gs_preprocess_forward", stream, [&] {
+            return gs_preprocess_forward(xyz.data_ptr(), quaternion.data_ptr(), scale.data_ptr(), opacity.data_ptr(),
+                                         rgb.data_ptr(), has_sh ? sh.data_ptr() : nullptr, n_sh, camera_T_world.data_ptr(),
+                                         K.data_ptr(), N, (int)W, (int)H, (float)near_thresh, (float)far_thresh, (float)padding,
+                                         (float)mh_dist, (int)row0, (int)row1, ws, center, count, mask, rank, vis_idx, uv,
+                                         xyz_cam, conic, opa, rgbr, packed, stream);
+        });
+        timed("gs_tile_count", stream, [&] {
+            return gs_tile_count(uv, conic, N, count, nullptr, nullptr, ntx, nty, (float)mh_dist, (int)row0, (int)row1,
+                                 tile_counts, ranges_buf, stream);
+        });
+
+        auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(dev);
+        Tensor sorted, keys;
+        auto emit_sort = [&](int64_t capacity) {
+            sorted = torch::empty({capacity}, i32);
+            keys = torch::empty({capacity}, i32.dtype(torch::kInt64));
+            if (capacity > 0)
+                timed("gs_tile_emit_sort", stream, [&] {
+                    return gs_tile_emit_sort(uv, xyz_cam, conic, N, count, nullptr, nullptr, ntx, nty, (float)mh_dist, (int)row0,
+                                             (int)row1, ranges_buf, tile_counts, (uint64_t*)keys.data_ptr<int64_t>(), capacity,
+                                             sorted.data_ptr<int32_t>(), sort_prefix, stream);
+                });
+        };
+
+        // the frame's only device->host read: (S, V), to size the outputs.  With a capacity guessed from
+        // earlier frames of this shape, emit + sort + render are enqueued before the host waits.
+        const HintKey key{(int)dev.index(), N, T, (int)row0, (int)row1};
+        int64_t guess = -1;
+        int32_t* host;
+        hipEvent_t ready;
+        {
+            std::lock_guard<std::mutex> lock(g_mutex);
+            auto it = g_capacity.find(key);
+            if (it != g_capacity.end()) guess = it->second;
+            std::tie(host, ready) = pinned_slot((int)dev.index());
+        }
+        hip_ok(hipMemcpyAsync(host, ranges_buf + T, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        hip_ok(hipEventRecord(ready, (hipStream_t)stream));
+        const bool speculative = guess >= 0;
+        RenderOut out;
+        bool rendered = false;
+        int64_t capacity = 0;
+        if (speculative) {
+            capacity = guess;
+            emit_sort(capacity);
+            if (g_early_render && sort_prefix && capacity > sort_prefix) {
+                out = render_forward(packed, rgbr, ranges_buf, sorted, keys, bg, (int)W, (int)H, (int)row0, (int)row1, whole,
+                                     sort_prefix, stream);
+                rendered = true;
+            }
+        }
+        hip_ok(hipEventSynchronize(ready));
+        const int64_t S = host[0], V = host[1];
+        {
+            std::lock_guard<std::mutex> lock(g_mutex);
+            g_counters.frames++;
+            g_counters.speculative += speculative;
+            g_counters.s_min = g_counters.s_min < 0 ? S : std::min(g_counters.s_min, S);
+            g_counters.s_max = std::max(g_counters.s_max, S);
+            if (!speculative || S > capacity) g_counters.misses += speculative;
+            int64_t& hint = g_capacity[key];
+            hint = std::max(hint, S + S / 4 + 4096);
+        }
+        if (!speculative || S > capacity) {
+            emit_sort(S);
+            rendered = false;
+        }
+        Tensor sorted_g = sorted.narrow(0, 0, S), keys_g = keys.narrow(0, 0, S);
+        if (!rendered)
+            out = render_forward(packed, rgbr, ranges_buf, sorted_g, keys_g, bg, (int)W, (int)H, (int)row0, (int)row1, whole,
+                                 sort_prefix, stream);
+
+        Tensor uv_t = far.block(1, 2 * (int64_t)N).view({N, 2}).narrow(0, 0, V);
+        Tensor conic_t = far.block(3, 3 * (int64_t)N).view({N, 3}).narrow(0, 0, V);
+        Tensor opa_t = far.block(4, N).view({N, 1}).narrow(0, 0, V);
+        Tensor rgbr_t = far.block(5, 3 * (int64_t)N).view({N, 3}).narrow(0, 0, V);
+        Tensor packed_t = far.block(6, 12 * (int64_t)N).view({N, 12});
+        Tensor ranges_t = iar.block(5, T + 1);
+        Tensor mask_t = iar.block(6, (N + 3) / 4).view(torch::kBool).narrow(0, 0, N);
+        ctx->save_for_backward({xyz, quaternion, scale, camera_T_world, K, far.block(0, 3), iar.block(2, N),
+                                far.block(4, N).view({N, 1})});
+        ctx->saved_data["n_sh"] = (int64_t)n_sh;
+        ctx->saved_data["V"] = V;
+        ctx->set_materialize_grads(false);
+        ctx->mark_non_differentiable({packed_t, ranges_t, sorted_g, mask_t, out.image, out.fw, out.nsp});
+        return {uv_t, conic_t, opa_t, rgbr_t, packed_t, ranges_t, sorted_g, mask_t, out.image, out.fw, out.nsp};
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        auto saved = ctx->get_saved_variables();
+        const Tensor &xyz = saved[0], &quaternion = saved[1], &scale = saved[2], &camera_T_world = saved[3], &K = saved[4],
+                     &center = saved[5], &rank = saved[6], &opacity_act = saved[7];
+        const int n_sh = (int)ctx->saved_data["n_sh"].toInt();
+        const int64_t V = ctx->saved_data["V"].toInt();
+        const int N = (int)xyz.size(0);
+        const auto dev = xyz.device();
+        const Tensor &g_uv = g[0], &g_conic = g[1], &g_opa = g[2], &g_rgb = g[3];
+        // the four render gradients as one [V, 9] slab: the slab they are views of when they come straight
+        // from Render::backward, a packed copy otherwise (outputs nobody consumed count as 0)
+        Tensor slab;
+        {
+            auto is_col = [&](const Tensor& t, int64_t start, int64_t width, const Tensor& base) {
+                return t.defined() && t.dim() == 2 && t.size(0) == V && t.size(1) == width && t.stride(0) == SLAB_WIDTH &&
+                       t.stride(1) == 1 && t.is_alias_of(base) && t.storage_offset() == base.storage_offset() + start;
+            };
+            if (g_rgb.defined() && g_rgb._base().defined()) {
+                Tensor base(g_rgb._base());
+                if (base.dim() == 2 && base.size(1) == SLAB_WIDTH && base.is_contiguous() && is_col(g_rgb, 0, 3, base) &&
+                    is_col(g_opa, 3, 1, base) && is_col(g_uv, 4, 2, base) && is_col(g_conic, 6, 3, base))
+                    slab = base;
+            }
+            if (!slab.defined()) {
+                {
+                    std::lock_guard<std::mutex> lock(g_mutex);
+                    g_counters.slab_copies++;
+                }
+                slab = torch::zeros({std::max<int64_t>(V, 1), SLAB_WIDTH}, xyz.options());
+                if (g_rgb.defined()) slab.narrow(0, 0, V).narrow(1, 0, 3).copy_(g_rgb);
+                if (g_opa.defined()) slab.narrow(0, 0, V).narrow(1, 3, 1).copy_(g_opa);
+                if (g_uv.defined()) slab.narrow(0, 0, V).narrow(1, 4, 2).copy_(g_uv);
+                if (g_conic.defined()) slab.narrow(0, 0, V).narrow(1, 6, 3).copy_(g_conic);
+            }
+        }
+        const int64_t n = N, extra = 3 * (int64_t)(n_sh - 1);
+        Arena ga(torch::kFloat32, dev, {3 * n, 4 * n, 3 * n, n, 3 * n, extra * n});
+        if (n > 0) {
+            void* stream = cur_stream();
+            timed("gs_preprocess_backward", stream, [&] {
+                return gs_preprocess_backward(xyz.data_ptr(), quaternion.data_ptr(), scale.data_ptr(), n_sh,
+                                              camera_T_world.data_ptr(), K.data_ptr(), center.data_ptr(),
+                                              rank.data_ptr<int32_t>(), opacity_act.data_ptr(), slab.data_ptr(), 0, (int)n,
+                                              ga.ptr<float>(0), ga.ptr<float>(1), ga.ptr<float>(2), ga.ptr<float>(3),
+                                              ga.ptr<float>(4), n_sh > 1 ? ga.ptr<float>(5) : nullptr, stream);
+            });
+        }
+        variable_list out(17);
+        out[0] = ga.block(0, 3 * n).view({n, 3});
+        out[1] = ga.block(1, 4 * n).view({n, 4});
+        out[2] = ga.block(2, 3 * n).view({n, 3});
+        out[3] = ga.block(3, n).view({n, 1});
+        out[4] = ga.block(4, 3 * n).view({n, 3});
+        if (n_sh > 1) out[5] = ga.block(5, extra * n).view({n, 3, (int64_t)n_sh - 1});
+        return out;
+    }
+};
+
+// ---- node 2: the per-splat quantities + lists -> image (already enqueued by node 1) ------------------------
+struct Render : public torch::autograd::Function<Render> {
+    static Tensor forward(AutogradContext* ctx, Tensor uv, Tensor conic, Tensor opacity, Tensor rgbr, Tensor packed,
+                          Tensor ranges, Tensor sorted_g, Tensor bg, Tensor image, Tensor fw, Tensor nsp, int64_t row0,
+                          int64_t row1) {
+        ctx->save_for_backward({packed, rgbr, ranges, sorted_g, bg, nsp, fw});
+        ctx->saved_data["row0"] = row0;
+        ctx->saved_data["row1"] = row1;
+        ctx->saved_data["V"] = uv.size(0);
+        ctx->set_materialize_grads(false);
+        return image;
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        variable_list out(13);
+        if (!g[0].defined()) return out;
+        auto s = ctx->get_saved_variables();
+        const Tensor &packed = s[0], &rgbr = s[1], &ranges = s[2], &sorted_g = s[3], &bg = s[4], &nsp = s[5], &fw = s[6];
+        const int64_t V = ctx->saved_data["V"].toInt();
+        const int H = (int)nsp.size(0), W = (int)nsp.size(1);
+        Tensor grad_image = g[0].contiguous();
+        Tensor slab = torch::zeros({std::max<int64_t>(V, 1), SLAB_WIDTH}, packed.options());
+        void* stream = cur_stream();
+        const int row0 = (int)ctx->saved_data["row0"].toInt(), row1 = (int)ctx->saved_data["row1"].toInt();
+        timed("gs_render_tiles_backward_slab", stream, [&] {
+            return gs_render_tiles_backward_slab(packed.data_ptr(), rgbr.data_ptr(), ranges.data_ptr<int32_t>(),
+                                                 sorted_g.data_ptr<int32_t>(), bg.data_ptr(), nsp.data_ptr<int32_t>(),
+                                                 fw.data_ptr(), grad_image.data_ptr(), W, H, row0, row1, slab.data_ptr(), stream);
+        });
+        Tensor rows = slab.narrow(0, 0, V);
+        out[0] = rows.narrow(1, 4, 2);   // uv
+        out[1] = rows.narrow(1, 6, 3);   // conic
+        out[2] = rows.narrow(1, 3, 1);   // opacity
+        out[3] = rows.narrow(1, 0, 3);   // colour
+        return out;
+    }
+};
+
+std::tuple<Tensor, Tensor, Tensor> rasterize(Tensor xyz, Tensor quaternion, Tensor scale, Tensor opacity, Tensor rgb,
+                                             c10::optional<Tensor> sh, Tensor camera_T_world, Tensor K, int64_t width,
+                                             int64_t height, double near_thresh, double far_thresh, double cull_mask_padding,
+                                             double mh_dist, Tensor background_rgb, int64_t row0, int64_t row1) {
+    const auto dev = xyz.device();
+    const int64_t N = xyz.size(0);
+    TORCH_CHECK(xyz.is_cuda(), "xyz is not a CUDA tensor");
+    require_f32_cuda(xyz, "xyz", dev, {N, 3});
+    require_f32_cuda(quaternion, "quaternion", dev, {N, 4});
+    require_f32_cuda(scale, "scale", dev, {N, 3});
+    require_f32_cuda(opacity, "opacity", dev, {N, 1});
+    require_f32_cuda(rgb, "rgb", dev, {N, 3});
+    require_f32_cuda(camera_T_world, "camera_T_world", dev, {4, 4});
+    require_f32_cuda(K, "K", dev, {3, 3});
+    require_f32_cuda(background_rgb, "background_rgb", dev, {3});
+    if (sh.has_value() && sh->defined()) {
+        TORCH_CHECK(sh->is_cuda() && sh->device() == dev, "sh is not a CUDA tensor on ", dev);
+        TORCH_CHECK(sh->scalar_type() == torch::kFloat32, "sh is not a float tensor");
+        TORCH_CHECK(sh->dim() == 3 && sh->size(0) == N && sh->size(1) == 3 &&
+                        (sh->size(2) == 3 || sh->size(2) == 8 || sh->size(2) == 15),
+                    "sh has the wrong shape ", sh->sizes());
+    }
+    TORCH_CHECK(width > 0 && height > 0, "image must be non-empty");
+    const int64_t nty = (height + 15) / 16;
+    if (row1 < 0) row1 = nty;
+    TORCH_CHECK(0 <= row0 && row0 <= row1 && row1 <= nty, "bad tile row range");
+    c10::DeviceGuard guard(dev);
+    auto o = Preprocess::apply(xyz.contiguous(), quaternion.contiguous(), scale.contiguous(), opacity.contiguous(),
+                               rgb.contiguous(), sh, camera_T_world.contiguous(), K.contiguous(), background_rgb.contiguous(),
+                               width, height, near_thresh, far_thresh, cull_mask_padding, mh_dist, row0, row1);
+    Tensor image = Render::apply(o[0], o[1], o[2], o[3], o[4], o[5], o[6], background_rgb.contiguous(), o[8], o[9], o[10],
+                                 row0, row1);
+    return std::make_tuple(image, o[7], o[0]);
+}
+
+py::dict counters() {
+    std::vector<Tensor> log;
+    Counters c;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        log = g_flag_log;
+        c = g_counters;
+    }
+    int64_t repaired = 0;
+    for (const Tensor& f : log) repaired += f.sum().item<int64_t>();
+    py::dict d;
+    d["frames"] = c.frames;
+    d["speculative_frames"] = c.speculative;
+    d["capacity_misses"] = c.misses;
+    d["S_min"] = c.s_min < 0 ? py::object(py::none()) : py::object(py::int_(c.s_min));
+    d["S_max"] = c.s_max < 0 ? py::object(py::none()) : py::object(py::int_(c.s_max));
+    d["slab_copies"] = c.slab_copies;   // backward calls that could not read the render node's slab in place
+    d["prefix_repaired_tiles"] = repaired;
+    d["prefix_frames_logged"] = (int64_t)log.size();
+    return d;
+}
+
+void reset_counters() {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    g_counters = Counters();
+    g_flag_log.clear();
+}
+
+c10::optional<Tensor> last_tile_flags(bool clear) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    c10::optional<Tensor> out;
+    if (g_last_flags.defined()) out = g_last_flags;
+    if (clear) g_last_flags = Tensor();
+    return out;
+}
+
+void enable_timing(bool on) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    g_timing.on = on;
+}
+
+void reserve_events(int64_t n) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    while ((int64_t)g_timing.pool.size() < n) {
+        hipEvent_t e;
+        hip_ok(hipEventCreate(&e));
+        g_timing.pool.push_back(e);
+    }
+}
+
+py::dict collect_timing() {
+    hip_ok(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lock(g_mutex);
+    py::dict d;
+    for (auto& kv : g_timing.spans) {
+        py::list ms;
+        for (auto& ab : kv.second) {
+            float t = 0;
+            hip_ok(hipEventElapsedTime(&t, ab.first, ab.second));
+            ms.append(t);
+            g_timing.pool.push_back(ab.first);
+            g_timing.pool.push_back(ab.second);
+        }
+        d[py::str(kv.first)] = ms;
+    }
+    g_timing.spans.clear();
+    return d;
+}
+
+void set_modes(bool sort_prefix, bool early_render) {
+    g_sort_prefix = sort_prefix;
+    g_early_render = early_render;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.doc() = "native orchestration of the fused MI355X rasterization frame (see gaussian_splatting_amd/fused.py)";
+    m.def("rasterize", &rasterize, "fused frame: -> (image, culling_mask, uv)", py::arg("xyz"), py::arg("quaternion"),
+          py::arg("scale"), py::arg("opacity"), py::arg("rgb"), py::arg("sh"), py::arg("camera_T_world"), py::arg("K"),
+          py::arg("width"), py::arg("height"), py::arg("near_thresh"), py::arg("far_thresh"), py::arg("cull_mask_padding"),
+          py::arg("mh_dist"), py::arg("background_rgb"), py::arg("row0") = 0, py::arg("row1") = -1);
+    m.def("counters", &counters);
+    m.def("reset_counters", &reset_counters);
+    m.def("set_modes", &set_modes, py::arg("sort_prefix"), py::arg("early_render"));
+    m.def("last_tile_flags", &last_tile_flags, py::arg("clear") = false);
+    m.def("enable_timing", &enable_timing);
+    m.def("reserve_events", &reserve_events);
+    m.def("collect_timing", &collect_timing);
+}

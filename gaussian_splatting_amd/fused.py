@@ -48,7 +48,46 @@ SORT_PREFIX = True
 # Enqueue the render on the speculative tile lists before waiting for the frame's host read.
 EARLY_RENDER = True
 
-last_tile_flags = None   # int32[T] of the latest prefix-mode frame: 1 = the tile was repaired (for tests/tools)
+last_tile_flags = None   # int32[T] of the latest prefix-mode frame of the Python path (see last_flags())
+# Frames without hooks go through the native orchestration (csrc/frame_hip.cpp: the same C-ABI calls and
+# autograd structure in C++, one Python call per frame).  False = always the Python orchestration below.
+NATIVE = True
+_native_mod = None
+_native_failed = False
+
+
+def native():
+    """the gsplat_frame module, or None when NATIVE is off / it is not built (the Python orchestration of
+    the same HIP kernels is then used; this is a host-side speed-up, not a compute fallback)"""
+    global _native_mod, _native_failed
+    if not NATIVE or _native_failed:
+        return None
+    if _native_mod is None:
+        try:
+            from . import splat_cuda_native
+            _native_mod = splat_cuda_native.load_frame()
+            _hip.timing_providers.append(_native_mod)
+        except ImportError as e:
+            import warnings
+            _native_failed = True
+            warnings.warn(f"native frame orchestration unavailable ({e}); using the Python orchestration")
+            return None
+    return _native_mod
+
+
+def last_flags(clear=False):
+    """tile_flags (int32[T]; 1 = the prefix sort ran out and the tile was repaired) of the latest
+    prefix-mode frame, whichever orchestration ran it; None if there was none since the last clear"""
+    global last_tile_flags
+    out = last_tile_flags
+    m = _native_mod
+    if m is not None:
+        nat = m.last_tile_flags(clear)
+        out = nat if nat is not None else out
+    if clear:
+        last_tile_flags = None
+    return out
+
 
 _capacity_hint = {}   # (device, N, tiles, band) -> instance capacity guessed from the previous frame
 _pinned = {}
@@ -78,6 +117,8 @@ _flag_log = []   # tile_flags of recent prefix-mode frames (device tensors: summ
 def reset_counters():
     _counters.update(frames=0, speculative_frames=0, capacity_misses=0, S_min=None, S_max=None)
     _flag_log.clear()
+    if _native_mod is not None:
+        _native_mod.reset_counters()
 
 
 def counters():
@@ -87,6 +128,16 @@ def counters():
     out = dict(_counters)
     out["prefix_repaired_tiles"] = int(sum(int(f.sum()) for f in _flag_log)) if _flag_log else 0
     out["prefix_frames_logged"] = len(_flag_log)
+    out["orchestration"] = "python"
+    if _native_mod is not None:
+        nat = _native_mod.counters()
+        if nat["frames"]:
+            for k in ("frames", "speculative_frames", "capacity_misses", "prefix_repaired_tiles", "prefix_frames_logged"):
+                out[k] += nat[k]
+            lo = [x for x in (out["S_min"], nat["S_min"]) if x is not None]
+            hi = [x for x in (out["S_max"], nat["S_max"]) if x is not None]
+            out["S_min"], out["S_max"] = (min(lo) if lo else None), (max(hi) if hi else None)
+            out["orchestration"] = "native (csrc/frame_hip.cpp)" if nat["frames"] == out["frames"] else "mixed"
     return out
 
 
@@ -211,7 +262,10 @@ def preprocess_finish(f):
         f.capacity = S
         redone = True
         c["capacity_misses"] += 1
-    _capacity_hint[f.hint_key] = int(S * 1.25) + 4096
+    # the capacity only sizes two buffers (12 B per instance; the kernels write S entries whatever it is), so
+    # the guess is the largest count seen for this frame shape plus a margin: views of a training run
+    # differ by tens of percent in S, and a miss costs a repeated emit + sort + render
+    _capacity_hint[f.hint_key] = max(_capacity_hint.get(f.hint_key, 0), int(S * 1.25) + 4096)
     f.host = f.host_buf.tolist()[2:]
     f.S, f.V = S, V
     f.sorted_g = f.sorted_buf[:S]
@@ -416,6 +470,13 @@ def rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_m
                                            tile_rows=tile_rows, grad_sync=grad_sync)
     g = gaussians
     validate(g, camera_T_world, camera, background_rgb)
+    nat = native() if not (return_aux or grad_sync or slab_sync or frame_hook) else None
+    if nat is not None:
+        nat.set_modes(bool(SORT_PREFIX), bool(EARLY_RENDER))
+        row0, row1 = tile_rows if tile_rows is not None else (0, -1)
+        return nat.rasterize(g.xyz, g.quaternion, g.scale, g.opacity, g.rgb, g.sh, camera_T_world, camera.K,
+                             int(camera.width), int(camera.height), near_thresh, far_thresh, cull_mask_padding, mh_dist,
+                             background_rgb, row0, row1)
     sh = g.sh.contiguous() if g.sh is not None else None
     sort_prefix = _hip.GS_SORT_PREFIX if (SORT_PREFIX and not return_aux) else 0
     out = _Preprocess.apply(

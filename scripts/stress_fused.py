@@ -38,9 +38,9 @@ for it in range(a.n):
                 getattr(g, k).requires_grad_(True)
         bg = torch.full((3,), bgv, device="cuda")
         if mode == "prefix":
-            fused.last_tile_flags = None
+            fused.last_flags(clear=True)
             img, mask, uv = fused.rasterize(g, T, cam, near, far, pad, 3.0, True, bg)
-            flags = fused.last_tile_flags
+            flags = fused.last_flags()
         else:
             img, mask, uv, aux = fused.rasterize(g, T, cam, near, far, pad, 3.0, True, bg, return_aux=True)
             counts = aux["tile_ranges"][1:] - aux["tile_ranges"][:-1]

@@ -48,15 +48,18 @@ def oracle_backend():
     backend.use(prev)
 
 
-@pytest.fixture
-def hip_backend():
+@pytest.fixture(params=["shim", "native"])
+def hip_backend(request):
+    """the two providers of the reference's `splat_cuda` functions on the GPU: the ctypes shim
+    (gaussian_splatting_amd.splat_cuda) and the compiled pybind11 module (csrc/bindings_hip.cpp)"""
     import torch
 
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    from gaussian_splatting_amd import backend, splat_cuda
+    from gaussian_splatting_amd import backend, splat_cuda, splat_cuda_native
 
     prev = backend._backend
-    backend.use(splat_cuda)
-    yield splat_cuda
+    mod = splat_cuda if request.param == "shim" else splat_cuda_native.load()
+    backend.use(mod)
+    yield mod
     backend.use(prev)

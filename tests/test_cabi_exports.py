@@ -39,3 +39,25 @@ def test_library_exports_every_declared_symbol():
 
 def test_python_loader_lists_the_same_symbols():
     assert sorted(_hip.EXPORTS) == declared_symbols()
+
+
+def test_native_splat_cuda_module_exports_the_reference_names():
+    """csrc/bindings_hip.cpp: the compiled `splat_cuda` module has the 14 functions of
+    src/bindings.cpp:118-159 and raises RuntimeError (TORCH_CHECK) for a non-device tensor"""
+    import pytest
+    import torch
+
+    from gaussian_splatting_amd import splat_cuda, splat_cuda_native
+    mod = splat_cuda_native.load()
+    names = ["render_tiles_cuda", "render_tiles_backward_cuda", "camera_projection_cuda",
+             "camera_projection_backward_cuda", "compute_sigma_world_cuda", "compute_sigma_world_backward_cuda",
+             "compute_projection_jacobian_cuda", "compute_projection_jacobian_backward_cuda", "compute_conic_cuda",
+             "compute_conic_backward_cuda", "get_sorted_gaussian_list", "precompute_rgb_from_sh_cuda",
+             "precompute_rgb_from_sh_backward_cuda", "render_depth_cuda"]
+    for n in names:
+        assert callable(getattr(mod, n)) and callable(getattr(splat_cuda, n)), n
+    with pytest.raises(RuntimeError, match="xyz is not a CUDA tensor"):
+        mod.camera_projection_cuda(torch.zeros(3, 3), torch.zeros(3, 3), torch.zeros(3, 2))
+    splat_cuda_native.install("splat_cuda_test_alias")
+    import sys
+    assert sys.modules.pop("splat_cuda_test_alias") is mod

@@ -356,6 +356,7 @@ def test_backward_hands_the_slab_through_without_a_copy(monkeypatch):
         return out
 
     monkeypatch.setattr(fused, "_as_slab", spy)
+    monkeypatch.setattr(fused, "NATIVE", False)   # the Python orchestration; the native one is checked below
     g, cam, T = make_scene(5000, 320, 240, 3, seed=5, device=DEV)
     for k in PARAMS:
         getattr(g, k).requires_grad_(True)
@@ -364,6 +365,51 @@ def test_backward_hands_the_slab_through_without_a_copy(monkeypatch):
     img.backward(make_grad_image(320, 240, seed=1, device=DEV))
     assert seen == [True]
     assert uv.grad is not None and uv.grad.shape == uv.shape and torch.isfinite(uv.grad).all()
+    py_uv_grad = uv.grad.clone()
+    # the native orchestration (csrc/frame_hip.cpp): same structure, counted by the module itself
+    monkeypatch.setattr(fused, "NATIVE", True)
+    nat = fused.native()
+    assert nat is not None, "native frame module not built"
+    nat.reset_counters()
+    g, cam, T = make_scene(5000, 320, 240, 3, seed=5, device=DEV)
+    for k in PARAMS:
+        getattr(g, k).requires_grad_(True)
+    img, _, uv = fused.rasterize(g, T, cam, 0.3, 500.0, 100, 3.0, True, torch.zeros(3, device=DEV))
+    uv.retain_grad()
+    img.backward(make_grad_image(320, 240, seed=1, device=DEV))
+    c = nat.counters()
+    assert c["frames"] == 1 and c["slab_copies"] == 0
+    assert uv.grad is not None and scaled_err(uv.grad, py_uv_grad) < 1e-5
+
+
+@pytest.mark.parametrize("deg,bgval", [(0, 0.0), (3, 0.5)])
+def test_native_orchestration_equals_python_orchestration(deg, bgval):
+    """csrc/frame_hip.cpp against fused.py's own stages: same kernels in the same order -> image and
+    culling mask bit-identical, gradients equal up to the atomics' order; also on a tile-row band"""
+    N, W, H = 20000, 640, 472
+    bg = torch.full((3,), bgval, device=DEV)
+    gi = make_grad_image(W, H, seed=4, device=DEV)
+    for rows in (None, (5, 19)):
+        outs = []
+        for native in (False, True):
+            fused.NATIVE = native
+            try:
+                g, cam, T = make_scene(N, W, H, deg, seed=2, device=DEV)
+                for k in PARAMS:
+                    if getattr(g, k) is not None:
+                        getattr(g, k).requires_grad_(True)
+                img, mask, uv = fused.rasterize(g, T, cam, 0.3, 500.0, 100, 3.0, True, bg, tile_rows=rows)
+                uv.retain_grad()
+                img.backward(gi)
+            finally:
+                fused.NATIVE = True
+            outs.append((img.detach(), mask, uv.detach(), uv.grad, {k: getattr(g, k).grad for k in PARAMS
+                                                                      if getattr(g, k) is not None}))
+        (i0, m0, u0, gu0, p0), (i1, m1, u1, gu1, p1) = outs
+        assert torch.equal(i0, i1) and torch.equal(m0, m1) and torch.equal(u0, u1)
+        assert scaled_err(gu1, gu0) < 1e-5
+        for k in p0:
+            assert scaled_err(p1[k], p0[k]) < 1e-5, k
 
 
 def test_fused_rasterize_rejects_bad_inputs():
@@ -377,16 +423,19 @@ def test_fused_rasterize_rejects_bad_inputs():
 
     g, cam, T = scene()
     fused.rasterize(g, T, cam, 0.3, 500.0, 100, 3.0, True, bg)   # the good case
+    def set_attr(obj, name, value):
+        setattr(obj, name, value)   # (the Gaussians constructor asserts shapes itself: break the tensor afterwards)
+        return obj
+
     for breakage, match in (
             (lambda g, cam, T: (g, cam, T.double()), "camera_T_world is not a float tensor"),
             (lambda g, cam, T: (g, type(cam)(cam.width, cam.height, cam.K.double()), T), "K is not a float tensor"),
             (lambda g, cam, T: (g, cam, T.cpu()), "camera_T_world is not a CUDA tensor"),
-            (lambda g, cam, T: (type(g)(g.xyz, g.rgb, g.opacity, g.scale, g.quaternion[:, :3], g.sh), cam, T),
+            (lambda g, cam, T: (set_attr(g, "quaternion", g.quaternion[:, :3].contiguous()), cam, T),
              "quaternion must have shape"),
-            (lambda g, cam, T: (type(g)(g.xyz, g.rgb, g.opacity.view(-1), g.scale, g.quaternion, g.sh), cam, T),
-             "opacity must have shape"),
-            (lambda g, cam, T: (type(g)(g.xyz, g.rgb, g.opacity, g.scale, g.quaternion, g.sh[:, :, :7]), cam, T),
-             "sh must have shape")):
+            (lambda g, cam, T: (set_attr(g, "opacity", g.opacity.view(-1)), cam, T), "opacity must have shape"),
+            (lambda g, cam, T: (set_attr(g, "scale", g.scale.double()), cam, T), "scale is not a float tensor"),
+            (lambda g, cam, T: (set_attr(g, "sh", g.sh[:, :, :7].contiguous()), cam, T), "sh must have shape")):
         g, cam, T = scene()
         g2, cam2, T2 = breakage(g, cam, T)
         with pytest.raises(RuntimeError, match=match):

@@ -199,7 +199,14 @@ def test_tile_lists_oversize_tile_falls_back_to_global_sort(hip_backend):
     assert torch.equal(got[1].cpu(), ref[1]) and torch.equal(got[0].cpu(), ref[0])
 
 
+def _needs_tile_rows_extension(mod):
+    if mod.__file__.endswith(".so"):
+        pytest.skip("tile_rows= is an extension of the ctypes shim (multi-GPU hooks), not part of the "
+                    "reference's signatures the native module mirrors")
+
+
 def test_tile_lists_empty_and_row_restricted(hip_backend):
+    _needs_tile_rows_extension(hip_backend)
     orc = oracle()
     e = torch.zeros(0, 2, device=DEV), torch.zeros(0, 3, device=DEV), torch.zeros(0, 3, device=DEV)
     s, r = hip_backend.get_sorted_gaussian_list(1024, e[0], e[1], e[2], 4, 3, 3.0)
@@ -301,6 +308,7 @@ def test_render_fp64_parity(hip_backend, n_sh):
 
 
 def test_render_tile_row_restriction(hip_backend):
+    _needs_tile_rows_extension(hip_backend)
     orc = oracle()
     W, H = 320, 240
     d = cpu_stage_inputs(8000, W, H, 0, 50)

@@ -319,10 +319,10 @@ def test_prefix_sort_mode_is_exact_on_config_D():
     """dense scene: every tile saturates inside its 1024-entry prefix; image identical, gradients
     equal up to summation order"""
     N, W, H, deg = WORKLOADS["D"]
-    fused.last_tile_flags = None
+    fused.last_flags(clear=True)
     out = run_both_sort_modes(lambda: make_scene(N, W, H, deg, seed=0, device=DEV) + (DEFAULTS,),
                               make_grad_image(W, H, seed=1, device=DEV))
-    assert fused.last_tile_flags is not None and int(fused.last_tile_flags.sum()) == 0
+    assert fused.last_flags() is not None and int(fused.last_flags().sum()) == 0
     assert torch.equal(out[True][0], out[False][0])
     for k in out[False][1]:
         assert scaled_err(out[True][1][k], out[False][1][k]) < 1e-5, k
@@ -338,9 +338,9 @@ def test_prefix_sort_mode_repairs_tiles_that_need_more():
         g.opacity.fill_(-5.0)
         return g, cam, T, DEFAULTS
 
-    fused.last_tile_flags = None
+    fused.last_flags(clear=True)
     out = run_both_sort_modes(make, make_grad_image(W, H, seed=2, device=DEV))
-    flags = fused.last_tile_flags
+    flags = fused.last_flags()
     assert flags is not None and 0 < int(flags.sum())
     g, cam, T, kw = make()
     _, _, _, aux = fused.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=torch.zeros(3, device=DEV),
