@@ -29,6 +29,7 @@ EXPORTS = [
     "gs_pack_splats", "gs_render_tiles", "gs_render_tiles_prefix", "gs_render_tiles_backward", "gs_render_tiles_backward_slab",
     "gs_render_depth", "gs_halo_workspace_ints", "gs_halo_plan", "gs_halo_gather_sum",
     "gs_adam_step", "gs_accumulate_grad_stats", "gs_ssim_l1_workspace_bytes", "gs_ssim_l1_loss",
+    "gs_densify_move",
 ]
 
 _lib = None

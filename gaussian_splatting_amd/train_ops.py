@@ -74,6 +74,12 @@ class Adam(torch.optim.Adam):
                       ctypes.c_double(chunk[0][6]), ctypes.c_double(chunk[0][7]), ctypes.c_double(chunk[0][8]),
                       stream)
             i = j
+        # the kernel wrote through raw pointers: bump the version counters like an in-place torch op would,
+        # so that autograd's saved-tensor check still catches a backward over stale parameters
+        for p, _, m, v, *_ in work:
+            torch.autograd.graph.increment_version(p)
+            torch.autograd.graph.increment_version(m)
+            torch.autograd.graph.increment_version(v)
         return loss
 
 

@@ -305,6 +305,32 @@ size_t gs_ssim_l1_workspace_bytes(int H, int W);
 int gs_ssim_l1_loss(const void* image, const void* target, int H, int W, float ssim_frac,
                     void* workspace, void* loss_out, void* grad_image, void* stream);
 
+/* Adaptive density control, the data movement of splat_py/trainer.py:114-206 (delete / clone / split) and
+ * of splat_py/optimizer_manager.py:78-172 (the same surgery on Adam's exp_avg / exp_avg_sq) in one pass:
+ * every source row is read once and every row of the new Gaussian set is written once, for up to 8
+ * parameter tensors (fp32, `width[k]` floats per row, N0 rows) together with their optimizer state
+ * (src_exp_avg[k] / src_exp_avg_sq[k]: NULL when the tensor has no state yet).  The per-row decisions
+ * come as destination indices (gaussian_splatting_amd/densify.py forms them from the reference's masks
+ * with prefix sums; -1 = does not apply):
+ *   dst_self[i]     row of Gaussian i in the new set when it survives unsplit (parameters + state copied)
+ *   dst_clone[i]    row of its clone (trainer.py:123-161): parameters copied, xyz - 0.01 * xyz_grad_accum /
+ *                   grad_accum_count, optimizer state zero
+ *   split_self[i], split_clone[i]   rank among the n_split split rows when the Gaussian (its clone) is
+ *                   split (trainer.py:163-206): `samples` new rows at sample_base + s * n_split + rank with
+ *                   xyz + R(q / |q|) (random * exp(scale)), scale = log(exp(scale) / split_scale_factor),
+ *                   quaternion = q / |q|, the rest copied, optimizer state zero
+ * kind[k]: 0 plain, 1 xyz, 2 scale (log), 3 quaternion (w, x, y, z) -- the tensors the split transforms;
+ * xyz / scale / quaternion: the SOURCE tensors again (read by the transform whatever tensor a thread moves);
+ * random_samples: [n_split * samples, 3] uniform numbers in the order of trainer.py:176.
+ * The destination tensors are caller-allocated with the new row count and must not alias the sources. */
+int gs_densify_move(int n_tensors, const void* const* src, void* const* dst, const void* const* src_exp_avg,
+                    void* const* dst_exp_avg, const void* const* src_exp_avg_sq, void* const* dst_exp_avg_sq,
+                    const int32_t* width, const int32_t* kind, int N0, const int32_t* dst_self,
+                    const int32_t* dst_clone, const int32_t* split_self, const int32_t* split_clone,
+                    const void* xyz, const void* scale, const void* quaternion, const void* xyz_grad_accum,
+                    const int32_t* grad_accum_count, const void* random_samples, int n_split, int samples,
+                    int sample_base, float split_scale_factor, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,3 +1,3 @@
-mkdir -p gpurun_out/r2k; O=gpurun_out/r2k
-python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $O/pytest.txt
-grep -v "^{" $O/pytest.txt | tail -12
+mkdir -p gpurun_out/r2m; O=gpurun_out/r2m
+python -m pytest tests/test_gpu_densify.py tests/test_gpu_train_ops.py -m gpu -x -q 2>&1 | tail -30 > $O/pytest.txt
+tail -30 $O/pytest.txt
