@@ -81,24 +81,30 @@ __device__ inline bool sat_overlaps(const Sat& s, float l, float r, float t, flo
     return true;
 }
 
-template <typename F>
-__device__ inline void for_each_tile(const float* __restrict__ uvs,
-                                     const float* __restrict__ conic, int g, int ntx, int nty,
-                                     float mh, int row0, int row1, F emit) {
+// Per-Gaussian part of the tile walk: OBB, separating-axis constants and the candidate window
+// (empty window: w.sx >= w.ex).
+struct TileWalk {
+    Sat s;
+    Window w;
+};
+
+__device__ inline TileWalk tile_walk_setup(const float* __restrict__ uvs, const float* __restrict__ conic, int g,
+                                           int ntx, int nty, float mh, int row0, int row1) {
+    TileWalk tw;
     const float u = uvs[g * 2], v = uvs[g * 2 + 1];
     const float a = conic[g * 3] + 0.25f;
     const float b = conic[g * 3 + 1] / 2.0f;
     const float c = conic[g * 3 + 2] + 0.25f;
     const Obb o = compute_obb(u, v, a, b, c, mh);
     Window w = candidate_window(u, v, o.radius_tiles, ntx, nty, row0, row1);
-    if (w.sx >= w.ex || w.sy >= w.ey) return;
-    const Sat s = sat_setup(o);
+    tw.s = sat_setup(o);
+    const Sat& s = tw.s;
     // The first two axes of the test (tile_culling.cu:14-25) are solved for the tile index instead
     // of being evaluated per candidate: tile tx passes  mnx <= 16 (tx+1)  and  mxx >= 16 tx  iff
     // ceil(mnx/16) - 1 <= tx <= floor(mxx/16)  (16 tx is exact in fp32, /16 is exact), likewise in y.
     // The window shrinks from the reference's (2r)^2 square to the OBB's bounding box; the set of
     // accepted tiles is unchanged.  Non-finite extents keep the full window (NaN compares pass).
-    if (s.mnx == s.mnx && s.mxx == s.mxx && s.mny == s.mny && s.mxy == s.mxy) {
+    if (w.sx < w.ex && w.sy < w.ey && s.mnx == s.mnx && s.mxx == s.mxx && s.mny == s.mny && s.mxy == s.mxy) {
         // (clamped in float before the conversion: +-inf extents must not overflow the int math;
         // tile indices are < 2^20, where float arithmetic on integers is exact)
         const float big = 1.0e9f;
@@ -107,11 +113,60 @@ __device__ inline void for_each_tile(const float* __restrict__ uvs,
         w.sy = max(w.sy, f2i(fminf(fmaxf(__builtin_ceilf(s.mny / 16.0f) - 1.0f, -big), big)));
         w.ey = min(w.ey, f2i(fminf(fmaxf(__builtin_floorf(s.mxy / 16.0f) + 1.0f, -big), big)));
     }
-    for (int tx = w.sx; tx < w.ex; tx++) {
-        const float l = (float)tx * 16.0f, r = (float)(tx + 1) * 16.0f;
-        for (int ty = w.sy; ty < w.ey; ty++) {
-            const float t = (float)ty * 16.0f, b2 = (float)(ty + 1) * 16.0f;
-            if (sat_overlaps(s, l, r, t, b2)) emit(ty * ntx + tx);
+    if (w.sx >= w.ex || w.sy >= w.ey) w.sx = w.ex = w.sy = w.ey = 0;
+    tw.w = w;
+    return tw;
+}
+
+__device__ inline float lane_bcast(float x, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src));
+}
+__device__ inline int lane_bcast(int x, int src) { return __builtin_amdgcn_readlane(x, src); }
+
+// The tile walk of one Gaussian per lane, for a whole wave (every lane of the wave must call it;
+// `active` = the lane holds a Gaussian): emit(tile, payload) for every tile the Gaussian's OBB overlaps.
+// A window of up to COOP_MIN candidate tiles is walked by the Gaussian's own lane; a larger one is walked
+// by all 64 lanes together, 64 candidate tiles per step, after broadcasting the Gaussian's constants -- a
+// lane looping alone over the thousands of tiles of a screen-filling Gaussian stalled its whole workgroup
+// (training scenes have such Gaussians: binning went from 0.2 to 3 ms on them).  The accepted set and
+// the payloads are unchanged; only the order of the emit calls differs (the per-tile sort fixes order).
+constexpr int COOP_MIN = 48;
+template <typename F>
+__device__ inline void wave_for_each_tile(bool active, const TileWalk& tw, int ntx, uint64_t payload, F emit) {
+    const Window& w = tw.w;
+    const int area = active ? (w.ex - w.sx) * (w.ey - w.sy) : 0;
+    if (area > 0 && area <= COOP_MIN) {
+        for (int tx = w.sx; tx < w.ex; tx++) {
+            const float l = (float)tx * 16.0f, r = (float)(tx + 1) * 16.0f;
+            for (int ty = w.sy; ty < w.ey; ty++) {
+                const float t = (float)ty * 16.0f, b2 = (float)(ty + 1) * 16.0f;
+                if (sat_overlaps(tw.s, l, r, t, b2)) emit(ty * ntx + tx, payload);
+            }
+        }
+    }
+    unsigned long long big = __builtin_amdgcn_ballot_w64(area > COOP_MIN);
+    const int lane = threadIdx.x & 63;
+    while (big) {
+        const int src = __builtin_ctzll(big);
+        big &= big - 1;
+        Sat s;
+        s.mnx = lane_bcast(tw.s.mnx, src); s.mxx = lane_bcast(tw.s.mxx, src);
+        s.mny = lane_bcast(tw.s.mny, src); s.mxy = lane_bcast(tw.s.mxy, src);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            s.ax[k] = lane_bcast(tw.s.ax[k], src); s.ay[k] = lane_bcast(tw.s.ay[k], src);
+            s.mn_o[k] = lane_bcast(tw.s.mn_o[k], src); s.mx_o[k] = lane_bcast(tw.s.mx_o[k], src);
+        }
+        const int sx = lane_bcast(w.sx, src), ex = lane_bcast(w.ex, src), sy = lane_bcast(w.sy, src),
+                  ey = lane_bcast(w.ey, src);
+        const uint64_t pl = ((uint64_t)(uint32_t)lane_bcast((int)(payload >> 32), src) << 32) |
+                            (uint32_t)lane_bcast((int)(uint32_t)payload, src);
+        const int h = ey - sy, n = (ex - sx) * h;
+        for (int t = lane; t < n; t += 64) {
+            const int cx = t / h;
+            const int tx = sx + cx, ty = sy + (t - cx * h);
+            if (sat_overlaps(s, (float)tx * 16.0f, (float)(tx + 1) * 16.0f, (float)ty * 16.0f, (float)(ty + 1) * 16.0f))
+                emit(ty * ntx + tx, pl);
         }
     }
 }
@@ -136,9 +191,10 @@ __global__ __launch_bounds__(BIN_BLOCK) void k_tile_count(const float* __restric
                                                           int row1, int* __restrict__ counts,
                                                           Items items) {
     const int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
-    if (i >= item_count(items, V)) return;
-    for_each_tile(uvs, conic, item_at(items, i), ntx, nty, mh, row0, row1,
-                  [&](int tile) { atomicAdd(counts + tile, 1); });
+    const bool active = i < item_count(items, V);
+    TileWalk tw;
+    if (active) tw = tile_walk_setup(uvs, conic, item_at(items, i), ntx, nty, mh, row0, row1);
+    wave_for_each_tile(active, tw, ntx, 0, [&](int tile, uint64_t) { atomicAdd(counts + tile, 1); });
 }
 
 // exclusive prefix of counts[T] -> ranges[T+1]; single workgroup of 1024 threads
@@ -207,9 +263,13 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_count(const float* __restric
     __syncthreads();
     int g0, g1;
     slice_of(blockIdx.x, item_count(items, V), g0, g1);
-    for (int i = g0 + threadIdx.x; i < g1; i += PRIV_BLOCK)
-        for_each_tile(uvs, conic, item_at(items, i), ntx, nty, mh, row0, row1,
-                      [&](int tile) { atomicAdd(&s_hist[tile], 1); });
+    for (int base = g0; base < g1; base += PRIV_BLOCK) {   // wave-uniform trip count
+        const int i = base + threadIdx.x;
+        const bool active = i < g1;
+        TileWalk tw;
+        if (active) tw = tile_walk_setup(uvs, conic, item_at(items, i), ntx, nty, mh, row0, row1);
+        wave_for_each_tile(active, tw, ntx, 0, [&](int tile, uint64_t) { atomicAdd(&s_hist[tile], 1); });
+    }
     __syncthreads();
     int* row = hist + (size_t)blockIdx.x * T;
     for (int t = threadIdx.x; t < T; t += PRIV_BLOCK) row[t] = s_hist[t];
@@ -260,12 +320,17 @@ __global__ __launch_bounds__(BIN_BLOCK) void k_tile_emit(
     const int* __restrict__ ranges, int* __restrict__ cursor, uint64_t* __restrict__ keys,
     Items items, int64_t cap) {
     const int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
-    if (i >= item_count(items, V)) return;
-    const int g = item_at(items, i);
-    const uint64_t key = ((uint64_t)sortable_bits(xyz_cam[g * 3 + 2]) << 32) | (uint32_t)g;
-    for_each_tile(uvs, conic, g, ntx, nty, mh, row0, row1, [&](int tile) {
+    const bool active = i < item_count(items, V);
+    TileWalk tw;
+    uint64_t key = 0;
+    if (active) {
+        const int g = item_at(items, i);
+        key = ((uint64_t)sortable_bits(xyz_cam[g * 3 + 2]) << 32) | (uint32_t)g;
+        tw = tile_walk_setup(uvs, conic, g, ntx, nty, mh, row0, row1);
+    }
+    wave_for_each_tile(active, tw, ntx, key, [&](int tile, uint64_t k) {
         const int pos = ranges[tile] + atomicAdd(cursor + tile, 1);
-        if (pos < cap) keys[pos] = key;
+        if (pos < cap) keys[pos] = k;
     });
 }
 
@@ -281,12 +346,19 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_emit(
     __syncthreads();
     int g0, g1;
     slice_of(blockIdx.x, item_count(items, V), g0, g1);
-    for (int i = g0 + threadIdx.x; i < g1; i += PRIV_BLOCK) {
-        const int g = item_at(items, i);
-        const uint64_t key = ((uint64_t)sortable_bits(xyz_cam[g * 3 + 2]) << 32) | (uint32_t)g;
-        for_each_tile(uvs, conic, g, ntx, nty, mh, row0, row1, [&](int tile) {
+    for (int base = g0; base < g1; base += PRIV_BLOCK) {   // wave-uniform trip count
+        const int i = base + threadIdx.x;
+        const bool active = i < g1;
+        TileWalk tw;
+        uint64_t key = 0;
+        if (active) {
+            const int g = item_at(items, i);
+            key = ((uint64_t)sortable_bits(xyz_cam[g * 3 + 2]) << 32) | (uint32_t)g;
+            tw = tile_walk_setup(uvs, conic, g, ntx, nty, mh, row0, row1);
+        }
+        wave_for_each_tile(active, tw, ntx, key, [&](int tile, uint64_t k) {
             const int pos = atomicAdd(&s_cursor[tile], 1);
-            if (pos < cap) keys[pos] = key;
+            if (pos < cap) keys[pos] = k;
         });
     }
 }

@@ -199,6 +199,30 @@ def test_tile_lists_oversize_tile_falls_back_to_global_sort(hip_backend):
     assert torch.equal(got[1].cpu(), ref[1]) and torch.equal(got[0].cpu(), ref[0])
 
 
+@pytest.mark.parametrize("N,W,H", [(3000, 640, 480), (60000, 320, 240)])   # global-atomic path, LDS-histogram path
+def test_tile_lists_with_screen_filling_gaussians(hip_backend, N, W, H):
+    """Gaussians whose candidate window holds hundreds of tiles are walked by a whole wave (binning.hip:
+    wave_for_each_tile); the lists must not change.  Mix of ordinary, large and screen-filling footprints,
+    some anisotropic and rotated."""
+    orc = oracle()
+    d = cpu_stage_inputs(N, W, H, 0, 31)
+    gen = torch.Generator().manual_seed(7)
+    conic = d["conic"].clone()
+    V = conic.shape[0]
+    big = torch.rand(V, generator=gen) < 0.05
+    grow = torch.where(torch.rand(V, generator=gen) < 0.3, 3e4, 4e2)   # sigma up to ~170 px
+    conic[big] = conic[big] * grow[big].unsqueeze(1)
+    huge = torch.nonzero(big)[:5, 0]
+    conic[huge, 0] *= 50.0                                              # long thin ones across the screen
+    ntx, nty = (W + 15) // 16, (H + 15) // 16
+    ref_s, ref_r = orc.get_sorted_gaussian_list(1024, d["uv"], d["xyz_c"], conic, ntx, nty, 3.0)
+    counts = ref_r[1:] - ref_r[:-1]
+    assert int(counts.min()) >= int(big.sum() * 0.2), "some Gaussians should cover every tile"
+    got_s, got_r = hip_backend.get_sorted_gaussian_list(1024, d["uv"].to(DEV), d["xyz_c"].to(DEV), conic.to(DEV), ntx, nty,
+                                                        3.0)
+    assert torch.equal(got_r.cpu(), ref_r) and torch.equal(got_s.cpu(), ref_s)
+
+
 def _needs_tile_rows_extension(mod):
     if mod.__file__.endswith(".so"):
         pytest.skip("tile_rows= is an extension of the ctypes shim (multi-GPU hooks), not part of the "
