@@ -485,44 +485,61 @@ __device__ __forceinline__ void permlane32_swap(float& a, float& b) {
 // (LDS, owned by this wave for this splat: plain stores, no atomics -- an LDS float atomic costs
 // ~3.5 cycles PER ACTIVE LANE on gfx950, which made the accumulators the bound of the kernel).
 // A TRANSPOSING reduction: instead of summing all 9 values in every lane (54 cross-lane adds), lanes
-// trade halves of the value set -- after the xor-1 step a lane keeps 4 of the first 8 values, after the
-// xor-2 step 2 -- two row shifts finish the 16-lane rows (sums of values 2q, 2q+1 in lane 12+q', the
-// ninth in all of 12..15), one v_permlane16_swap puts the even values' row pairs in rows 0/2 and the
-// odd values' in rows 1/3, one v_permlane32_swap joins the halves: totals of the even values end in
-// lanes 12..15, of the odd values in lanes 28..31, the ninth in lane 47; those nine lanes store with
+// trade halves of the value set -- after the stride-4 step a lane keeps 4 of the first 8 values, after the
+// stride-8 step 2 (see the function body) -- one v_permlane16_swap puts the even values' row pairs in
+// rows 0/2 and the odd values' in rows 1/3, one v_permlane32_swap joins the halves: totals of the even
+// values end in row 0, of the odd values in row 1, the ninth in lanes 32..63; nine lanes store with
 // ONE ds_write_b32 (slot_lane_offset gives each its element, -1 elsewhere).
 // Lanes that do not contribute must hold zeros.
 __device__ __forceinline__ int slot_lane_offset(int lane) {
-    const int e = ((lane & 1) ? 4 : 0) + ((lane & 2) ? 2 : 0);   // the element pair the lane's quad position keeps
-    if ((lane & 12) != 12 || lane >= 48) return -1;
-    if (lane < 16) return e;
-    if (lane < 32) return e + 1;
-    return lane == 47 ? 8 : -1;
+    // after the reduction: row 0 holds the totals of the even values, row 1 of the odd ones, bank k of a
+    // row (lanes 4k..4k+3) the pair e(k) = (0, 4, 2, 6)[k]; lanes 32..63 hold the ninth value
+    if (lane == 32) return 8;
+    if (lane >= 32 || (lane & 3) != 0) return -1;
+    const int bank = (lane >> 2) & 3;
+    const int e = ((bank & 1) ? 4 : 0) + ((bank & 2) ? 2 : 0);
+    return lane < 16 ? e : e + 1;
 }
 __device__ __forceinline__ void reduce9_to_slot(const float* val, int lane, int lane_offset, float* slot) {
-    const bool b0 = lane & 1, b1 = lane & 2;
-    float r[4], s2[2];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const float send = b0 ? val[j] : val[j + 4];
-        const float keep = b0 ? val[j + 4] : val[j];
-        r[j] = keep + GS_DPP(send, 0xB1, 0xf, true);     // quad_perm [1,0,3,2]
-    }
-    float s8 = val[8] + GS_DPP(val[8], 0xB1, 0xf, true);
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const float send = b1 ? r[j] : r[j + 2];
-        const float keep = b1 ? r[j + 2] : r[j];
-        s2[j] = keep + GS_DPP(send, 0x4E, 0xf, true);    // quad_perm [2,3,0,1]
-    }
-    s8 += GS_DPP(s8, 0x4E, 0xf, true);
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        s2[j] += GS_DPP(s2[j], 0x114, 0xf, true);        // row_shr:4
-        s2[j] += GS_DPP(s2[j], 0x118, 0xf, true);        // row_shr:8 -> lanes 12..15 of every row
-    }
-    s8 += GS_DPP(s8, 0x114, 0xf, true);
-    s8 += GS_DPP(s8, 0x118, 0xf, true);
+    // Rows first (16 lanes), hand-scheduled.  A DPP add with a BANK mask writes only the enabled quads
+    // (bank = the four lanes i/4 of a row), so the trade "keep one half of the values, send the other"
+    // needs no select when it is done ACROSS quads:
+    //   stride 4   r_j = banks 0,2: v_j + v_j@(i+4)          banks 1,3: v_{j+4} + v_{j+4}@(i-4)     (j = 0..3)
+    //   stride 8   s_j = banks 0,1: r_j + r_j@(i+8)          banks 2,3: r_{j+2} + r_{j+2}@(i-8)     (j = 0, 1)
+    //   inside the quads the two survivors are summed plainly (xor 1, xor 2): every lane of bank k then
+    //   holds the ROW totals of values e(k), e(k)+1 with e = (0, 4, 2, 6); the ninth value takes xor 1,
+    //   xor 2, row_ror 4, row_ror 8 (row total in every lane).
+    // 20 DPP adds and no v_cndmask (the compiler's form of the same trade: 12 selects + 17 DPP ops).
+    // Every DPP source was written at least two instructions earlier (the DPP read-after-VALU-write hazard
+    // needs two wait states; the s_nop covers the compiler's code in front of the block).
+    float r0, r1, r2, r3, s2[2], s8;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %7, %7 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %8, %8 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %2, %9, %9 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %3, %10, %10 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %11, %11 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %1, %12, %12 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %2, %13, %13 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %3, %14, %14 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %6, %15, %15 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %0, %0 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %5, %1, %1 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %4, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %5, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %6, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(s2[0]), "=&v"(s2[1]), "=&v"(s8)
+        : "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5]), "v"(val[6]), "v"(val[7]),
+          "v"(val[8]));
+    (void)lane;
     // rows -> wave
     float x = s2[0], y = s2[1];
     permlane16_swap(x, y);           // x: rows (x0, y0, x2, y2); y: rows (x1, y1, x3, y3)
@@ -538,8 +555,13 @@ __device__ __forceinline__ void reduce9_to_slot(const float* val, int lane, int 
 // ---------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------
+#ifdef GS_BWD_WAVES
+#define GS_BWD_OCC __attribute__((amdgpu_waves_per_eu(GS_BWD_WAVES, GS_BWD_WAVES)))
+#else
+#define GS_BWD_OCC
+#endif
 template <typename T, int N_SH>
-__global__ __launch_bounds__(RB) void k_render_bwd(
+__global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     const T* __restrict__ packed, const T* __restrict__ rgb, const T* __restrict__ view_dir,
     const int* __restrict__ ranges, const int* __restrict__ sorted, const T* __restrict__ bg,
     const int* __restrict__ nsp_in, const T* __restrict__ fw_in, const T* __restrict__ grad_image,

@@ -108,6 +108,17 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
                     }
                     asm volatile("" ::: "memory");
                 }
+            } else if constexpr (KIND == 30) {  // ONE dependent chain per lane: 8 v_fma, each reading the previous result
+                a0 = __builtin_fmaf(a0, m, c); a0 = __builtin_fmaf(a0, m, c); a0 = __builtin_fmaf(a0, m, c); a0 = __builtin_fmaf(a0, m, c);
+                a0 = __builtin_fmaf(a0, m, c); a0 = __builtin_fmaf(a0, m, c); a0 = __builtin_fmaf(a0, m, c); a0 = __builtin_fmaf(a0, m, c);
+            } else if constexpr (KIND == 31) {  // two interleaved dependent chains
+                a0 = __builtin_fmaf(a0, m, c); a1 = __builtin_fmaf(a1, m, c); a0 = __builtin_fmaf(a0, m, c); a1 = __builtin_fmaf(a1, m, c);
+                a0 = __builtin_fmaf(a0, m, c); a1 = __builtin_fmaf(a1, m, c); a0 = __builtin_fmaf(a0, m, c); a1 = __builtin_fmaf(a1, m, c);
+            } else if constexpr (KIND == 32) {  // dependent chain of mixed ops the render loops use: mul, sub, fma, max, cndmask(e64), dpp add
+                a0 = a0 * m; a0 = a0 - a1; a0 = __builtin_fmaf(a0, m, c); a0 = __builtin_fmaxf(a0, a2);
+                asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(a0) : "v"(a0), "v"(a3), "s"(selmask));
+                a0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a0), 0x111, 0xf, 0xf, true));
+                a0 = a0 * m; a0 = __builtin_fmaf(a0, m, c);
             } else if constexpr (KIND == 18) {  // v_readfirstlane_b32 x8 (value goes back to a VGPR through an s_add)
                 a0 += __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a1)));
                 a1 += __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a2)));
@@ -152,7 +163,12 @@ template <int KIND> int run(const char* name, int insts_per_trip, int wg_per_cu)
 }
 
 int main() {
-    for (int w : {4, 8}) {
+    for (int w : {1, 2, 3, 4, 6, 8}) {
+        run<30>("dependent v_fma chain", 64, w);
+        run<31>("two dependent v_fma chains", 64, w);
+        run<32>("dependent mixed chain (mul sub fma max cnd dpp mul fma)", 64, w);
+    }
+    for (int w : {8}) {
         run<0>("v_fma_f32", 64, w);
         run<1>("v_pk_fma_f32", 32, w);
         run<3>("v_mul_f32", 64, w);
