@@ -184,3 +184,43 @@ def test_fused_slab_detection_and_arena():
     assert all(p % 16 == 0 for p in starts)
     blocks[0].fill_(1.0); blocks[1].fill_(2.0); blocks[3].fill_(3.0)
     assert float(blocks[0].sum()) == 3 and float(blocks[1].sum()) == 20 and float(blocks[3].sum()) == 15
+
+
+def test_bench_helpers():
+    """bench.py's host-side pieces: the frame's algorithmic bytes are SURVEY.md 8(d)'s formula, camera poses
+    are seeded rigid transforms, the median, and the self-spawn command line"""
+    import importlib
+    import sys
+    import types
+    bench = importlib.import_module("bench")
+    N, V, S, P = 1000, 900, 4000, 50000
+    per = bench.algorithmic_bytes(N, V, S, P, 16)
+    assert per["frame"] == 248 * N + 384 * V + 144 * S + 40 * P
+    per0 = bench.algorithmic_bytes(N, V, S, P, 1)
+    assert per0["frame"] == 68 * N + 204 * V + 144 * S + 40 * P
+    assert per["gs_render_tiles_backward"] == 76 * S + 20 * P
+    poses = bench.camera_poses(5, 7, "cpu", moving=True)
+    again = bench.camera_poses(5, 7, "cpu", moving=True)
+    assert all(torch.equal(a, b) for a, b in zip(poses, again)) and not torch.equal(poses[0], poses[1])
+    for M in poses:
+        R = M[:3, :3]
+        assert torch.allclose(R @ R.T, torch.eye(3), atol=1e-6) and abs(float(torch.det(R)) - 1) < 1e-6
+        assert torch.equal(M[3], torch.tensor([0.0, 0.0, 0.0, 1.0]))
+    assert all(torch.equal(M, torch.eye(4)) for M in bench.camera_poses(3, 7, "cpu", moving=False))
+    assert bench.median([3, 1, 2]) == 2 and bench.median([4, 1, 2, 3]) == 2.5 and bench.median([]) == 0.0
+    # --gpus N without a launcher: the command re-executes bench.py under torch.distributed.run with N ranks
+    seen = {}
+    real = sys.modules.get("subprocess")
+    fake = types.SimpleNamespace(call=lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    sys.modules["subprocess"] = fake
+    argv = sys.argv
+    sys.argv = ["bench.py", "--gpus", "4", "--steps", "3"]
+    try:
+        assert bench.spawn_ranks(types.SimpleNamespace(gpus=4)) == 0
+    finally:
+        sys.argv = argv
+        sys.modules["subprocess"] = real
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert "127.0.0.1" in cmd and cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
