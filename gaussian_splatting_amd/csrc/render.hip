@@ -678,13 +678,16 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                 // contribute, so the reduction needs no zero-filled value array.
                 const T* rec = s_geom + i * GS_PACKED_WIDTH;
                 const Vec4<T> g0 = *reinterpret_cast<const Vec4<T>*>(rec);       // u v r2 opacity
+                // the whole 48-byte record at once (one LDS round trip per visit instead of three dependent
+                // ones; LDS bandwidth is no longer what bounds this kernel): 0.70 -> 0.69 ms
+                const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(rec + 4);   // a b c det
+                const Vec4<T> g2 = *reinterpret_cast<const Vec4<T>*>(rec + 8);   // 1/det, colour
+                asm volatile("" ::"v"(g1.x), "v"(g1.y), "v"(g1.z), "v"(g2.x), "v"(g2.y), "v"(g2.z), "v"(g2.w));
                 const T du = pu - g0.x, dv = pv - g0.y;
                 const T du2 = du * du, dv2 = dv * dv;
                 T aw = 0, w = 0, q0 = 0, q1 = 0, q2 = 0;
                 if (reach && !(du2 + dv2 > g0.z)) {   // inside the cutoff radius
                     GS_STAT_SET(st_in);
-                    const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(rec + 4);   // a b c det
-                    const Vec4<T> g2 = *reinterpret_cast<const Vec4<T>*>(rec + 8);   // 1/det, colour
                     // render_backward.cu:153-165 (multiplies by 1/det; the forward divides)
                     const T duv = du * dv;
                     const T mh = (g1.z * du * du - (g1.y + g1.y) * du * dv + g1.x * dv * dv) * g2.x;
@@ -828,12 +831,12 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
         }
         __syncthreads();
         // one global atomic per value per (splat, tile)
-        if (tid < cnt) {
-            const int g = s_idx[tid];
-            T acc_row[NV];
-            T* a = SLOTS ? acc_row : s_acc + tid * NV;
-            if constexpr (SLOTS) {
-                // the slots of the waves that wrote this splat, in wave order (deterministic per tile)
+        if constexpr (SLOTS) {
+            // Phase 1, thread = splat: add the slots of the waves that wrote this splat, in wave order
+            // (deterministic per tile), apply the per-splat factors, and park the row in wave 0's slot of the
+            // same splat (each thread only ever touches its own splat's slots: no barrier needed before).
+            if (tid < cnt) {
+                T a[NV];
 #pragma unroll
                 for (int j = 0; j < NV; j++) a[j] = 0;
 #pragma unroll
@@ -854,16 +857,42 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                 a[6] *= k;
                 a[7] *= k;
                 a[8] *= k;
+                T* row = s_acc + tid * NV;
+#pragma unroll
+                for (int j = 0; j < NV; j++) row[j] = a[j];
             }
+            __syncthreads();
+            // Phase 2, nine lanes = one row: a wave's atomic instruction then covers seven whole 36-byte
+            // rows with consecutive addresses, which the L2 handles per cache line -- 6x the rate of one
+            // thread per row with nine instructions (scripts/ubench/atomic_rows.hip: 0.094 vs 0.557 ms for
+            // the 1.25 M rows of a frame; the per-row form had become 0.17 ms of this kernel).
+            const int sub = lane / NV, col = lane - sub * NV;   // lane 63: idle
+            for (int r0 = wave * 7; r0 < cnt; r0 += 28) {
+                const int r = r0 + sub;
+                const bool in = lane < 63 && r < cnt;
+                const T v = in ? s_acc[r * NV + col] : T(0);
+                const unsigned long long nz = ballot(v != T(0));
+                const bool any = in && ((nz >> (sub * NV)) & 0x1ffull) != 0;   // rows of zeros stay untouched
+                GS_STAT(11, __popcll(ballot(any && col == 0)));   // flushed rows
+                if (any) {
+                    const int g = s_idx[r];
+                    T* dst;
+                    if (slab) dst = g_rgb + (size_t)g * NV + col;   // [V, 9]: rgb 3 | opacity 1 | uv 2 | conic 3
+                    else if (col < 3) dst = g_rgb + (size_t)g * 3 + col;
+                    else if (col == 3) dst = g_opa + g;
+                    else if (col < 6) dst = g_uv + (size_t)g * 2 + (col - 4);
+                    else dst = g_conic + (size_t)g * 3 + (col - 6);
+                    global_add(dst, v);
+                }
+            }
+        } else if (tid < cnt) {
+            const int g = s_idx[tid];
+            const T* a = s_acc + tid * NV;
             bool any = false;
 #pragma unroll
             for (int j = 0; j < NV; j++) any |= (a[j] != T(0));
             GS_STAT(11, __popcll(__ballot(any)));   // flushed rows
-            if (any && slab) {
-                // one [V, 9] row per Gaussian (rgb 3 | opacity 1 | uv 2 | conic 3): the order of a[]
-#pragma unroll
-                for (int j = 0; j < NV; j++) global_add(g_rgb + (size_t)g * NV + j, a[j]);
-            } else if (any) {
+            if (any) {
 #pragma unroll
                 for (int j = 0; j < C; j++) global_add(g_rgb + (size_t)g * C + j, a[j]);
                 global_add(g_opa + g, a[C + 0]);

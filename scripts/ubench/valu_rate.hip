@@ -119,6 +119,12 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
                 asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(a0) : "v"(a0), "v"(a3), "s"(selmask));
                 a0 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a0), 0x111, 0xf, 0xf, true));
                 a0 = a0 * m; a0 = __builtin_fmaf(a0, m, c);
+            } else if constexpr (KIND == 33) {  // v_permlane16_swap_b32 x8 (pairs of registers)
+#define PSWAP16(x, y) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y))
+                PSWAP16(a0, a1); PSWAP16(a2, a3); PSWAP16(a4, a5); PSWAP16(a6, a7); PSWAP16(a0, a2); PSWAP16(a1, a3); PSWAP16(a4, a6); PSWAP16(a5, a7);
+            } else if constexpr (KIND == 34) {  // v_permlane32_swap_b32 x8
+#define PSWAP32(x, y) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y))
+                PSWAP32(a0, a1); PSWAP32(a2, a3); PSWAP32(a4, a5); PSWAP32(a6, a7); PSWAP32(a0, a2); PSWAP32(a1, a3); PSWAP32(a4, a6); PSWAP32(a5, a7);
             } else if constexpr (KIND == 18) {  // v_readfirstlane_b32 x8 (value goes back to a VGPR through an s_add)
                 a0 += __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a1)));
                 a1 += __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a2)));
@@ -167,6 +173,10 @@ int main() {
         run<30>("dependent v_fma chain", 64, w);
         run<31>("two dependent v_fma chains", 64, w);
         run<32>("dependent mixed chain (mul sub fma max cnd dpp mul fma)", 64, w);
+    }
+    for (int w : {4, 8}) {
+        run<33>("v_permlane16_swap_b32", 64, w);
+        run<34>("v_permlane32_swap_b32", 64, w);
     }
     for (int w : {8}) {
         run<0>("v_fma_f32", 64, w);
