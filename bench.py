@@ -77,8 +77,10 @@ ENTRY_ALIAS = {"gs_render_tiles_backward_slab": "gs_render_tiles_backward", "gs_
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100,
+                    help="timed frames (default 100 = ~0.17 s at workload D: one host hiccup of a few ms, as bench boxes "
+                    "show now and then, then moves the mean by a few percent instead of 15)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="D", choices=["A", "B", "C", "D"])
     ap.add_argument("--path", default="auto", choices=["auto", "fused", "reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
