@@ -15,6 +15,15 @@ LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(_HERE, "libgsplat_hi
 GS_F32 = 0
 GS_F64 = 1
 GS_SORT_PREFIX = 1024
+GS_BACKWARD_COMPAT = 0   # render backward bug-compatible with render_backward.cu:185 (default)
+GS_BACKWARD_EXACT = 1    # the exact gradient of the forward pass
+
+
+def set_backward_mode(mode):
+    """"compat" (default: the reference's arithmetic including SURVEY.md Q1) or "exact" (global splat index
+    in the transmittance update: the mathematically exact gradient); process-wide"""
+    code = {"compat": GS_BACKWARD_COMPAT, "exact": GS_BACKWARD_EXACT}.get(mode, mode)
+    check(lib().gs_set_backward_mode(int(code)))
 
 # every entry point include/gsplat_hip.h declares
 EXPORTS = [
@@ -27,7 +36,7 @@ EXPORTS = [
     "gs_tile_workspace_ints", "gs_tile_count", "gs_tile_emit_sort", "gs_tile_sort_flagged",
     "gs_preprocess_workspace_ints", "gs_preprocess_forward", "gs_preprocess_backward",
     "gs_pack_splats", "gs_render_tiles", "gs_render_tiles_prefix", "gs_render_tiles_backward", "gs_render_tiles_backward_slab",
-    "gs_render_depth", "gs_halo_workspace_ints", "gs_halo_plan", "gs_halo_gather_sum",
+    "gs_set_backward_mode", "gs_get_backward_mode", "gs_render_depth", "gs_halo_workspace_ints", "gs_halo_plan", "gs_halo_gather_sum",
     "gs_adam_step", "gs_accumulate_grad_stats", "gs_ssim_l1_workspace_bytes", "gs_ssim_l1_loss",
     "gs_densify_move",
 ]

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     const int* __restrict__ ranges, const int* __restrict__ sorted, const T* __restrict__ bg,
     const int* __restrict__ nsp_in, const T* __restrict__ fw_in, const T* __restrict__ grad_image,
     int W, int H, int ntx, int tile0, int nt, T* __restrict__ g_rgb, T* __restrict__ g_opa,
-    T* __restrict__ g_uv, T* __restrict__ g_conic, int slab) {
+    T* __restrict__ g_uv, T* __restrict__ g_conic, int slab, int exact) {
     constexpr bool fast = sizeof(T) == 4;
     constexpr int CW = ColW<N_SH>::value;
     constexpr int C = 3 * N_SH;
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                         {
 #pragma clang fp contract(fast)
                             const T r1ma = fast_rcp(T(1) - alpha);
-                            if ((k % REF_CH) < nsp - 1) weight = weight * r1ma;   // Q1 (chunk-local index)
+                            if ((exact ? k : k % REF_CH) < nsp - 1) weight = weight * r1ma;   // Q1 (chunk-local index) unless exact
                             aw = alpha * weight;
                             // grad_alpha (render_backward.cu:196-203); the record's colour is Y0 * coefficient
                             const T c0 = g2.y, c1 = g2.z, c2 = g2.w;
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                     {
 #pragma clang fp contract(fast)
                         const T r1ma = fast_rcp(T(1) - alpha);
-                        if ((k % REF_CH) < nsp - 1) weight = weight * r1ma;   // Q1 (chunk-local index)
+                        if ((exact ? k : k % REF_CH) < nsp - 1) weight = weight * r1ma;   // Q1 (chunk-local index) unless exact
                         T col[3];
                         splat_colour<T, N_SH>(s_geom, s_col, i, Y, col);
                         const T aw = alpha * weight;
@@ -1004,7 +1004,16 @@ static int check_rows(int H, int row0, int row1) {
     return GS_OK;
 }
 
+static int g_backward_mode = GS_BACKWARD_COMPAT;
+
 extern "C" {
+
+int gs_set_backward_mode(int mode) {
+    GS_REQUIRE(mode == GS_BACKWARD_COMPAT || mode == GS_BACKWARD_EXACT, "backward mode must be GS_BACKWARD_COMPAT or GS_BACKWARD_EXACT");
+    g_backward_mode = mode;
+    return GS_OK;
+}
+int gs_get_backward_mode(void) { return g_backward_mode; }
 
 #ifdef GS_STATS
 // instrumented build only: copies the 32 counters to the host (and clears them when reset != 0)
@@ -1093,7 +1102,7 @@ int gs_render_tiles_backward(const void* packed, const void* rgb, const void* vi
                                      num_splats_per_pixel, (const T*)final_weight_per_pixel,
                                      (const T*)grad_image, W, H, ntx, tile_row0 * ntx, nt,
                                      (T*)grad_rgb, (T*)grad_opacity, (T*)grad_uv,
-                                     (T*)grad_conic, 0))));
+                                     (T*)grad_conic, 0, g_backward_mode))));
     return check_launch("render_tiles_backward");
 }
 
@@ -1114,7 +1123,7 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
         (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
         (const float*)background_rgb, num_splats_per_pixel, (const float*)final_weight_per_pixel,
         (const float*)grad_image, W, H, ntx, tile_row0 * ntx, nt, (float*)grad_slab, nullptr,
-        nullptr, nullptr, 1);
+        nullptr, nullptr, 1, g_backward_mode);
     return check_launch("render_tiles_backward_slab");
 }
 

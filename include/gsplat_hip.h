@@ -216,7 +216,7 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
                            void* final_weight_per_pixel, void* image, void* stream);
 /* render_tiles_backward_cuda (bindings.cpp:120; render_backward.cu:12-595).
  * grad_rgb[V,3,n_sh], grad_opacity[V,1], grad_uv[V,2], grad_conic[V,3] are accumulated.
- * Bug-compatible with render_backward.cu:185. */
+ * Bug-compatible with render_backward.cu:185 by default; see gs_set_backward_mode. */
 int gs_render_tiles_backward(const void* packed, const void* rgb, const void* view_dir_by_pixel,
                              const int32_t* tile_ranges, const int32_t* sorted_gaussians,
                              const void* background_rgb, const int32_t* num_splats_per_pixel,
@@ -233,6 +233,19 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
                                   const void* final_weight_per_pixel, const void* grad_image, int W,
                                   int H, int tile_row0, int tile_row1, void* grad_slab,
                                   void* stream);
+/* Gradient mode of the render backward (both entry points above; process-wide, default COMPAT).
+ *   GS_BACKWARD_COMPAT  the reference's arithmetic, including render_backward.cu:185: the transmittance is
+ *                       divided back by (1 - alpha) only while the CHUNK-LOCAL splat index is below
+ *                       num_splats - 1, so for pixels that composite deeper than the reference's first
+ *                       shared-memory chunk (960 splats in fp32 with one colour coefficient) the weights of
+ *                       the later chunks are off by a factor 1 / (1 - alpha_last)
+ *   GS_BACKWARD_EXACT   the same with the GLOBAL splat index: the mathematically exact gradient of the
+ *                       forward pass.  Identical to COMPAT whenever no pixel composites past the first chunk. */
+#define GS_BACKWARD_COMPAT 0
+#define GS_BACKWARD_EXACT 1
+int gs_set_backward_mode(int mode);
+int gs_get_backward_mode(void);
+
 /* render_depth_cuda (bindings.cpp:158; depth.cu:7-177), fp32 only.  depth_image[H,W] is written
  * only where the accumulated alpha passes alpha_threshold (caller pre-fills with -1). */
 int gs_render_depth(const void* packed, const void* xyz_camera_frame, const int32_t* tile_ranges,

@@ -56,6 +56,8 @@ int g_sh_band1_mode = 0;
 //   alpha >= 1/255 test before the pixel saturated (render.cu:145-163) -- two runs whose inputs differ
 //   in the last ulp took the same decisions at a pixel iff this count and num_splats agree.
 int g_bwd_abs = 0;
+int g_q1_exact = 0;   // 1: the transmittance update uses the global splat index (exact gradient) instead of
+                      // render_backward.cu:185's chunk-local one -- the checker of GS_BACKWARD_EXACT
 int* g_contrib_count = nullptr;
 
 // ---------------------------------------------------------------------------------------
@@ -537,6 +539,7 @@ void orc_set_modes(int exp_mode, int trig_mode) {
 }
 void orc_set_sh_band1_mode(int m) { g_sh_band1_mode = m; }
 void orc_set_backward_abs(int on) { g_bwd_abs = on; }
+void orc_set_backward_exact(int on) { g_q1_exact = on; }
 void orc_set_contrib_count(int* per_pixel) { g_contrib_count = per_pixel; }
 int orc_num_threads() {
 #ifdef _OPENMP
@@ -833,7 +836,7 @@ void render_tiles_backward(const T* uvs, const T* opacity, const T* rgb, const T
                         T color_accum[3] = {0.0, 0.0, 0.0};
                         bool bg_init = false;
                         for (int k = std::min(nsp, n_tile) - 1; k >= 0; k--) {
-                            const int i = k % CH;   // chunk-local index (render_backward.cu:120)
+                            const int i = g_q1_exact ? k : k % CH;   // chunk-local index (render_backward.cu:120)
                             const int g = sorted[s0 + k];
                             const T u_diff = T(u_px) - uvs[g * 2 + 0];
                             const T v_diff = T(v_px) - uvs[g * 2 + 1];

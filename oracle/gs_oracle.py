@@ -221,6 +221,12 @@ def render_tiles_backward_cuda(uvs, opacity, rgb, conic, view_dir_by_pixel, spla
         _p(grad_rgb), _p(grad_opacity), _p(grad_uv), _p(grad_conic), y0, y1)
 
 
+def set_backward_exact(on):
+    """1: exact gradient (global splat index in the transmittance update) instead of the reference's
+    render_backward.cu:185 -- the checker of the library's GS_BACKWARD_EXACT mode"""
+    lib().orc_set_backward_exact(int(bool(on)))
+
+
 def render_tiles_backward_abs(*args, **kw):
     """render_tiles_backward_cuda with |term| accumulated instead of term: per gradient element the sum
     of the magnitudes of its per-pixel terms (checker aid, no reference counterpart)."""

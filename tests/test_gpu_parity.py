@@ -465,3 +465,73 @@ def test_error_behaviour(hip_backend):
         hip_backend.render_tiles_cuda(z(4, 2), z(4, 1), z(4, 3), z(4, 3), z(1, 1, 1), z(5, dtype=torch.int64),
                                       z(0, dtype=torch.int32), z(3), z(32, 32, dtype=torch.int32), z(32, 32),
                                       z(32, 32, 3))
+
+
+# ---------------------------------------------------------------------------------------------------
+# gradient mode: compat (render_backward.cu:185) vs exact
+# ---------------------------------------------------------------------------------------------------
+def test_exact_backward_mode_is_the_derivative_of_the_forward():
+    """fp64 (no alpha threshold: the forward is smooth), 400 faint splats on one tile, so every pixel
+    composites past the reference's first fp64 chunk (320).  A central difference of the forward along a
+    random direction equals <gradient, direction> in GS_BACKWARD_EXACT mode and does not in the default
+    compat mode (the weights beyond the first chunk carry the factor 1 / (1 - alpha_last)); the oracle's
+    exact mode agrees with the kernel's."""
+    from gaussian_splatting_amd import _hip, splat_cuda
+    from oracle import gs_oracle as orc
+    gen = torch.Generator().manual_seed(3)
+    V, W, H = 400, 16, 16
+    uv = (torch.rand(V, 2, generator=gen, dtype=torch.float64) * 16)
+    conic = torch.stack([20 + 30 * torch.rand(V, generator=gen, dtype=torch.float64),
+                         4 * (torch.rand(V, generator=gen, dtype=torch.float64) - 0.5),
+                         20 + 30 * torch.rand(V, generator=gen, dtype=torch.float64)], dim=1)
+    opacity = 0.002 + 0.004 * torch.rand(V, 1, generator=gen, dtype=torch.float64)
+    rgb = torch.rand(V, 3, generator=gen, dtype=torch.float64)
+    bg = torch.full((3,), 0.3, dtype=torch.float64)
+    gi = torch.randn(H, W, 3, generator=gen, dtype=torch.float64)
+    ranges = torch.tensor([0, V], dtype=torch.int32)
+    sorted_g = torch.arange(V, dtype=torch.int32)
+    rays = torch.zeros(1, 1, 1, dtype=torch.float64)
+    inputs = [uv, opacity, rgb, conic]
+    direction = [torch.randn(t.shape, generator=gen, dtype=torch.float64) * s
+                 for t, s in zip(inputs, (1e-2, 1e-4, 1e-2, 1e-1))]
+
+    def forward(mod, dev, ts):
+        img = torch.zeros(H, W, 3, dtype=torch.float64, device=dev)
+        nsp = torch.zeros(H, W, dtype=torch.int32, device=dev)
+        fw = torch.zeros(H, W, dtype=torch.float64, device=dev)
+        a = [t.to(dev).contiguous() for t in ts]
+        mod.render_tiles_cuda(a[0], a[1], a[2], a[3], rays.to(dev), ranges.to(dev), sorted_g.to(dev), bg.to(dev), nsp, fw, img)
+        return img, nsp, fw, a
+
+    def backward(mod, dev, ts):
+        img, nsp, fw, a = forward(mod, dev, ts)
+        g = [torch.zeros(V, 3, dtype=torch.float64, device=dev), torch.zeros(V, 1, dtype=torch.float64, device=dev),
+             torch.zeros(V, 2, dtype=torch.float64, device=dev), torch.zeros(V, 3, dtype=torch.float64, device=dev)]
+        mod.render_tiles_backward_cuda(a[0], a[1], a[2], a[3], rays.to(dev), ranges.to(dev), sorted_g.to(dev), bg.to(dev),
+                                       nsp, fw, gi.to(dev), *g)
+        assert int(nsp.min()) == V   # nobody saturates: every pixel walks all 400 splats
+        return {"uv": g[2].cpu(), "opacity": g[1].cpu(), "rgb": g[0].cpu(), "conic": g[3].cpu()}
+
+    h = 1e-4
+    plus = forward(splat_cuda, DEV, [t + h * d for t, d in zip(inputs, direction)])[0].cpu()
+    minus = forward(splat_cuda, DEV, [t - h * d for t, d in zip(inputs, direction)])[0].cpu()
+    numeric = float(((plus - minus) / (2 * h) * gi).sum())
+
+    def directional(grads):
+        return float(sum((grads[k] * d).sum() for k, d in zip(("uv", "opacity", "rgb", "conic"), direction)))
+
+    try:
+        _hip.set_backward_mode("exact")
+        orc.set_backward_exact(1)
+        exact = backward(splat_cuda, DEV, inputs)
+        ref_exact = backward(orc, "cpu", inputs)
+    finally:
+        _hip.set_backward_mode("compat")
+        orc.set_backward_exact(0)
+    compat = backward(splat_cuda, DEV, inputs)
+    ref_compat = backward(orc, "cpu", inputs)
+    assert abs(directional(exact) - numeric) < 1e-6 * abs(numeric), (directional(exact), numeric)
+    assert abs(directional(compat) - numeric) > 1e-4 * abs(numeric), "Q1 should be visible past the first chunk"
+    for k in exact:
+        assert scaled_err(exact[k], ref_exact[k]) < 1e-11, k
+        assert scaled_err(compat[k], ref_compat[k]) < 1e-11, k

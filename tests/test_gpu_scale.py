@@ -351,3 +351,23 @@ def test_prefix_sort_mode_repairs_tiles_that_need_more():
     assert torch.equal(out[True][0], out[False][0])
     for k in out[False][1]:
         assert scaled_err(out[True][1][k], out[False][1][k]) < 1e-5, k
+
+
+def test_config_D_faint_exact_mode_matches_the_oracle_exact_mode():
+    """GS_BACKWARD_EXACT at full size where it matters (every pixel past the first reference chunk): against the
+    oracle in its exact mode; and it differs from the compat gradients there"""
+    from gaussian_splatting_amd import _hip
+    rows = (26, 27)
+    orc = oracle()
+    try:
+        _hip.set_backward_mode("exact")
+        orc.set_backward_exact(1)
+        img, mask, uv, aux, grads, (W, H) = frame("D", tile_rows=rows, opacity_shift=-4.0)
+        ref = oracle_rows(aux, uv, W, H, rows, make_grad_image(W, H, seed=1))
+    finally:
+        _hip.set_backward_mode("compat")
+        orc.set_backward_exact(0)
+    assert torch.equal(img.cpu(), ref["image"])
+    check_band_backward("config_D_faint_band_backward row 26 (exact mode)", grads, ref)
+    _, _, _, _, compat, _ = frame("D", tile_rows=rows, opacity_shift=-4.0)
+    assert scaled_err(compat["opacity_act"], grads["opacity_act"]) > 1e-3
