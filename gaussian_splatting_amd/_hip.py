@@ -55,6 +55,11 @@ def lib():
             raise HipLibraryError(
                 f"{LIB_PATH} not found: the HIP extension is not built. "
                 "Run `make -C gaussian_splatting_amd/csrc` (there is no CPU fallback).")
+        # One HIP runtime per process: the library needs libamdhip64.so.7 and must bind to the copy
+        # PyTorch ships (same SONAME), whose streams and allocations it works on.  Loaded before torch
+        # it would pull in /opt/rocm's runtime instead, and the second runtime to initialise finds no
+        # device ("no ROCm-capable device is detected").
+        import torch  # noqa: F401
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.gs_last_error.restype = ctypes.c_char_p
         _lib.gs_preprocess_workspace_ints.restype = ctypes.c_size_t

@@ -61,3 +61,15 @@ def test_native_splat_cuda_module_exports_the_reference_names():
     splat_cuda_native.install("splat_cuda_test_alias")
     import sys
     assert sys.modules.pop("splat_cuda_test_alias") is mod
+
+
+def test_library_shares_the_hip_runtime_torch_loaded():
+    """loading the library before `import torch` must not bring a second libamdhip64 into the process
+    (the second runtime to initialise finds no device: __graft_entry__.build() followed by smoke())"""
+    import subprocess
+    import sys
+    code = ("from gaussian_splatting_amd import _hip\n_hip.lib()\nimport torch\n"
+            "print(len({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}))\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().splitlines()[-1] == "1", out.stdout
