@@ -39,15 +39,41 @@ namespace gs {
 // the product library.
 #ifdef GS_STATS
 __device__ unsigned long long g_render_stats[32];
-#define GS_STAT_DECL unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define GS_STAT(i, v) st_[i] += (unsigned long long)(v)
+// wave timeline (scripts/render_timeline.py, -DGS_STATS -DGS_TIMELINE): one record {begin, end, hw id |
+// xcc id, visits, chunks} per wave at slot (kernel, block, wave), times from the 100 MHz constant clock.
+// The timeline build does not add to the shared counters (their atomics serialise the waves' exits).
+constexpr int GS_TIMELINE_CAP = 1 << 16;   // waves per kernel
+__device__ unsigned long long g_timeline[2 * GS_TIMELINE_CAP * 5];
+#define GS_STAT_DECL                                                                               \
+    unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                  \
+    const unsigned long long st_t0_ = wall_clock64();                                             \
+    (void)st_t0_
 #define GS_STAT_FLAG(name) bool name = false
 #define GS_STAT_SET(name) name = true
+#ifdef GS_TIMELINE
+#define GS_STAT(i, v)                                                                              \
+    if ((i) == 1 || (i) == 2) st_[i] += (unsigned long long)(v)
+#define GS_STAT_FLUSH(base)                                                                        \
+    if ((threadIdx.x & 63) == 0) {                                                                 \
+        const unsigned r_ = blockIdx.x * 4 + (threadIdx.x >> 6);                                   \
+        if (r_ < (unsigned)GS_TIMELINE_CAP) {                                                      \
+            unsigned long long* t_ = g_timeline + ((size_t)((base) ? GS_TIMELINE_CAP : 0) + r_) * 5; \
+            t_[0] = st_t0_;                                                                        \
+            t_[1] = wall_clock64();                                                                \
+            t_[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32) | \
+                    (unsigned)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));              \
+            t_[3] = st_[2];                                                                        \
+            t_[4] = st_[1];                                                                        \
+        }                                                                                          \
+    }
+#else
+#define GS_STAT(i, v) st_[i] += (unsigned long long)(v)
 #define GS_STAT_FLUSH(base)                                                                        \
     if ((threadIdx.x & 63) == 0) {                                                                 \
         for (int q_ = 0; q_ < 16; q_++)                                                            \
             if (st_[q_]) atomicAdd(&g_render_stats[(base) + q_], st_[q_]);                         \
     }
+#endif
 #else
 #define GS_STAT_DECL
 #define GS_STAT(i, v)
@@ -83,10 +109,31 @@ template <> __host__ __device__ constexpr int ref_chunk<double>(int n_sh) {
     return n_sh == 1 ? 320 : n_sh == 4 ? 160 : n_sh == 9 ? 128 : 64;
 }
 
-// XCD-aware tile order: block b -> tile index inside [0, nt)
+// XCD-aware tile order: block b -> tile index inside [0, nt) (or >= nt: nothing to do).  The hardware
+// hands block b to XCD b % 8, a fixed eighth of the grid each.  Default: one contiguous eighth of the
+// frame per XCD (its L2 holds the records neighbouring tiles share).  GS_XCD_SEG > 0 deals runs of that
+// many consecutive tiles to the XCDs in turn instead; the wave timeline (scripts/render_timeline.py)
+// shows the eight XCDs finishing within 10 % of each other either way and the kernel times do not move
+// (workloads B, C, D: +-1 %), so the option stays off.
+#ifndef GS_XCD_SEG
+#define GS_XCD_SEG 0
+#endif
+__host__ __device__ inline int render_grid(int nt) {
+#if GS_XCD_SEG > 0
+    const int nseg = (nt + GS_XCD_SEG - 1) / GS_XCD_SEG;
+    return ((nseg + 7) / 8) * GS_XCD_SEG * 8;
+#else
+    return ((nt + 7) / 8) * 8;
+#endif
+}
 __device__ inline int tile_of_block(int b, int nt) {
+#if GS_XCD_SEG > 0
+    const int x = b & 7, j = b >> 3;
+    return ((j / GS_XCD_SEG) * 8 + x) * GS_XCD_SEG + j % GS_XCD_SEG;
+#else
     const int per = (nt + 7) >> 3;
     return (b & 7) * per + (b >> 3);
+#endif
 }
 
 struct PixelMap {
@@ -1027,6 +1074,18 @@ int gs_debug_render_stats(unsigned long long* out, int reset) {
     }
     return GS_OK;
 }
+// instrumented build only: copies the wave timeline (2 kernels x GS_TIMELINE_CAP slots x 5 u64; unused
+// slots are zero) to the host and clears it
+int gs_debug_render_timeline(unsigned long long* out, int cap_waves) {
+    if (hipDeviceSynchronize() != hipSuccess) return GS_EHIP;
+    if (cap_waves != gs::GS_TIMELINE_CAP) return GS_EINVAL;
+    const size_t bytes = (size_t)2 * gs::GS_TIMELINE_CAP * 5 * sizeof(unsigned long long);
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gs::g_timeline), bytes) != hipSuccess) return GS_EHIP;
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(gs::g_timeline)) != hipSuccess) return GS_EHIP;
+    if (hipMemset(p, 0, bytes) != hipSuccess) return GS_EHIP;
+    return GS_OK;
+}
 #endif
 
 int gs_render_tiles(const void* packed, const void* rgb, const void* view_dir_by_pixel,
@@ -1040,7 +1099,7 @@ int gs_render_tiles(const void* packed, const void* rgb, const void* view_dir_by
     const int ntx = (W + 15) / 16;
     const int nt = (tile_row1 - tile_row0) * ntx;
     if (nt == 0) return GS_OK;
-    const int grid = ((nt + 7) / 8) * 8;
+    const int grid = render_grid(nt);
     DISPATCH_T(dtype, DISPATCH_SH(n_sh, (k_render_fwd<T, N_SH><<<grid, RB, 0, s>>>(
                                             (const T*)packed, (const T*)rgb,
                                             (const T*)view_dir_by_pixel, tile_ranges,
@@ -1063,7 +1122,7 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
     const int ntx = (W + 15) / 16;
     const int nt = (tile_row1 - tile_row0) * ntx;
     if (nt == 0) return GS_OK;
-    const int grid = ((nt + 7) / 8) * 8;
+    const int grid = render_grid(nt);
     const int t0 = tile_row0 * ntx;
     // 1. provisional pass over the ordered prefixes; raises the flags
     k_render_fwd<float, 1><<<grid, RB, 0, s>>>(
@@ -1094,7 +1153,7 @@ int gs_render_tiles_backward(const void* packed, const void* rgb, const void* vi
     const int ntx = (W + 15) / 16;
     const int nt = (tile_row1 - tile_row0) * ntx;
     if (nt == 0) return GS_OK;
-    const int grid = ((nt + 7) / 8) * 8;
+    const int grid = render_grid(nt);
     DISPATCH_T(dtype,
                DISPATCH_SH(n_sh, (k_render_bwd<T, N_SH><<<grid, RB, 0, s>>>(
                                      (const T*)packed, (const T*)rgb, (const T*)view_dir_by_pixel,
@@ -1118,7 +1177,7 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
     const int ntx = (W + 15) / 16;
     const int nt = (tile_row1 - tile_row0) * ntx;
     if (nt == 0) return GS_OK;
-    const int grid = ((nt + 7) / 8) * 8;
+    const int grid = render_grid(nt);
     k_render_bwd<float, 1><<<grid, RB, 0, s>>>(
         (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
         (const float*)background_rgb, num_splats_per_pixel, (const float*)final_weight_per_pixel,
@@ -1134,7 +1193,7 @@ int gs_render_depth(const void* packed, const void* xyz_camera_frame, const int3
     hipStream_t s = (hipStream_t)stream;
     const int ntx = (W + 15) / 16, nty = (H + 15) / 16;
     const int nt = ntx * nty;
-    const int grid = ((nt + 7) / 8) * 8;
+    const int grid = render_grid(nt);
     k_render_depth<<<grid, RB, 0, s>>>((const float*)packed, (const float*)xyz_camera_frame,
                                        tile_ranges, sorted_gaussians, W, H, ntx, nt,
                                        alpha_threshold, (float*)depth_image);

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
+    fused.NATIVE = False   # the native frame module is linked against the product library, not the instrumented one
     lib = _hip.lib()
     N, W, H, deg = WORKLOADS[args.workload]
     g, cam, T = make_scene(N, W, H, deg, seed=0, device=dev)
