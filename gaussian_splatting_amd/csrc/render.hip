@@ -43,30 +43,44 @@ __device__ unsigned long long g_render_stats[32];
 // xcc id, visits, chunks} per wave at slot (kernel, block, wave), times from the 100 MHz constant clock.
 // The timeline build does not add to the shared counters (their atomics serialise the waves' exits).
 constexpr int GS_TIMELINE_CAP = 1 << 16;   // waves per kernel
-__device__ unsigned long long g_timeline[2 * GS_TIMELINE_CAP * 5];
+constexpr int GS_TIMELINE_W = 10;
+__device__ unsigned long long g_timeline[2 * GS_TIMELINE_CAP * GS_TIMELINE_W];
 #define GS_STAT_DECL                                                                               \
     unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                  \
     const unsigned long long st_t0_ = wall_clock64();                                             \
-    (void)st_t0_
+    const unsigned long long st_c0_ = __builtin_readcyclecounter();                                \
+    unsigned long long st_ph_ = st_c0_;                                                            \
+    (void)st_t0_;                                                                                  \
+    (void)st_c0_;                                                                                  \
+    (void)st_ph_
 #define GS_STAT_FLAG(name) bool name = false
 #define GS_STAT_SET(name) name = true
 #ifdef GS_TIMELINE
 #define GS_STAT(i, v)                                                                              \
     if ((i) == 1 || (i) == 2) st_[i] += (unsigned long long)(v)
+// cycles since the previous mark go to phase k (k = 0..4)
+#define GS_PHASE(k)                                                                                \
+    {                                                                                              \
+        const unsigned long long c_ = __builtin_readcyclecounter();                                \
+        st_[10 + (k)] += c_ - st_ph_;                                                              \
+        st_ph_ = c_;                                                                               \
+    }
 #define GS_STAT_FLUSH(base)                                                                        \
     if ((threadIdx.x & 63) == 0) {                                                                 \
         const unsigned r_ = blockIdx.x * 4 + (threadIdx.x >> 6);                                   \
         if (r_ < (unsigned)GS_TIMELINE_CAP) {                                                      \
-            unsigned long long* t_ = g_timeline + ((size_t)((base) ? GS_TIMELINE_CAP : 0) + r_) * 5; \
+            unsigned long long* t_ = g_timeline + ((size_t)((base) ? GS_TIMELINE_CAP : 0) + r_) * GS_TIMELINE_W; \
+            for (int q_ = 0; q_ < 5; q_++) t_[5 + q_] = st_[10 + q_];                              \
             t_[0] = st_t0_;                                                                        \
             t_[1] = wall_clock64();                                                                \
             t_[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32) | \
                     (unsigned)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));              \
             t_[3] = st_[2];                                                                        \
-            t_[4] = st_[1];                                                                        \
+            t_[4] = (st_[1] << 48) | ((__builtin_readcyclecounter() - st_c0_) & 0xffffffffffffull);   \
         }                                                                                          \
     }
 #else
+#define GS_PHASE(k)
 #define GS_STAT(i, v) st_[i] += (unsigned long long)(v)
 #define GS_STAT_FLUSH(base)                                                                        \
     if ((threadIdx.x & 63) == 0) {                                                                 \
@@ -80,6 +94,7 @@ __device__ unsigned long long g_timeline[2 * GS_TIMELINE_CAP * 5];
 #define GS_STAT_FLAG(name)
 #define GS_STAT_SET(name)
 #define GS_STAT_FLUSH(base)
+#define GS_PHASE(k)
 #endif
 
 #ifndef GS_BWD_GROUP
@@ -209,6 +224,10 @@ __device__ __forceinline__ float div_by_reciprocal(float q, float det, float r) 
     return __builtin_fmaf(e, r, y);
 }
 __device__ __forceinline__ double div_by_reciprocal(double q, double det, double) { return q / det; }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
 template <typename T> __device__ inline T tmin(T a, T b) { return b < a ? b : a; }
 template <typename T> __device__ inline T tmax(T a, T b) { return b > a ? b : a; }
 
@@ -240,14 +259,20 @@ __device__ inline void build_touch_masks(const T* s_geom, int cnt, int tid, int 
             // 1-D parabola.  tau_m = r2 / lmax >= 1.05 tau (r2 carries the margin of cutoff_r2), and
             // the continuous minimum bounds every pixel's q from below, so q_min > tau_m means no
             // pixel of the patch can reach alpha >= 1/255.  Cheaper bounds first (circle).
+            // (b/a, b/c, 1/lmax from the hardware reciprocal, 1 ulp: where the clamped minimiser lands
+            // 1e-7 off, q exceeds the true edge minimum by a second-order 1e-14 -- the 1.001 on tau_m and
+            // the 5 % margin inside r2 cover that a million times over.  17 IEEE divisions per splat and
+            // chunk were 14 % of the forward kernel's wave time.)
             bool use_q = false;
-            T a = 0, b = 0, c = 0, rdet = 0, tau_m = 0;
+            T a = 0, b = 0, c = 0, rdet = 0, tau_m = 0, b_over_a = 0, b_over_c = 0;
             if (fast_mode<T>() && r2 > T(0) && r2 < T(1e30)) {
                 a = rec[4]; b = rec[5]; c = rec[6]; rdet = rec[8];
                 const T half = T(0.5) * (a + c);
-                const T lmax = half + gsqrt<T>(T(0.25) * (a - c) * (a - c) + b * b);
-                tau_m = (r2 / lmax) * T(1.001);
+                const T lmax = half + fast_sqrt(T(0.25) * (a - c) * (a - c) + b * b);
+                tau_m = (r2 * fast_rcp(lmax)) * T(1.001);
                 use_q = a > T(0) && c > T(0) && rdet > T(0);
+                b_over_a = b * fast_rcp(a);
+                b_over_c = b * fast_rcp(c);
             }
 #pragma unroll
             for (int p = 0; p < 4; p++) {
@@ -266,11 +291,11 @@ __device__ inline void build_touch_masks(const T* s_geom, int cnt, int tid, int 
 #pragma unroll
                     for (int e = 0; e < 2; e++) {
                         const T X = e ? X1 : X0;            // vertical edges: dy* = b X / a
-                        T yy = b * X / a;
+                        T yy = b_over_a * X;
                         yy = tmin<T>(tmax<T>(yy, Y0), Y1);
                         qmin = tmin<T>(qmin, (c * X * X - T(2) * b * X * yy + a * yy * yy) * rdet);
                         const T Y = e ? Y1 : Y0;            // horizontal edges: dx* = b Y / c
-                        T xx = b * Y / c;
+                        T xx = b_over_c * Y;
                         xx = tmin<T>(tmax<T>(xx, X0), X1);
                         qmin = tmin<T>(qmin, (c * xx * xx - T(2) * b * xx * Y + a * Y * Y) * rdet);
                     }
@@ -301,6 +326,27 @@ __device__ inline void splat_colour(const T* s_geom, const T* s_col, int i, cons
     } else {
         sh_to_rgb<T, N_SH>(s_col + i * ColW<N_SH>::value, Y, col);
     }
+}
+
+// ---- software-pipelined LDS record reads (fp32 kernels of the fused renderer) -------------------------
+// A wave walking its touch mask is latency-bound, not issue-bound: the wave timeline
+// (scripts/render_timeline.py) shows the same ~1200 cycles per visit per wave whether 8 waves or 1 share
+// the SIMD, and three dependent LDS round trips (u v r2 | conic, opacity | colour) are a third of it.  The
+// whole 48-byte record of the NEXT visit is therefore requested (three ds_read_b128, uniform address)
+// before the current visit is worked on, into the other of two register sets.  Volatile loads, so that
+// the compiler neither sinks them to their first use nor merges them, pinned by a scheduling barrier; it
+// still tracks them, i.e. waits with lgkmcnt(3) for the current record while the next one is in flight.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const volatile __attribute__((address_space(3))) f32x4* LdsVec4Ptr;
+struct LdsRecord {
+    f32x4 g0, g1, g2;   // u v r2 opacity | a b c det | 1/det colour
+};
+__device__ __forceinline__ void lds_record_fetch(LdsRecord& r, const float* rec) {
+    LdsVec4Ptr p = (LdsVec4Ptr)(const __attribute__((address_space(3))) float*)rec;
+    r.g0 = p[0];
+    r.g1 = p[1];
+    r.g2 = p[2];
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -367,39 +413,50 @@ __device__ __forceinline__ void render_tile_fwd(
         GS_STAT(8, cnt);    // list entries staged
         stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, nullptr);
         __syncthreads();
+        GS_PHASE(0);
         build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
         __syncthreads();
-        for (int word = 0; word < NW && word * 64 < cnt; word++) {
-            if (ballot(!done) == 0) break;   // wave-uniform: every pixel of the patch saturated
-            unsigned long long m = wave_uniform(s_mask[wave][word]);
-            while (m) {
-                const int i = word * 64 + __builtin_ctzll(m);
-                m &= m - 1;
-                GS_STAT(2, 1);                        // visits (touch-mask bits walked)
-                GS_STAT(6, __popcll(ballot(!done)));   // live lanes at the visit
+        GS_PHASE(1);
+        if constexpr (fast && N_SH == 1) {
+            // pipelined walk: the record of the next visit is in flight while this one is composited
+            auto visit = [&](const LdsRecord& r, int i) {
+                GS_STAT(2, 1);
+                GS_STAT(6, __popcll(ballot(!done)));
                 GS_STAT_FLAG(st_in);
                 GS_STAT_FLAG(st_hit);
                 if (!done) {
-                    const T* rec = s_geom + i * GS_PACKED_WIDTH;
-                    const Vec4<T> g0 = *reinterpret_cast<const Vec4<T>*>(rec);   // u v r2 opacity
-                    const T du = pu - g0.x, dv = pv - g0.y;
-                    // beyond the cutoff radius alpha < 1/255 is certain: same outcome as :145-148
-                    if (!(fast && du * du + dv * dv > g0.z)) {
+                    const T du = pu - r.g0.x, dv = pv - r.g0.y;
+#ifdef GS_EXP_NOCIRCLE
+                    {
+#else
+                    if (!(du * du + dv * dv > r.g0.z)) {
+#endif
                         GS_STAT_SET(st_in);
-                        const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(rec + 4);   // a b c det
-                        const Vec4<T> g2 = *reinterpret_cast<const Vec4<T>*>(rec + 8);   // 1/det, colour
-                        const T a = g1.x, b = g1.y, c = g1.z, det = g1.w;
-                        const T mh = div_by_reciprocal(c * du * du - (b + b) * du * dv + a * dv * dv, det, g2.x);
-                        T alpha = g0.w * exp_neg_half(mh);
+                        const T a = r.g1.x, b = r.g1.y, c = r.g1.z, det = r.g1.w;
+                        const T mh = div_by_reciprocal(c * du * du - (b + b) * du * dv + a * dv * dv, det, r.g2.x);
+#ifdef GS_EXP_NOEXP
+                        T alpha = r.g0.w * (T(1) - T(0.001) * mh);
+#else
+                        T alpha = r.g0.w * exp_neg_half(mh);
+#endif
                         alpha = (mh > T(0)) ? alpha : T(0);                 // render.cu:133
-                        if (!(fast && alpha < Thr<T>::alpha_min())) {       // render.cu:145
+#ifdef GS_EXP_NOTHR
+                        alpha = (alpha < Thr<T>::alpha_min()) ? T(0) : alpha;
+                        {
+#else
+                        if (!(alpha < Thr<T>::alpha_min())) {               // render.cu:145
+#endif
                             GS_STAT_SET(st_hit);
+#ifdef GS_EXP_F32W
+                            fw = T(1) - acc;
+                            const T weight = alpha * fw;
+#else
                             fw = 1.0 - acc;
                             const T weight = alpha * (1.0 - acc);           // double, narrowed
-                            T col[3];
-                            splat_colour<T, N_SH>(s_geom, s_col, i, Y, col);
-#pragma unroll
-                            for (int ch = 0; ch < 3; ch++) img[ch] += col[ch] * weight;
+#endif
+                            img[0] += r.g2.y * weight;
+                            img[1] += r.g2.z * weight;
+                            img[2] += r.g2.w * weight;
                             acc += weight;
                             if (acc > Thr<T>::sat_gt()) {   // saturated: the next splat's check fails
                                 done = true;
@@ -408,12 +465,88 @@ __device__ __forceinline__ void render_tile_fwd(
                         }
                     }
                 }
-                GS_STAT(3, ballot(st_in) != 0);           // visits with a lane inside the cutoff circle
-                GS_STAT(4, ballot(st_hit) != 0);          // visits with a contributing lane
-                GS_STAT(5, __popcll(ballot(st_hit)));     // contributing (pixel, splat) pairs
+                GS_STAT(3, ballot(st_in) != 0);
+                GS_STAT(4, ballot(st_hit) != 0);
+                GS_STAT(5, __popcll(ballot(st_hit)));
+            };
+            for (int word = 0; word < NW && word * 64 < cnt; word++) {
+                if (ballot(!done) == 0) break;   // wave-uniform: every pixel of the patch saturated
+                unsigned long long m = wave_uniform(s_mask[wave][word]);
+                if (m == 0) continue;
+                LdsRecord ra, rb;
+                int cur = word * 64 + __builtin_ctzll(m), nxt;
+                m &= m - 1;
+                lds_record_fetch(ra, s_geom + cur * GS_PACKED_WIDTH);
+                while (true) {
+                    nxt = -1;
+                    if (m) {
+                        nxt = word * 64 + __builtin_ctzll(m);
+                        m &= m - 1;
+                        lds_record_fetch(rb, s_geom + nxt * GS_PACKED_WIDTH);
+                    }
+                    visit(ra, cur);
+                    if (nxt < 0) break;
+                    cur = nxt;
+                    nxt = -1;
+                    if (m) {
+                        nxt = word * 64 + __builtin_ctzll(m);
+                        m &= m - 1;
+                        lds_record_fetch(ra, s_geom + nxt * GS_PACKED_WIDTH);
+                    }
+                    visit(rb, cur);
+                    if (nxt < 0) break;
+                    cur = nxt;
+                }
+            }
+        } else {
+            for (int word = 0; word < NW && word * 64 < cnt; word++) {
+                if (ballot(!done) == 0) break;   // wave-uniform: every pixel of the patch saturated
+                unsigned long long m = wave_uniform(s_mask[wave][word]);
+                while (m) {
+                    const int i = word * 64 + __builtin_ctzll(m);
+                    m &= m - 1;
+                    GS_STAT(2, 1);                        // visits (touch-mask bits walked)
+                    GS_STAT(6, __popcll(ballot(!done)));   // live lanes at the visit
+                    GS_STAT_FLAG(st_in);
+                    GS_STAT_FLAG(st_hit);
+                    if (!done) {
+                        const T* rec = s_geom + i * GS_PACKED_WIDTH;
+                        const Vec4<T> g0 = *reinterpret_cast<const Vec4<T>*>(rec);   // u v r2 opacity
+                        const T du = pu - g0.x, dv = pv - g0.y;
+                        // beyond the cutoff radius alpha < 1/255 is certain: same outcome as :145-148
+                        if (!(fast && du * du + dv * dv > g0.z)) {
+                            GS_STAT_SET(st_in);
+                            const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(rec + 4);   // a b c det
+                            const Vec4<T> g2 = *reinterpret_cast<const Vec4<T>*>(rec + 8);   // 1/det, colour
+                            const T a = g1.x, b = g1.y, c = g1.z, det = g1.w;
+                            const T mh = div_by_reciprocal(c * du * du - (b + b) * du * dv + a * dv * dv, det, g2.x);
+                            T alpha = g0.w * exp_neg_half(mh);
+                            alpha = (mh > T(0)) ? alpha : T(0);                 // render.cu:133
+                            if (!(fast && alpha < Thr<T>::alpha_min())) {       // render.cu:145
+                                GS_STAT_SET(st_hit);
+                                fw = 1.0 - acc;
+                                const T weight = alpha * (1.0 - acc);           // double, narrowed
+                                T col[3];
+                                splat_colour<T, N_SH>(s_geom, s_col, i, Y, col);
+#pragma unroll
+                                for (int ch = 0; ch < 3; ch++) img[ch] += col[ch] * weight;
+                                acc += weight;
+                                if (acc > Thr<T>::sat_gt()) {   // saturated: the next splat's check fails
+                                    done = true;
+                                    nsp = base + i + 1;
+                                }
+                            }
+                        }
+                    }
+                    GS_STAT(3, ballot(st_in) != 0);           // visits with a lane inside the cutoff circle
+                    GS_STAT(4, ballot(st_hit) != 0);          // visits with a contributing lane
+                    GS_STAT(5, __popcll(ballot(st_hit)));     // contributing (pixel, splat) pairs
+                }
             }
         }
+        GS_PHASE(2);
         all_done = __syncthreads_and(done);
+        GS_PHASE(3);
         if (all_done) break;
     }
     GS_STAT_FLUSH(0);
@@ -507,9 +640,6 @@ __device__ inline double wave_sum(double v) {   // gradcheck-only path: plain sh
     }
     return v;
 }
-
-__device__ inline float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ inline double fast_rcp(double x) { return 1.0 / x; }
 
 template <typename T> __device__ inline void lds_add(T* p, T v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -694,8 +824,10 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
         if constexpr (!SLOTS)
             for (int k = tid; k < cnt * NV; k += RB) s_acc[k] = 0;
         __syncthreads();
+        GS_PHASE(0);
         build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
         __syncthreads();
+        GS_PHASE(1);
 
         for (int word = (cnt - 1) >> 6; word >= 0; word--) {
           unsigned long long m = s_mask[wave][word];
@@ -876,7 +1008,9 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
           if constexpr (SLOTS)
               if (lane == 0) s_hit[wave][word] = hit;
         }
+        GS_PHASE(2);
         __syncthreads();
+        GS_PHASE(3);
         // one global atomic per value per (splat, tile)
         if constexpr (SLOTS) {
             // Phase 1, thread = splat: add the slots of the waves that wrote this splat, in wave order
@@ -950,6 +1084,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                 global_add(g_conic + (size_t)g * 3 + 2, a[C + 5]);
             }
         }
+        GS_PHASE(4);
     }
     GS_STAT_FLUSH(16);
 }
@@ -1074,12 +1209,12 @@ int gs_debug_render_stats(unsigned long long* out, int reset) {
     }
     return GS_OK;
 }
-// instrumented build only: copies the wave timeline (2 kernels x GS_TIMELINE_CAP slots x 5 u64; unused
+// instrumented build only: copies the wave timeline (2 kernels x GS_TIMELINE_CAP slots x GS_TIMELINE_W u64; unused
 // slots are zero) to the host and clears it
 int gs_debug_render_timeline(unsigned long long* out, int cap_waves) {
     if (hipDeviceSynchronize() != hipSuccess) return GS_EHIP;
     if (cap_waves != gs::GS_TIMELINE_CAP) return GS_EINVAL;
-    const size_t bytes = (size_t)2 * gs::GS_TIMELINE_CAP * 5 * sizeof(unsigned long long);
+    const size_t bytes = (size_t)2 * gs::GS_TIMELINE_CAP * gs::GS_TIMELINE_W * sizeof(unsigned long long);
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gs::g_timeline), bytes) != hipSuccess) return GS_EHIP;
     void* p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(gs::g_timeline)) != hipSuccess) return GS_EHIP;

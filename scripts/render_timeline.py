@@ -63,7 +63,11 @@ def analyse(rec, slices=20):
         "cu_busy_wave_us": {"min": float(b.min() / 100), "mean": float(b.mean() / 100), "max": float(b.max() / 100)},
         "visits_per_wave": {"mean": float(visits.mean()), "p90": float(np.percentile(visits, 90)),
                             "max": float(visits.max())},
-        "cycles_per_visit_per_wave_at_2400MHz": float(dur.sum() * 24.0 / max(visits.sum(), 1)),
+        "shader_clock_mhz": float((rec[:, 4] & 0xffffffffffff).astype(np.float64).sum() / (dur.sum() / 100.0)),
+        "phase_share_of_wave_cycles": dict(zip(["stage", "touch_masks", "walk", "barrier_after_walk", "flush"],
+                                               [round(float(x), 4) for x in rec[:, 5:10].astype(np.float64).sum(0) /
+                                                max((rec[:, 4] & 0xffffffffffff).astype(np.float64).sum(), 1)])),
+        "ns_per_visit_per_wave": float(dur.sum() * 10.0 / max(visits.sum(), 1)),
     }
 
 
@@ -83,7 +87,7 @@ def main():
             p.requires_grad_(True)
     gi = make_grad_image(W, H, seed=1, device=dev)
     bg = torch.zeros(3, device=dev)
-    buf = (ctypes.c_ulonglong * (2 * CAP * 5))()
+    buf = (ctypes.c_ulonglong * (2 * CAP * 10))()
 
     def frame():
         img, _, _ = fused.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, **DEFAULTS)
@@ -94,7 +98,7 @@ def main():
     _hip.check(lib.gs_debug_render_timeline(buf, CAP))
     frame()
     _hip.check(lib.gs_debug_render_timeline(buf, CAP))
-    rec = np.ctypeslib.as_array(buf).reshape(2, CAP, 5).copy()
+    rec = np.ctypeslib.as_array(buf).reshape(2, CAP, 10).copy()
     fwd, bwd = (r[r[:, 1] != 0] for r in rec)
     out = {"workload": args.workload, "forward": analyse(fwd), "backward": analyse(bwd)}
     text = json.dumps(out, indent=1)
