@@ -335,7 +335,10 @@ __device__ inline void splat_colour(const T* s_geom, const T* s_col, int i, cons
 // whole 48-byte record of the NEXT visit is therefore requested (three ds_read_b128, uniform address)
 // before the current visit is worked on, into the other of two register sets.  Volatile loads, so that
 // the compiler neither sinks them to their first use nor merges them, pinned by a scheduling barrier; it
-// still tracks them, i.e. waits with lgkmcnt(3) for the current record while the next one is in flight.
+// still tracks them, i.e. waits for the current record while the next one is in flight.  Costs 18 VGPRs
+// (54 -> 72, 8 -> 7 waves per SIMD) and still wins: forward 0.274 -> 0.265 ms at workload D; prefetching
+// only u v r2 opacity | conic (61 VGPRs, 8 waves) and the colour quad at the visit is slower (0.256 vs
+// 0.248 ms with the division-free touch masks in both).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const volatile __attribute__((address_space(3))) f32x4* LdsVec4Ptr;
 struct LdsRecord {
@@ -426,34 +429,16 @@ __device__ __forceinline__ void render_tile_fwd(
                 GS_STAT_FLAG(st_hit);
                 if (!done) {
                     const T du = pu - r.g0.x, dv = pv - r.g0.y;
-#ifdef GS_EXP_NOCIRCLE
-                    {
-#else
                     if (!(du * du + dv * dv > r.g0.z)) {
-#endif
                         GS_STAT_SET(st_in);
                         const T a = r.g1.x, b = r.g1.y, c = r.g1.z, det = r.g1.w;
                         const T mh = div_by_reciprocal(c * du * du - (b + b) * du * dv + a * dv * dv, det, r.g2.x);
-#ifdef GS_EXP_NOEXP
-                        T alpha = r.g0.w * (T(1) - T(0.001) * mh);
-#else
                         T alpha = r.g0.w * exp_neg_half(mh);
-#endif
                         alpha = (mh > T(0)) ? alpha : T(0);                 // render.cu:133
-#ifdef GS_EXP_NOTHR
-                        alpha = (alpha < Thr<T>::alpha_min()) ? T(0) : alpha;
-                        {
-#else
                         if (!(alpha < Thr<T>::alpha_min())) {               // render.cu:145
-#endif
                             GS_STAT_SET(st_hit);
-#ifdef GS_EXP_F32W
-                            fw = T(1) - acc;
-                            const T weight = alpha * fw;
-#else
                             fw = 1.0 - acc;
                             const T weight = alpha * (1.0 - acc);           // double, narrowed
-#endif
                             img[0] += r.g2.y * weight;
                             img[1] += r.g2.z * weight;
                             img[2] += r.g2.w * weight;
