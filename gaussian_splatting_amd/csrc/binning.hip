@@ -379,6 +379,8 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_emit(
             key = ((uint64_t)sortable_bits(xyz_cam[g * 3 + 2]) << 32) | (uint32_t)g;
             tw = tile_walk_setup(uvs, conic, g, ntx, nty, mh, row0, row1);
         }
+        // (storing a hit's key only after the NEXT hit's cursor atomic has been issued, so that the LDS round
+        // trip overlaps the following separating-axis test, changes nothing: 0.293 vs 0.291 ms)
         wave_for_each_tile(active, tw, ntx, key, [&](int tile, uint64_t k) {
             const int pos = atomicAdd(&s_cursor[tile], 1);
             if (pos < cap) keys[pos] = k;

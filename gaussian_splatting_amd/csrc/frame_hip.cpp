@@ -142,25 +142,32 @@ RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* 
     const int64_t P = (int64_t)W * H;
     auto opt = torch::TensorOptions().dtype(torch::kFloat32).device(bg.device());
     RenderOut r;
-    // one allocation: image [H,W,3] | final weight [H,W] | splat count [H,W] (int32 view).  Rows outside
-    // [row0, row1) are not written by the kernel: zero-fill only when restricted
-    r.buf = whole ? torch::empty({5 * P}, opt) : torch::zeros({5 * P}, opt);
+    // one allocation: image [H,W,3] | final weight [H,W] | splat count [H,W] (int32 view) | per-tile render
+    // cost int32[T] | launch-order workspace int32[T + 8] (the backward finds the last two behind the splat
+    // counts: tile_cost_of()).  Rows outside [row0, row1) are not written by the kernel: zero-fill only when
+    // restricted
+    const int ntx = (W + 15) / 16, nty = (H + 15) / 16;
+    const int64_t T = (int64_t)ntx * nty;
+    r.buf = whole ? torch::empty({5 * P + 2 * T + 8}, opt) : torch::zeros({5 * P + 2 * T + 8}, opt);
     r.image = r.buf.narrow(0, 0, 3 * P).view({H, W, 3});
     r.fw = r.buf.narrow(0, 3 * P, P).view({H, W});
     r.nsp = r.buf.narrow(0, 4 * P, P).view(torch::kInt32).view({H, W});
-    const int ntx = (W + 15) / 16, nty = (H + 15) / 16;
+    int32_t* tile_cost = reinterpret_cast<int32_t*>(r.buf.data_ptr<float>()) + 5 * P;
     if (sort_prefix && sorted.size(0) > sort_prefix) {
         Tensor flags = torch::empty({(int64_t)ntx * nty}, opt.dtype(torch::kInt32));
         timed("gs_render_tiles_prefix", stream, [&] {
             return gs_render_tiles_prefix(packed, rgbr, ranges, sorted.data_ptr<int32_t>(),
                                           (const uint64_t*)keys.data_ptr<int64_t>(), sorted.size(0), bg.data_ptr(), W, H, row0,
                                           row1, flags.data_ptr<int32_t>(), r.nsp.data_ptr<int32_t>(), r.fw.data_ptr(),
-                                          r.image.data_ptr(), stream);
+                                          r.image.data_ptr(), tile_cost, stream);
         });
         std::lock_guard<std::mutex> lock(g_mutex);
         if (g_flag_log.size() < 512) g_flag_log.push_back(flags);
         g_last_flags = flags;
     } else {
+        // no costs measured: all tiles equal (any launch order is as good as another)
+        TORCH_CHECK(hipMemsetAsync(tile_cost, 0, sizeof(int32_t) * (size_t)T, (hipStream_t)stream) == hipSuccess,
+                    "hipMemsetAsync failed");
         timed("gs_render_tiles", stream, [&] {
             return gs_render_tiles(packed, rgbr, nullptr, ranges, sorted.data_ptr<int32_t>(), bg.data_ptr(), W, H, 1, row0, row1,
                                    r.nsp.data_ptr<int32_t>(), r.fw.data_ptr(), r.image.data_ptr(), GS_F32, stream);
@@ -364,10 +371,14 @@ struct Render : public torch::autograd::Function<Render> {
         Tensor slab = torch::zeros({std::max<int64_t>(V, 1), SLAB_WIDTH}, packed.options());
         void* stream = cur_stream();
         const int row0 = (int)ctx->saved_data["row0"].toInt(), row1 = (int)ctx->saved_data["row1"].toInt();
+        // the forward's per-tile costs and the order workspace sit behind the splat counts (render_forward)
+        const int64_t T = (int64_t)((W + 15) / 16) * ((H + 15) / 16);
+        int32_t* tile_cost = nsp.data_ptr<int32_t>() + (int64_t)W * H;
         timed("gs_render_tiles_backward_slab", stream, [&] {
             return gs_render_tiles_backward_slab(packed.data_ptr(), rgbr.data_ptr(), ranges.data_ptr<int32_t>(),
                                                  sorted_g.data_ptr<int32_t>(), bg.data_ptr(), nsp.data_ptr<int32_t>(),
-                                                 fw.data_ptr(), grad_image.data_ptr(), W, H, row0, row1, slab.data_ptr(), stream);
+                                                 fw.data_ptr(), grad_image.data_ptr(), W, H, row0, row1, slab.data_ptr(),
+                                                 tile_cost, tile_cost + T, stream);
         });
         Tensor rows = slab.narrow(0, 0, V);
         out[0] = rows.narrow(1, 4, 2);   // uv

@@ -352,6 +352,55 @@ __device__ __forceinline__ void lds_record_fetch(LdsRecord& r, const float* rec)
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---- longest-first tile order for the backward -------------------------------------------------------
+// The hardware starts workgroups in grid order and the kernel ends when the last one does; a workgroup
+// lives ~150 us of the 520 us backward, so the tail in which the chip drains is a fifth of the kernel
+// (scripts/render_timeline.py).  Started longest-first, the tiles that finish last are the short ones.
+// The forward measures each tile's own duration (shader clock; the backward of a tile is slow where its
+// forward was: same lists, same hit pattern, correlation 0.7) and k_tile_order turns the costs into a
+// launch order with a counting sort on 1024 cost classes; consecutive entries go to different XCDs, which
+// also evens out their totals.  Only the start order changes, no result does.
+constexpr int GS_LPT_MIN_TILES = 2048;   // smaller grids: the 5 us of the order kernel exceed the gain
+__global__ __launch_bounds__(1024) void k_tile_order(const int* __restrict__ cost, int tile0, int nt, int n_grid,
+                                                     int* __restrict__ order) {
+    __shared__ int s_hist[1024];
+    __shared__ int s_max;
+    const int tid = threadIdx.x;
+    s_hist[tid] = 0;
+    if (tid == 0) s_max = 1;
+    __syncthreads();
+    int mx = 0;
+    for (int t = tid; t < nt; t += 1024) mx = max(mx, cost[tile0 + t]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
+    if ((tid & 63) == 0) atomicMax(&s_max, mx);
+    __syncthreads();
+    const float scale = 1023.0f / (float)s_max;
+    auto cls = [&](int t) {   // class 0 = most expensive
+        const int c = (int)((float)max(cost[tile0 + t], 0) * scale);
+        return 1023 - min(c, 1023);
+    };
+    for (int t = tid; t < nt; t += 1024) atomicAdd(&s_hist[cls(t)], 1);
+    __syncthreads();
+    // exclusive scan of the class counts: wave scans + one pass over the 16 wave totals
+    __shared__ int s_wave[16];
+    const int v = s_hist[tid];
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if ((tid & 63) >= d) incl += o;
+    }
+    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < (tid >> 6); w++) off += s_wave[w];
+    s_hist[tid] = off + incl - v;
+    __syncthreads();
+    for (int t = tid; t < nt; t += 1024) order[atomicAdd(&s_hist[cls(t)], 1)] = t;
+    for (int t = nt + tid; t < n_grid; t += 1024) order[t] = -1;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
@@ -364,8 +413,10 @@ __device__ __forceinline__ void render_tile_fwd(
     const T* __restrict__ view_dir, const int* __restrict__ ranges, const int* __restrict__ sorted,
     const T* __restrict__ bg, int W, int H, int ntx, int* __restrict__ nsp_out,
     T* __restrict__ fw_out, T* __restrict__ image, int sort_prefix, int* __restrict__ tile_flags,
-    bool flagged_only, int64_t cap) {
+    bool flagged_only, int64_t cap, int* __restrict__ tile_cost = nullptr) {
     constexpr bool fast = sizeof(T) == 4;
+    // the tile's own duration in 16-cycle units: the launch-order key of the backward (k_tile_order)
+    const unsigned long long cost_c0 = tile_cost ? __builtin_readcyclecounter() : 0ull;
     constexpr int CW = ColW<N_SH>::value;
     constexpr int RCHUNK = Chunk<T, N_SH>::value;
     __shared__ alignas(16) T s_geom[RCHUNK * GS_PACKED_WIDTH];
@@ -378,7 +429,10 @@ __device__ __forceinline__ void render_tile_fwd(
     const int n_tile = ranges[tile + 1] - s0;
     // lists enqueued with a speculative capacity: a segment beyond it was never written (the caller
     // repeats the frame's binning and this render with the exact size)
-    if ((int64_t)s0 + n_tile > cap) return;
+    if ((int64_t)s0 + n_tile > cap) {
+        if (tile_cost != nullptr && tid == 0) tile_cost[tile] = 0;
+        return;
+    }
     // prefix mode (binning.hip "prefix sort"): only the first sort_prefix entries are there
     const bool prefix_only = !flagged_only && prefix_sorted_tile(n_tile, sort_prefix);
     const int n_list = prefix_only ? sort_prefix : n_tile;
@@ -535,6 +589,8 @@ __device__ __forceinline__ void render_tile_fwd(
         if (all_done) break;
     }
     GS_STAT_FLUSH(0);
+    if (tile_cost != nullptr && tid == 0)
+        tile_cost[tile] = (int)min((__builtin_readcyclecounter() - cost_c0) >> 4, 0x3fffffffull);
     // an unsaturated pixel at the end of the prefix: the tile is redone from its full list
     if (tile_flags != nullptr && !flagged_only && tid == 0) tile_flags[tile] = prefix_only && !all_done;
 
@@ -557,11 +613,12 @@ __global__ __launch_bounds__(RB) void k_render_fwd(
     const T* __restrict__ packed, const T* __restrict__ rgb, const T* __restrict__ view_dir,
     const int* __restrict__ ranges, const int* __restrict__ sorted, const T* __restrict__ bg,
     int W, int H, int ntx, int tile0, int nt, int* __restrict__ nsp_out, T* __restrict__ fw_out,
-    T* __restrict__ image, int sort_prefix, int* __restrict__ tile_flags, int64_t cap) {
+    T* __restrict__ image, int sort_prefix, int* __restrict__ tile_flags, int64_t cap,
+    int* __restrict__ tile_cost) {
     const int t_local = tile_of_block(blockIdx.x, nt);
     if (t_local >= nt) return;
     render_tile_fwd<T, N_SH>(tile0 + t_local, packed, rgb, view_dir, ranges, sorted, bg, W, H, ntx,
-                             nsp_out, fw_out, image, sort_prefix, tile_flags, false, cap);
+                             nsp_out, fw_out, image, sort_prefix, tile_flags, false, cap, tile_cost);
 }
 
 // repair pass of the prefix mode: a small grid walks the flags and renders the flagged tiles again,
@@ -570,11 +627,11 @@ __global__ __launch_bounds__(RB) void k_render_fwd_flagged(
     const float* __restrict__ packed, const float* __restrict__ rgb, const int* __restrict__ ranges,
     const int* __restrict__ sorted, const float* __restrict__ bg, int W, int H, int ntx, int tile0,
     int nt, int* __restrict__ nsp_out, float* __restrict__ fw_out, float* __restrict__ image,
-    int* __restrict__ tile_flags, int64_t cap) {
+    int* __restrict__ tile_flags, int64_t cap, int* __restrict__ tile_cost) {
     for (int t = blockIdx.x; t < nt; t += gridDim.x) {
         if (tile_flags[tile0 + t] == 0) continue;
         render_tile_fwd<float, 1>(tile0 + t, packed, rgb, nullptr, ranges, sorted, bg, W, H, ntx,
-                                  nsp_out, fw_out, image, 0, tile_flags, true, cap);
+                                  nsp_out, fw_out, image, 0, tile_flags, true, cap, tile_cost);
         __syncthreads();
     }
 }
@@ -728,7 +785,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     const int* __restrict__ ranges, const int* __restrict__ sorted, const T* __restrict__ bg,
     const int* __restrict__ nsp_in, const T* __restrict__ fw_in, const T* __restrict__ grad_image,
     int W, int H, int ntx, int tile0, int nt, T* __restrict__ g_rgb, T* __restrict__ g_opa,
-    T* __restrict__ g_uv, T* __restrict__ g_conic, int slab, int exact) {
+    T* __restrict__ g_uv, T* __restrict__ g_conic, int slab, int exact, const int* __restrict__ tile_order) {
     constexpr bool fast = sizeof(T) == 4;
     constexpr int CW = ColW<N_SH>::value;
     constexpr int C = 3 * N_SH;
@@ -749,8 +806,8 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     __shared__ unsigned long long s_mask[4][NWORD];
     __shared__ unsigned long long s_hit[SLOTS ? 4 : 1][NWORD];   // SLOTS: slots written by each wave
 
-    const int t_local = tile_of_block(blockIdx.x, nt);
-    if (t_local >= nt) return;
+    const int t_local = tile_order ? tile_order[blockIdx.x] : tile_of_block(blockIdx.x, nt);
+    if (t_local < 0 || t_local >= nt) return;
     const int tile = tile0 + t_local;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const PixelMap px = pixel_of_thread(tile % ntx, tile / ntx, tid);
@@ -1226,7 +1283,7 @@ int gs_render_tiles(const void* packed, const void* rgb, const void* view_dir_by
                                             sorted_gaussians, (const T*)background_rgb, W, H, ntx,
                                             tile_row0 * ntx, nt, num_splats_per_pixel,
                                             (T*)final_weight_per_pixel, (T*)image, 0,
-                                            nullptr, INT64_MAX))));
+                                            nullptr, INT64_MAX, nullptr))));
     return check_launch("render_tiles");
 }
 
@@ -1234,7 +1291,7 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
                            int32_t* sorted_gaussians, const uint64_t* keys, int64_t S,
                            const void* background_rgb, int W, int H, int tile_row0, int tile_row1,
                            int32_t* tile_flags, int32_t* num_splats_per_pixel,
-                           void* final_weight_per_pixel, void* image, void* stream) {
+                           void* final_weight_per_pixel, void* image, int32_t* tile_cost, void* stream) {
     GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
     GS_REQUIRE(tile_flags != nullptr, "tile_flags must not be null");
     if (int e = check_rows(H, tile_row0, tile_row1)) return e;
@@ -1248,14 +1305,14 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
     k_render_fwd<float, 1><<<grid, RB, 0, s>>>(
         (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
         (const float*)background_rgb, W, H, ntx, t0, nt, num_splats_per_pixel,
-        (float*)final_weight_per_pixel, (float*)image, GS_SORT_PREFIX, tile_flags, S);
+        (float*)final_weight_per_pixel, (float*)image, GS_SORT_PREFIX, tile_flags, S, tile_cost);
     if (S > GS_SORT_PREFIX) {
         // 2. + 3. flagged tiles: full sort, render again (no-ops on a dense scene)
         sort_flagged_tiles(tile_ranges, keys, sorted_gaussians, t0, nt, S, tile_flags, s);
         k_render_fwd_flagged<<<nt < 512 ? nt : 512, RB, 0, s>>>(
             (const float*)packed, (const float*)rgb, tile_ranges, sorted_gaussians,
             (const float*)background_rgb, W, H, ntx, t0, nt, num_splats_per_pixel,
-            (float*)final_weight_per_pixel, (float*)image, tile_flags, S);
+            (float*)final_weight_per_pixel, (float*)image, tile_flags, S, tile_cost);
     }
     return check_launch("render_tiles_prefix");
 }
@@ -1281,7 +1338,7 @@ int gs_render_tiles_backward(const void* packed, const void* rgb, const void* vi
                                      num_splats_per_pixel, (const T*)final_weight_per_pixel,
                                      (const T*)grad_image, W, H, ntx, tile_row0 * ntx, nt,
                                      (T*)grad_rgb, (T*)grad_opacity, (T*)grad_uv,
-                                     (T*)grad_conic, 0, g_backward_mode))));
+                                     (T*)grad_conic, 0, g_backward_mode, nullptr))));
     return check_launch("render_tiles_backward");
 }
 
@@ -1290,19 +1347,22 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
                                   const int32_t* num_splats_per_pixel,
                                   const void* final_weight_per_pixel, const void* grad_image, int W,
                                   int H, int tile_row0, int tile_row1, void* grad_slab,
-                                  void* stream) {
+                                  const int32_t* tile_cost, int32_t* tile_order, void* stream) {
     GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
+    GS_REQUIRE((tile_cost == nullptr) == (tile_order == nullptr), "tile_cost and tile_order go together");
     if (int e = check_rows(H, tile_row0, tile_row1)) return e;
     hipStream_t s = (hipStream_t)stream;
     const int ntx = (W + 15) / 16;
     const int nt = (tile_row1 - tile_row0) * ntx;
     if (nt == 0) return GS_OK;
     const int grid = render_grid(nt);
+    const bool ordered = tile_cost != nullptr && nt >= GS_LPT_MIN_TILES;
+    if (ordered) k_tile_order<<<1, 1024, 0, s>>>(tile_cost, tile_row0 * ntx, nt, grid, tile_order);
     k_render_bwd<float, 1><<<grid, RB, 0, s>>>(
         (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
         (const float*)background_rgb, num_splats_per_pixel, (const float*)final_weight_per_pixel,
         (const float*)grad_image, W, H, ntx, tile_row0 * ntx, nt, (float*)grad_slab, nullptr,
-        nullptr, nullptr, 1, g_backward_mode);
+        nullptr, nullptr, 1, g_backward_mode, ordered ? tile_order : nullptr);
     return check_launch("render_tiles_backward_slab");
 }
 

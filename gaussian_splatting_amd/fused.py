@@ -294,8 +294,10 @@ def preprocess_backward(xyz, quaternion, scale, camera_T_world, K, f, slab, v_ba
 
 def render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, width, tile_rows, sort_prefix,
                    image_rows=None):
-    """-> image, splat counts, final weights.  image_rows > height: the image buffer gets that many
-    rows (the multi-GPU gather wants equal-sized bands); the kernels only see the first `height`."""
+    """-> image, splat counts, final weights, tile costs.  image_rows > height: the image buffer gets that
+    many rows (the multi-GPU gather wants equal-sized bands); the kernels only see the first `height`.
+    tile costs: int32[n_tiles], how long each tile took (prefix mode; empty otherwise) -- the launch-order
+    hint render_backward hands back to the library."""
     dev = packed.device
     ntx = (width + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
     nty = (height + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
@@ -313,28 +315,36 @@ def render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, 
     if sort_prefix and sorted_g.shape[0] > sort_prefix:
         # provisional render from the ordered prefixes; tiles that ran out of prefix are flagged,
         # sorted in full and rendered again -- one call, the host never looks at the flags
-        flags = torch.empty(ntx * nty, dtype=torch.int32, device=dev)
+        scratch = torch.empty(2 * ntx * nty, dtype=torch.int32, device=dev)
+        flags, cost = scratch[:ntx * nty], scratch[ntx * nty:]
         _hip.call("gs_render_tiles_prefix", _p(packed), _p(rgb), _p(ranges), _p(sorted_g), _p(keys),
                   ctypes.c_int64(sorted_g.shape[0]), _p(background_rgb), width, height, row0, row1, _p(flags),
-                  _p(nsp), _p(fw), _p(image), stream)
+                  _p(nsp), _p(fw), _p(image), _p(cost), stream)
         global last_tile_flags
         last_tile_flags = flags
         if len(_flag_log) < 512:
             _flag_log.append(flags)
     else:
+        cost = torch.empty(0, dtype=torch.int32, device=dev)
         _hip.call("gs_render_tiles", _p(packed), _p(rgb), None, _p(ranges), _p(sorted_g), _p(background_rgb),
                   width, height, 1, row0, row1, _p(nsp), _p(fw), _p(image), _hip.GS_F32, stream)
-    return image, nsp, fw
+    return image, nsp, fw, cost
 
 
 def render_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, grad_image, height, width, tile_rows,
-                    V):
-    """-> the slab [V, 9] of accumulated render gradients (rgb 3 | opacity 1 | uv 2 | conic 3)"""
+                    V, tile_cost=None):
+    """-> the slab [V, 9] of accumulated render gradients (rgb 3 | opacity 1 | uv 2 | conic 3).
+    tile_cost: render_forward's fourth output (the tiles are then started longest-first)"""
     nty = (height + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
     row0, row1 = tile_rows if tile_rows is not None else (0, nty)
     slab = torch.zeros(max(V, 1), SLAB_WIDTH, dtype=torch.float32, device=packed.device)
+    cost = order = None
+    if tile_cost is not None and tile_cost.numel() > 0:
+        cost = tile_cost
+        order = torch.empty(tile_cost.numel() + 8, dtype=torch.int32, device=packed.device)
     _hip.call("gs_render_tiles_backward_slab", _p(packed), _p(rgb), _p(ranges), _p(sorted_g), _p(background_rgb),
-              _p(nsp), _p(fw), _p(grad_image), width, height, row0, row1, _p(slab), _stream())
+              _p(nsp), _p(fw), _p(grad_image), width, height, row0, row1, _p(slab),
+              _p(cost) if cost is not None else None, _p(order) if order is not None else None, _stream())
     return slab[:V]
 
 
@@ -399,10 +409,10 @@ class _Render(torch.autograd.Function):
     @staticmethod
     def forward(ctx, uv, conic, opacity, rgb, packed, ranges, sorted_g, background_rgb, height, width, tile_rows,
                 slab_sync=None, keys=None, sort_prefix=0, rendered=None):
-        # rendered: (image, nsp, fw) when _Preprocess.forward already enqueued this node's kernels
-        image, nsp, fw = rendered if rendered else render_forward(
+        # rendered: (image, nsp, fw, cost) when _Preprocess.forward already enqueued this node's kernels
+        image, nsp, fw, cost = rendered if rendered else render_forward(
             packed, rgb, ranges, sorted_g, keys, background_rgb, height, width, tile_rows, sort_prefix)
-        ctx.save_for_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw)
+        ctx.save_for_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, cost)
         ctx.set_materialize_grads(False)
         ctx.dims = (height, width, tile_rows, uv.shape[0])
         ctx.slab_sync = slab_sync
@@ -410,12 +420,12 @@ class _Render(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_image):
-        packed, rgb, ranges, sorted_g, background_rgb, nsp, fw = ctx.saved_tensors
+        packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, cost = ctx.saved_tensors
         height, width, tile_rows, V = ctx.dims
         if grad_image is None:
             return (None,) * 15
         slab = render_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, grad_image.contiguous(),
-                               height, width, tile_rows, V)
+                               height, width, tile_rows, V, cost)
         if ctx.slab_sync is not None:
             ctx.slab_sync(slab.view(-1))   # multi-GPU: sum the partial gradients of all bands in place
         # the four gradients are views of the one slab; _Preprocess.backward recognises that

@@ -368,11 +368,11 @@ class _OwnerRender(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, uv, rast, fr, height, width):
-        image, nsp, fw = fr.rendered
+        image, nsp, fw, cost = fr.rendered
         fr.rendered = None
         f = fr.f
         V = f.V
-        ctx.save_for_backward(f.packed, f.rgb_render[:V], f.ranges, f.sorted_g, fr.background, nsp, fw)
+        ctx.save_for_backward(f.packed, f.rgb_render[:V], f.ranges, f.sorted_g, fr.background, nsp, fw, cost)
         ctx.fr, ctx.rast, ctx.dims = fr, rast, (height, width)
         ctx.set_materialize_grads(False)
         return rast.gather(image, height, ranges=f.ranges, ntx=f.ntx)
@@ -382,12 +382,12 @@ class _OwnerRender(torch.autograd.Function):
         from . import fused
         if grad_image is None:
             return (None,) * 5
-        packed, rgb_v, ranges, sorted_g, background_rgb, nsp, fw = ctx.saved_tensors
+        packed, rgb_v, ranges, sorted_g, background_rgb, nsp, fw, cost = ctx.saved_tensors
         fr, rast = ctx.fr, ctx.rast
         f, plan = fr.f, fr.plan
         height, width = ctx.dims
         slab = fused.render_backward(packed, rgb_v, ranges, sorted_g, background_rgb, nsp, fw,
-                                     grad_image.contiguous(), height, width, rast.tile_rows, f.V)
+                                     grad_image.contiguous(), height, width, rast.tile_rows, f.V, cost)
         owned = plan.exchange(slab, group=rast.group, all_to_all=rast.all_to_all)
         rast.last_owned_render_grads = fr.owned_rows = owned
         uv_out = fr.uv_ref() if fr.uv_ref is not None else None

@@ -208,12 +208,14 @@ int gs_render_tiles(const void* packed, const void* rgb, const void* view_dir_by
  * (2) gs_tile_sort_flagged, (3) a second render of the flagged tiles from their full lists.
  * Afterwards every output equals what gs_render_tiles gives on fully sorted lists, and the
  * segments of the flagged tiles in sorted_gaussians are fully sorted (the backward pass reads them).
- * keys, S: as passed to gs_tile_emit_sort.  tile_flags: int32[n_tiles] scratch/out. */
+ * keys, S: as passed to gs_tile_emit_sort.  tile_flags: int32[n_tiles] scratch/out.
+ * tile_cost (may be NULL): int32[n_tiles] out, the time each tile of [tile_row0, tile_row1) took to render
+ * (16-shader-cycle units) -- a scheduling hint for gs_render_tiles_backward_slab, no effect on any result. */
 int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* tile_ranges,
                            int32_t* sorted_gaussians, const uint64_t* keys, int64_t S,
                            const void* background_rgb, int W, int H, int tile_row0, int tile_row1,
                            int32_t* tile_flags, int32_t* num_splats_per_pixel,
-                           void* final_weight_per_pixel, void* image, void* stream);
+                           void* final_weight_per_pixel, void* image, int32_t* tile_cost, void* stream);
 /* render_tiles_backward_cuda (bindings.cpp:120; render_backward.cu:12-595).
  * grad_rgb[V,3,n_sh], grad_opacity[V,1], grad_uv[V,2], grad_conic[V,3] are accumulated.
  * Bug-compatible with render_backward.cu:185 by default; see gs_set_backward_mode. */
@@ -226,13 +228,16 @@ int gs_render_tiles_backward(const void* packed, const void* rgb, const void* vi
                              void* stream);
 /* The fused renderer's form of the above (fp32, n_sh == 1): the four gradients of a Gaussian are
  * accumulated into one row of grad_slab[V, 9] = (rgb 3 | opacity 1 | uv 2 | conic 3), which must be
- * zero-initialised (or hold values to accumulate onto). */
+ * zero-initialised (or hold values to accumulate onto).
+ * tile_cost / tile_order (both NULL, or both given): with the costs gs_render_tiles_prefix measured and an
+ * int32[n_tiles + 8] workspace, the tiles' workgroups are started longest-first (shorter drain at the end of
+ * the kernel; grids below 2048 tiles keep the natural order).  The gradients do not depend on it. */
 int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int32_t* tile_ranges,
                                   const int32_t* sorted_gaussians, const void* background_rgb,
                                   const int32_t* num_splats_per_pixel,
                                   const void* final_weight_per_pixel, const void* grad_image, int W,
                                   int H, int tile_row0, int tile_row1, void* grad_slab,
-                                  void* stream);
+                                  const int32_t* tile_cost, int32_t* tile_order, void* stream);
 /* Gradient mode of the render backward (both entry points above; process-wide, default COMPAT).
  *   GS_BACKWARD_COMPAT  the reference's arithmetic, including render_backward.cu:185: the transmittance is
  *                       divided back by (1 - alpha) only while the CHUNK-LOCAL splat index is below

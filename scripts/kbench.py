@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--check", default="")
     ap.add_argument("--full", action="store_true", help="also time preprocess / binning / per-Gaussian backward")
     ap.add_argument("--tag", default="")
+    ap.add_argument("--natural-order", action="store_true", help="backward without the longest-first tile order")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     _hip.lib()
@@ -52,23 +53,23 @@ def main():
     def fwd():
         return fused.render_forward(f.packed, rgb_v, f.ranges, f.sorted_g, f.keys, bg, H, W, None, _hip.GS_SORT_PREFIX)
 
-    def bwd(nsp, fw):
-        return fused.render_backward(f.packed, rgb_v, f.ranges, f.sorted_g, bg, nsp, fw, gi, H, W, None, V)
+    def bwd(nsp, fw, cost=None):
+        return fused.render_backward(f.packed, rgb_v, f.ranges, f.sorted_g, bg, nsp, fw, gi, H, W, None, V, cost)
 
-    image, nsp, fw = fwd()
-    slab = bwd(nsp, fw)
+    image, nsp, fw, cost = fwd()
+    slab = bwd(nsp, fw, None if args.natural_order else cost)
     torch.cuda.synchronize()
     for _ in range(3):
-        image, nsp, fw = fwd()
-        slab = bwd(nsp, fw)
+        image, nsp, fw, cost = fwd()
+        slab = bwd(nsp, fw, None if args.natural_order else cost)
     torch.cuda.synchronize()
     _hip.reserve_events(2 * 16 * args.reps)
     _hip.enable_timing(True)
     for _ in range(args.reps):
         if args.full:
             f2 = stage1()
-        image, nsp, fw = fwd()
-        slab = bwd(nsp, fw)
+        image, nsp, fw, cost = fwd()
+        slab = bwd(nsp, fw, None if args.natural_order else cost)
         if args.full:
             fused.preprocess_backward(g.xyz, g.quaternion, g.scale, T, cam.K, f, slab)
     timing = _hip.collect_timing()
