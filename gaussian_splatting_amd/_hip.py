@@ -101,11 +101,16 @@ def reserve_events(n):
         p.reserve_events(n)
 
 
-def enable_timing(on=True):
-    global _timers
+_only = None   # name of the one entry point to time, or None for all
+
+
+def enable_timing(on=True, only=None):
+    """only: time just this entry point (two events per frame instead of two per C-ABI call)"""
+    global _timers, _only
     _timers = {} if on else None
+    _only = only if on else None
     for p in timing_providers:
-        p.enable_timing(bool(on))
+        p.enable_timing(bool(on), only or "")
 
 
 def collect_timing():
@@ -130,7 +135,7 @@ def collect_timing():
 def timed_region(name, fn):
     """run fn() and, when timing is enabled, book its GPU time (events on the current stream) under
     `name` next to the C-ABI entry points -- used for the RCCL collectives of the multi-GPU frame"""
-    if _timers is None:
+    if _timers is None or (_only is not None and _only != name):
         return fn()
     a, b = _event(), _event()
     a.record()
@@ -142,7 +147,7 @@ def timed_region(name, fn):
 
 def call(name, *args):
     fn = getattr(lib(), name)
-    if _timers is None:
+    if _timers is None or (_only is not None and _only != name):
         check(fn(*args))
         return
     a, b = _event(), _event()

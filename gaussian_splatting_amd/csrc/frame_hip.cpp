@@ -62,6 +62,7 @@ bool g_sort_prefix = true, g_early_render = true;
 // elapsed time of one entry point is the GPU time of the kernels it enqueues
 struct Timing {
     bool on = false;
+    std::string only;   // non-empty: only this entry point is timed
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> spans;
     std::vector<hipEvent_t> pool;
     hipEvent_t get() {
@@ -77,7 +78,7 @@ struct Timing {
 } g_timing;
 
 template <typename F> void timed(const char* name, void* stream, F&& call) {
-    if (!g_timing.on) {
+    if (!g_timing.on || (!g_timing.only.empty() && g_timing.only != name)) {
         ok(call());
         return;
     }
@@ -460,9 +461,10 @@ c10::optional<Tensor> last_tile_flags(bool clear) {
     return out;
 }
 
-void enable_timing(bool on) {
+void enable_timing(bool on, const std::string& only) {
     std::lock_guard<std::mutex> lock(g_mutex);
     g_timing.on = on;
+    g_timing.only = only;
 }
 
 void reserve_events(int64_t n) {
@@ -510,7 +512,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("reset_counters", &reset_counters);
     m.def("set_modes", &set_modes, py::arg("sort_prefix"), py::arg("early_render"));
     m.def("last_tile_flags", &last_tile_flags, py::arg("clear") = false);
-    m.def("enable_timing", &enable_timing);
+    m.def("enable_timing", &enable_timing, py::arg("on"), py::arg("only") = std::string());
     m.def("reserve_events", &reserve_events);
     m.def("collect_timing", &collect_timing);
 }

@@ -10,9 +10,9 @@
 // The reference runs a batched 4x4 matmul, ~10 boolean-mask gathers, a cat and six kernels with
 // host synchronisations in between.
 //
-//   k_camera_center   camera centre = -A^-1 t of camera_T_world (fp64, one thread); the reference
-//                     takes torch.inverse() on the host side (rasterize.py:92)
-//   k_cull_count      cull predicate per Gaussian, per-workgroup survivor counts
+//   k_cull_count      cull predicate per Gaussian, per-workgroup survivor counts; its first thread also
+//                     leaves the camera centre = -A^-1 t of camera_T_world (fp64; the reference takes
+//                     torch.inverse() on the host side, rasterize.py:92) for k_preprocess
 //   k_scan_counts     exclusive prefix over workgroups (+ total V)
 //   k_preprocess      recompute the predicate, rank survivors (wave ballot + prefix), compute and
 //                     write everything at the compacted index
@@ -35,8 +35,7 @@ struct Frustum {
     float near, far, u_lo, u_hi, v_lo, v_hi;   // rasterize.py:33-49, compared in fp32
 };
 
-__global__ void k_camera_center(const float* __restrict__ M, float* __restrict__ center) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ inline void camera_center(const float* __restrict__ M, float* __restrict__ center) {
     const double a = M[0], b = M[1], c = M[2], d = M[4], e = M[5], f = M[6], g = M[8], h = M[9],
                  i = M[10];
     const double tx = M[3], ty = M[7], tz = M[11];
@@ -68,9 +67,11 @@ __device__ inline bool is_culled(const float* c, const float* __restrict__ K, co
 __global__ __launch_bounds__(PP_BLOCK) void k_cull_count(const float* __restrict__ xyz,
                                                          const float* __restrict__ M,
                                                          const float* __restrict__ K, int N,
-                                                         Frustum fr, int* __restrict__ block_counts) {
+                                                         Frustum fr, int* __restrict__ block_counts,
+                                                         float* __restrict__ center) {
     __shared__ int s_cnt[PP_BLOCK / GS_WAVE];
     const int g = blockIdx.x * PP_BLOCK + threadIdx.x;
+    if (g == 0) camera_center(M, center);
     bool vis = false;
     if (g < N) {
         float c[3], uv[2];
@@ -444,9 +445,8 @@ int gs_preprocess_forward(const void* xyz, const void* quaternion, const void* s
     const int nb = div_up(N > 0 ? N : 1, PP_BLOCK);
     int* block_counts = workspace;
     int* block_offsets = workspace + nb;
-    k_camera_center<<<1, 64, 0, s>>>((const float*)camera_T_world, (float*)camera_center);
     k_cull_count<<<nb, PP_BLOCK, 0, s>>>((const float*)xyz, (const float*)camera_T_world,
-                                         (const float*)K, N, fr, block_counts);
+                                         (const float*)K, N, fr, block_counts, (float*)camera_center);
     k_scan_counts<<<1, 1024, 0, s>>>(block_counts, nb, block_offsets, visible_count);
     PreOut o;
     o.uv = (float*)uv;

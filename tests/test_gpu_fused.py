@@ -540,3 +540,49 @@ def test_end_to_end_difference_is_flipped_threshold_decisions(N, W, H, deg, seed
                max_scaled_input_diff=max(input_diff.values()), grad_scaled_err_unflipped=max(errs.values()))
     finally:
         backend.use(splat_cuda)
+
+
+def test_backward_longest_first_tile_order():
+    """gs_render_tiles_backward_slab with the forward's tile costs: the launch order is a permutation of the
+    tiles by non-increasing cost class, and the gradients are those of the natural order (the atomics'
+    summation order is the only difference)"""
+    import ctypes
+
+    from gaussian_splatting_amd import _hip
+    N, W, H = 60000, 1024, 592                       # 64 x 37 = 2368 tiles (>= 2048: the order is used)
+    g, cam, T = make_scene(N, W, H, 0, seed=5, device=DEV)
+    bg = torch.zeros(3, device=DEV)
+    gi = make_grad_image(W, H, seed=6, device=DEV)
+    f = fused.preprocess_forward(g.xyz, g.quaternion, g.scale, g.opacity, g.rgb, g.sh, T, cam.K, W, H, 0.3, 500.0, 100,
+                                 3.0, None, _hip.GS_SORT_PREFIX)
+    V = f.V
+    rgb_v = f.rgb_render[:V]
+    image, nsp, fw, cost = fused.render_forward(f.packed, rgb_v, f.ranges, f.sorted_g, f.keys, bg, H, W, None,
+                                                _hip.GS_SORT_PREFIX)
+    nt = ((W + 15) // 16) * ((H + 15) // 16)
+    assert cost.shape == (nt,) and int(cost.min()) > 0
+    natural = fused.render_backward(f.packed, rgb_v, f.ranges, f.sorted_g, bg, nsp, fw, gi, H, W, None, V)
+    ordered = fused.render_backward(f.packed, rgb_v, f.ranges, f.sorted_g, bg, nsp, fw, gi, H, W, None, V, cost)
+    for j in range(9):
+        assert scaled_err(ordered[:, j], natural[:, j]) < 2e-6, j
+    # the order itself
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    order = torch.full((nt + 8,), -7, dtype=torch.int32, device=DEV)
+    slab = torch.zeros(V, 9, device=DEV)
+    _hip.call("gs_render_tiles_backward_slab", p(f.packed), p(rgb_v), p(f.ranges), p(f.sorted_g), p(bg), p(nsp), p(fw),
+              p(gi), W, H, 0, (H + 15) // 16, p(slab), p(cost), p(order),
+              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    o = order.cpu()
+    assert sorted(o[:nt].tolist()) == list(range(nt))
+    n_grid = (nt + 7) // 8 * 8                       # the launch grid: entries [nt, n_grid) are idle blocks
+    assert (o[nt:n_grid] == -1).all() and (o[n_grid:] == -7).all()
+    c = cost.cpu()[o[:nt].long()].float()
+    cls = (c * (1023.0 / float(cost.max()))).int()    # the kernel's cost classes
+    assert (cls[1:] <= cls[:-1]).all()
+    assert scaled_err(slab, natural) < 2e-6
+    # cost without order (or the reverse) is refused
+    with pytest.raises(RuntimeError, match="go together"):
+        _hip.call("gs_render_tiles_backward_slab", p(f.packed), p(rgb_v), p(f.ranges), p(f.sorted_g), p(bg), p(nsp),
+                  p(fw), p(gi), W, H, 0, (H + 15) // 16, p(slab), p(cost), None,
+                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
