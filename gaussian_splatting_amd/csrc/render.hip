@@ -134,7 +134,7 @@ template <> __host__ __device__ constexpr int ref_chunk<double>(int n_sh) {
 #define GS_XCD_SEG 0
 #endif
 __host__ __device__ inline int render_grid(int nt) {
-#if GS_XCD_SEG > 0
+#if GS_XCD_SEG > 0   // (experiment builds only: k_tile_order assumes the contiguous eighths)
     const int nseg = (nt + GS_XCD_SEG - 1) / GS_XCD_SEG;
     return ((nseg + 7) / 8) * GS_XCD_SEG * 8;
 #else
@@ -358,16 +358,22 @@ __device__ __forceinline__ void lds_record_fetch(LdsRecord& r, const float* rec)
 // (scripts/render_timeline.py).  Started longest-first, the tiles that finish last are the short ones.
 // The forward measures each tile's own duration (shader clock; the backward of a tile is slow where its
 // forward was: same lists, same hit pattern, correlation 0.7) and k_tile_order turns the costs into a
-// launch order with a counting sort on 1024 cost classes; consecutive entries go to different XCDs, which
-// also evens out their totals.  Only the start order changes, no result does.
-constexpr int GS_LPT_MIN_TILES = 2048;   // smaller grids: the 5 us of the order kernel exceed the gain
+// launch order.  Every XCD keeps its contiguous eighth of the frame (tile_of_block: neighbouring tiles
+// add to the same Gaussians' rows, and with one L2 per XCD a frame-wide order doubled the kernel's HBM
+// traffic, 194 -> 405 MB): the order is longest-first WITHIN each eighth -- a counting sort on
+// 8 x 128 (eighth, cost class) bins -- and block b = 8 j + x starts the j-th tile of eighth x.
+// Only the start order changes, no result does.
+constexpr int GS_LPT_MIN_TILES = 2048;   // smaller grids: the 6 us of the order kernel exceed the gain
 __global__ __launch_bounds__(1024) void k_tile_order(const int* __restrict__ cost, int tile0, int nt, int n_grid,
                                                      int* __restrict__ order) {
     __shared__ int s_hist[1024];
+    __shared__ int s_wave[16];
     __shared__ int s_max;
     const int tid = threadIdx.x;
+    const int per = n_grid >> 3;   // tiles per XCD (render_grid / tile_of_block with GS_XCD_SEG == 0)
     s_hist[tid] = 0;
     if (tid == 0) s_max = 1;
+    for (int b = tid; b < n_grid; b += 1024) order[b] = -1;
     __syncthreads();
     int mx = 0;
     for (int t = tid; t < nt; t += 1024) mx = max(mx, cost[tile0 + t]);
@@ -375,15 +381,14 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int* __restrict__ cos
     for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
     if ((tid & 63) == 0) atomicMax(&s_max, mx);
     __syncthreads();
-    const float scale = 1023.0f / (float)s_max;
-    auto cls = [&](int t) {   // class 0 = most expensive
+    const float scale = 127.0f / (float)s_max;
+    auto bin_of = [&](int t) {   // class 0 = most expensive
         const int c = (int)((float)max(cost[tile0 + t], 0) * scale);
-        return 1023 - min(c, 1023);
+        return (t / per) * 128 + 127 - min(c, 127);
     };
-    for (int t = tid; t < nt; t += 1024) atomicAdd(&s_hist[cls(t)], 1);
+    for (int t = tid; t < nt; t += 1024) atomicAdd(&s_hist[bin_of(t)], 1);
     __syncthreads();
-    // exclusive scan of the class counts: wave scans + one pass over the 16 wave totals
-    __shared__ int s_wave[16];
+    // exclusive scan of the bin counts: wave scans + one pass over the 16 wave totals
     const int v = s_hist[tid];
     int incl = v;
 #pragma unroll
@@ -397,8 +402,11 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int* __restrict__ cos
     for (int w = 0; w < (tid >> 6); w++) off += s_wave[w];
     s_hist[tid] = off + incl - v;
     __syncthreads();
-    for (int t = tid; t < nt; t += 1024) order[atomicAdd(&s_hist[cls(t)], 1)] = t;
-    for (int t = nt + tid; t < n_grid; t += 1024) order[t] = -1;
+    for (int t = tid; t < nt; t += 1024) {
+        const int x = t / per;
+        const int rank = atomicAdd(&s_hist[bin_of(t)], 1) - x * per;   // the eighths before x are full
+        order[rank * 8 + x] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -544,8 +544,8 @@ def test_end_to_end_difference_is_flipped_threshold_decisions(N, W, H, deg, seed
 
 def test_backward_longest_first_tile_order():
     """gs_render_tiles_backward_slab with the forward's tile costs: the launch order is a permutation of the
-    tiles by non-increasing cost class, and the gradients are those of the natural order (the atomics'
-    summation order is the only difference)"""
+    tiles, by non-increasing cost class within each XCD's eighth of the frame, and the gradients are those of
+    the natural order (the atomics' summation order is the only difference)"""
     import ctypes
 
     from gaussian_splatting_amd import _hip
@@ -574,12 +574,17 @@ def test_backward_longest_first_tile_order():
               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     o = order.cpu()
-    assert sorted(o[:nt].tolist()) == list(range(nt))
-    n_grid = (nt + 7) // 8 * 8                       # the launch grid: entries [nt, n_grid) are idle blocks
-    assert (o[nt:n_grid] == -1).all() and (o[n_grid:] == -7).all()
-    c = cost.cpu()[o[:nt].long()].float()
-    cls = (c * (1023.0 / float(cost.max()))).int()    # the kernel's cost classes
-    assert (cls[1:] <= cls[:-1]).all()
+    n_grid = (nt + 7) // 8 * 8                       # the launch grid; block 8 j + x is the j-th tile of XCD x
+    per = n_grid // 8
+    assert sorted(t for t in o[:n_grid].tolist() if t >= 0) == list(range(nt)) and (o[n_grid:] == -7).all()
+    for x in range(8):
+        mine = o[x:n_grid:8]
+        tiles = mine[mine >= 0]
+        assert (mine[len(tiles):] == -1).all()                      # idle blocks come last
+        assert ((tiles // per) == x).all()                          # the XCD keeps its contiguous eighth
+        c = cost.cpu()[tiles.long()].float()
+        cls = (c * (127.0 / float(cost.max()))).int()               # the kernel's cost classes
+        assert (cls[1:] <= cls[:-1]).all()
     assert scaled_err(slab, natural) < 2e-6
     # cost without order (or the reverse) is refused
     with pytest.raises(RuntimeError, match="go together"):
