@@ -101,12 +101,11 @@ void render_tiles_cuda(torch::Tensor uvs, torch::Tensor opacity, torch::Tensor r
     const int nty = (H + 15) / 16;
     TORCH_CHECK(splat_start_end_idx_by_tile_idx.size(0) == (int64_t)((W + 15) / 16) * nty + 1,
                 "splat_start_end_idx_by_tile_idx must have n_tiles + 1 entries");
-    torch::Tensor packed = pack(uvs, opacity, conic, &rgb, dt);
-    ok(gs_render_tiles(packed.data_ptr(), rgb.data_ptr(), view_dir_by_pixel.data_ptr(),
+    ok(gs_render_tiles(uvs.data_ptr(), opacity.data_ptr(), rgb.data_ptr(), conic.data_ptr(), view_dir_by_pixel.data_ptr(),
                        splat_start_end_idx_by_tile_idx.data_ptr<int32_t>(),
-                       gaussian_idx_by_splat_idx.data_ptr<int32_t>(), background_rgb.data_ptr(), W, H, n_sh, 0, nty,
+                       gaussian_idx_by_splat_idx.data_ptr<int32_t>(), background_rgb.data_ptr(),
                        num_splats_per_pixel.data_ptr<int32_t>(), final_weight_per_pixel.data_ptr(),
-                       rendered_image.data_ptr(), dt, cur_stream()));
+                       rendered_image.data_ptr(), W, H, n_sh, 0, nty, dt, cur_stream()));
 }
 
 void render_tiles_backward_cuda(torch::Tensor uvs, torch::Tensor opacity, torch::Tensor rgb, torch::Tensor conic,
@@ -139,13 +138,12 @@ void render_tiles_backward_cuda(torch::Tensor uvs, torch::Tensor opacity, torch:
     SAME_TYPE(dt, background_rgb); SAME_TYPE(dt, final_weight_per_pixel); SAME_TYPE(dt, grad_image);
     SAME_TYPE(dt, grad_rgb); SAME_TYPE(dt, grad_opacity); SAME_TYPE(dt, grad_uvs); SAME_TYPE(dt, grad_conic);
     IS_INT(splat_start_end_idx_by_tile_idx); IS_INT(gaussian_idx_by_splat_idx); IS_INT(num_splats_per_pixel);
-    torch::Tensor packed = pack(uvs, opacity, conic, &rgb, dt);
-    ok(gs_render_tiles_backward(packed.data_ptr(), rgb.data_ptr(), view_dir_by_pixel.data_ptr(),
-                                splat_start_end_idx_by_tile_idx.data_ptr<int32_t>(),
+    ok(gs_render_tiles_backward(uvs.data_ptr(), opacity.data_ptr(), rgb.data_ptr(), conic.data_ptr(),
+                                view_dir_by_pixel.data_ptr(), splat_start_end_idx_by_tile_idx.data_ptr<int32_t>(),
                                 gaussian_idx_by_splat_idx.data_ptr<int32_t>(), background_rgb.data_ptr(),
                                 num_splats_per_pixel.data_ptr<int32_t>(), final_weight_per_pixel.data_ptr(),
-                                grad_image.data_ptr(), W, H, n_sh, 0, nty, grad_rgb.data_ptr(),
-                                grad_opacity.data_ptr(), grad_uvs.data_ptr(), grad_conic.data_ptr(), dt, cur_stream()));
+                                grad_image.data_ptr(), grad_rgb.data_ptr(), grad_opacity.data_ptr(), grad_uvs.data_ptr(),
+                                grad_conic.data_ptr(), W, H, n_sh, 0, nty, dt, cur_stream()));
 }
 
 void render_depth_cuda(torch::Tensor xyz_camera_frame, torch::Tensor uvs, torch::Tensor opacity, torch::Tensor conic,

@@ -169,8 +169,8 @@ RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* 
         // no costs measured: all tiles equal (any launch order is as good as another)
         TORCH_CHECK(hipMemsetAsync(tile_cost, 0, sizeof(int32_t) * (size_t)T, (hipStream_t)stream) == hipSuccess,
                     "hipMemsetAsync failed");
-        timed("gs_render_tiles", stream, [&] {
-            return gs_render_tiles(packed, rgbr, nullptr, ranges, sorted.data_ptr<int32_t>(), bg.data_ptr(), W, H, 1, row0, row1,
+        timed("gs_render_tiles_packed", stream, [&] {
+            return gs_render_tiles_packed(packed, rgbr, nullptr, ranges, sorted.data_ptr<int32_t>(), bg.data_ptr(), W, H, 1, row0, row1,
                                    r.nsp.data_ptr<int32_t>(), r.fw.data_ptr(), r.image.data_ptr(), GS_F32, stream);
         });
     }

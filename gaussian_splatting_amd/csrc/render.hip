@@ -30,7 +30,7 @@
 // operand precisions as render.cu (including its double-literal promotions), IEEE division,
 // det_expf in place of __expf.  Backward forms alpha and the skip decisions bit-identically
 // (render_backward.cu:141-170) and evaluates the gradient formulas in T.
-#include "gs_common.h"
+#include "pg_math.h"
 
 namespace gs {
 
@@ -164,18 +164,34 @@ __device__ inline PixelMap pixel_of_thread(int tile_x, int tile_y, int tid) {
 
 // gather one chunk of splats into LDS: the 12-scalar packed record (three 16-byte loads) and, for
 // N_SH > 1, the [3, N_SH] colour coefficients.  s_idx (optional) keeps the Gaussian indices.
+// src_opacity != nullptr: the splats come as the reference's separate arrays (render_tiles_cuda's
+// uvs / opacity / conic / rgb: `packed` is then uvs[V,2]) and the record is formed here, with the
+// function gs_pack_splats uses -- the same values, no packing pass and no [V,12] buffer for the caller.
 template <typename T, int N_SH>
 __device__ inline void stage_chunk(const T* __restrict__ packed, const T* __restrict__ rgb,
                                    const int* __restrict__ sorted, int first, int count, int tid,
-                                   T* s_geom, T* s_col, int* s_idx) {
+                                   T* s_geom, T* s_col, int* s_idx, const T* __restrict__ src_opacity = nullptr,
+                                   const T* __restrict__ src_conic = nullptr) {
     constexpr int CW = ColW<N_SH>::value;
     if (tid < count) {
         const int g = sorted[first + tid];
-        const Vec4<T>* src = reinterpret_cast<const Vec4<T>*>(packed + (size_t)g * GS_PACKED_WIDTH);
-        Vec4<T>* dst = reinterpret_cast<Vec4<T>*>(s_geom + tid * GS_PACKED_WIDTH);
-        dst[0] = src[0];
-        dst[1] = src[1];
-        dst[2] = src[2];
+        if (src_opacity != nullptr) {
+            const T c3[3] = {src_conic[(size_t)g * 3 + 0], src_conic[(size_t)g * 3 + 1], src_conic[(size_t)g * 3 + 2]};
+            T col[3] = {0, 0, 0};
+            if constexpr (N_SH == 1) {
+                col[0] = rgb[(size_t)g * 3 + 0]; col[1] = rgb[(size_t)g * 3 + 1]; col[2] = rgb[(size_t)g * 3 + 2];
+            }
+            T p[GS_PACKED_WIDTH];
+            pack_record<T>(packed[(size_t)g * 2 + 0], packed[(size_t)g * 2 + 1], c3, src_opacity[g], col, p);
+#pragma unroll
+            for (int k = 0; k < GS_PACKED_WIDTH; k++) s_geom[tid * GS_PACKED_WIDTH + k] = p[k];
+        } else {
+            const Vec4<T>* src = reinterpret_cast<const Vec4<T>*>(packed + (size_t)g * GS_PACKED_WIDTH);
+            Vec4<T>* dst = reinterpret_cast<Vec4<T>*>(s_geom + tid * GS_PACKED_WIDTH);
+            dst[0] = src[0];
+            dst[1] = src[1];
+            dst[2] = src[2];
+        }
         if constexpr (N_SH > 1) {
             const T* c = rgb + (size_t)g * 3 * N_SH;
 #pragma unroll
@@ -421,7 +437,8 @@ __device__ __forceinline__ void render_tile_fwd(
     const T* __restrict__ view_dir, const int* __restrict__ ranges, const int* __restrict__ sorted,
     const T* __restrict__ bg, int W, int H, int ntx, int* __restrict__ nsp_out,
     T* __restrict__ fw_out, T* __restrict__ image, int sort_prefix, int* __restrict__ tile_flags,
-    bool flagged_only, int64_t cap, int* __restrict__ tile_cost = nullptr) {
+    bool flagged_only, int64_t cap, int* __restrict__ tile_cost = nullptr,
+    const T* __restrict__ src_opacity = nullptr, const T* __restrict__ src_conic = nullptr) {
     constexpr bool fast = sizeof(T) == 4;
     // the tile's own duration in 16-cycle units: the launch-order key of the backward (k_tile_order)
     const unsigned long long cost_c0 = tile_cost ? __builtin_readcyclecounter() : 0ull;
@@ -476,7 +493,7 @@ __device__ __forceinline__ void render_tile_fwd(
         const int cnt = min(RCHUNK, n_list - base);
         GS_STAT(1, 1);      // chunks
         GS_STAT(8, cnt);    // list entries staged
-        stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, nullptr);
+        stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, nullptr, src_opacity, src_conic);
         __syncthreads();
         GS_PHASE(0);
         build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
@@ -622,11 +639,12 @@ __global__ __launch_bounds__(RB) void k_render_fwd(
     const int* __restrict__ ranges, const int* __restrict__ sorted, const T* __restrict__ bg,
     int W, int H, int ntx, int tile0, int nt, int* __restrict__ nsp_out, T* __restrict__ fw_out,
     T* __restrict__ image, int sort_prefix, int* __restrict__ tile_flags, int64_t cap,
-    int* __restrict__ tile_cost) {
+    int* __restrict__ tile_cost, const T* __restrict__ src_opacity, const T* __restrict__ src_conic) {
     const int t_local = tile_of_block(blockIdx.x, nt);
     if (t_local >= nt) return;
     render_tile_fwd<T, N_SH>(tile0 + t_local, packed, rgb, view_dir, ranges, sorted, bg, W, H, ntx,
-                             nsp_out, fw_out, image, sort_prefix, tile_flags, false, cap, tile_cost);
+                             nsp_out, fw_out, image, sort_prefix, tile_flags, false, cap, tile_cost, src_opacity,
+                             src_conic);
 }
 
 // repair pass of the prefix mode: a small grid walks the flags and renders the flagged tiles again,
@@ -793,7 +811,8 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     const int* __restrict__ ranges, const int* __restrict__ sorted, const T* __restrict__ bg,
     const int* __restrict__ nsp_in, const T* __restrict__ fw_in, const T* __restrict__ grad_image,
     int W, int H, int ntx, int tile0, int nt, T* __restrict__ g_rgb, T* __restrict__ g_opa,
-    T* __restrict__ g_uv, T* __restrict__ g_conic, int slab, int exact, const int* __restrict__ tile_order) {
+    T* __restrict__ g_uv, T* __restrict__ g_conic, int slab, int exact, const int* __restrict__ tile_order,
+    const T* __restrict__ src_opacity, const T* __restrict__ src_conic) {
     constexpr bool fast = sizeof(T) == 4;
     constexpr int CW = ColW<N_SH>::value;
     constexpr int C = 3 * N_SH;
@@ -870,7 +889,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
         const int cnt = min(RCHUNK, n_used - base);
         GS_STAT(1, 1);
         __syncthreads();   // previous chunk fully flushed
-        stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, s_idx);
+        stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, s_idx, src_opacity, src_conic);
         if constexpr (!SLOTS)
             for (int k = tid; k < cnt * NV; k += RB) s_acc[k] = 0;
         __syncthreads();
@@ -1273,11 +1292,11 @@ int gs_debug_render_timeline(unsigned long long* out, int cap_waves) {
 }
 #endif
 
-int gs_render_tiles(const void* packed, const void* rgb, const void* view_dir_by_pixel,
-                    const int32_t* tile_ranges, const int32_t* sorted_gaussians,
-                    const void* background_rgb, int W, int H, int n_sh, int tile_row0,
-                    int tile_row1, int32_t* num_splats_per_pixel, void* final_weight_per_pixel,
-                    void* image, int dtype, void* stream) {
+static int launch_render_fwd(const void* packed_or_uvs, const void* opacity, const void* conic, const void* rgb,
+                             const void* view_dir_by_pixel, const int32_t* tile_ranges,
+                             const int32_t* sorted_gaussians, const void* background_rgb, int W, int H, int n_sh,
+                             int tile_row0, int tile_row1, int32_t* num_splats_per_pixel,
+                             void* final_weight_per_pixel, void* image, int dtype, void* stream) {
     GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
     if (int e = check_rows(H, tile_row0, tile_row1)) return e;
     hipStream_t s = (hipStream_t)stream;
@@ -1286,13 +1305,34 @@ int gs_render_tiles(const void* packed, const void* rgb, const void* view_dir_by
     if (nt == 0) return GS_OK;
     const int grid = render_grid(nt);
     DISPATCH_T(dtype, DISPATCH_SH(n_sh, (k_render_fwd<T, N_SH><<<grid, RB, 0, s>>>(
-                                            (const T*)packed, (const T*)rgb,
+                                            (const T*)packed_or_uvs, (const T*)rgb,
                                             (const T*)view_dir_by_pixel, tile_ranges,
                                             sorted_gaussians, (const T*)background_rgb, W, H, ntx,
                                             tile_row0 * ntx, nt, num_splats_per_pixel,
                                             (T*)final_weight_per_pixel, (T*)image, 0,
-                                            nullptr, INT64_MAX, nullptr))));
+                                            nullptr, INT64_MAX, nullptr, (const T*)opacity, (const T*)conic))));
     return check_launch("render_tiles");
+}
+
+int gs_render_tiles(const void* uvs, const void* opacity, const void* rgb, const void* conic,
+                    const void* view_dir_by_pixel, const int32_t* tile_ranges,
+                    const int32_t* sorted_gaussians, const void* background_rgb,
+                    int32_t* num_splats_per_pixel, void* final_weight_per_pixel, void* image, int W, int H,
+                    int n_sh, int tile_row0, int tile_row1, int dtype, void* stream) {
+    GS_REQUIRE(opacity != nullptr && conic != nullptr, "opacity and conic must not be null");
+    return launch_render_fwd(uvs, opacity, conic, rgb, view_dir_by_pixel, tile_ranges, sorted_gaussians,
+                             background_rgb, W, H, n_sh, tile_row0, tile_row1, num_splats_per_pixel,
+                             final_weight_per_pixel, image, dtype, stream);
+}
+
+int gs_render_tiles_packed(const void* packed, const void* rgb, const void* view_dir_by_pixel,
+                           const int32_t* tile_ranges, const int32_t* sorted_gaussians,
+                           const void* background_rgb, int W, int H, int n_sh, int tile_row0,
+                           int tile_row1, int32_t* num_splats_per_pixel, void* final_weight_per_pixel,
+                           void* image, int dtype, void* stream) {
+    return launch_render_fwd(packed, nullptr, nullptr, rgb, view_dir_by_pixel, tile_ranges, sorted_gaussians,
+                             background_rgb, W, H, n_sh, tile_row0, tile_row1, num_splats_per_pixel,
+                             final_weight_per_pixel, image, dtype, stream);
 }
 
 int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* tile_ranges,
@@ -1313,7 +1353,7 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
     k_render_fwd<float, 1><<<grid, RB, 0, s>>>(
         (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
         (const float*)background_rgb, W, H, ntx, t0, nt, num_splats_per_pixel,
-        (float*)final_weight_per_pixel, (float*)image, GS_SORT_PREFIX, tile_flags, S, tile_cost);
+        (float*)final_weight_per_pixel, (float*)image, GS_SORT_PREFIX, tile_flags, S, tile_cost, nullptr, nullptr);
     if (S > GS_SORT_PREFIX) {
         // 2. + 3. flagged tiles: full sort, render again (no-ops on a dense scene)
         sort_flagged_tiles(tile_ranges, keys, sorted_gaussians, t0, nt, S, tile_flags, s);
@@ -1325,12 +1365,12 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
     return check_launch("render_tiles_prefix");
 }
 
-int gs_render_tiles_backward(const void* packed, const void* rgb, const void* view_dir_by_pixel,
-                             const int32_t* tile_ranges, const int32_t* sorted_gaussians,
-                             const void* background_rgb, const int32_t* num_splats_per_pixel,
-                             const void* final_weight_per_pixel, const void* grad_image, int W,
-                             int H, int n_sh, int tile_row0, int tile_row1, void* grad_rgb,
-                             void* grad_opacity, void* grad_uv, void* grad_conic, int dtype,
+static int launch_render_bwd(const void* packed_or_uvs, const void* opacity, const void* conic, const void* rgb,
+                             const void* view_dir_by_pixel, const int32_t* tile_ranges,
+                             const int32_t* sorted_gaussians, const void* background_rgb,
+                             const int32_t* num_splats_per_pixel, const void* final_weight_per_pixel,
+                             const void* grad_image, int W, int H, int n_sh, int tile_row0, int tile_row1,
+                             void* grad_rgb, void* grad_opacity, void* grad_uv, void* grad_conic, int dtype,
                              void* stream) {
     GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
     if (int e = check_rows(H, tile_row0, tile_row1)) return e;
@@ -1341,13 +1381,39 @@ int gs_render_tiles_backward(const void* packed, const void* rgb, const void* vi
     const int grid = render_grid(nt);
     DISPATCH_T(dtype,
                DISPATCH_SH(n_sh, (k_render_bwd<T, N_SH><<<grid, RB, 0, s>>>(
-                                     (const T*)packed, (const T*)rgb, (const T*)view_dir_by_pixel,
+                                     (const T*)packed_or_uvs, (const T*)rgb, (const T*)view_dir_by_pixel,
                                      tile_ranges, sorted_gaussians, (const T*)background_rgb,
                                      num_splats_per_pixel, (const T*)final_weight_per_pixel,
                                      (const T*)grad_image, W, H, ntx, tile_row0 * ntx, nt,
                                      (T*)grad_rgb, (T*)grad_opacity, (T*)grad_uv,
-                                     (T*)grad_conic, 0, g_backward_mode, nullptr))));
+                                     (T*)grad_conic, 0, g_backward_mode, nullptr, (const T*)opacity,
+                                     (const T*)conic))));
     return check_launch("render_tiles_backward");
+}
+
+int gs_render_tiles_backward(const void* uvs, const void* opacity, const void* rgb, const void* conic,
+                             const void* view_dir_by_pixel, const int32_t* tile_ranges,
+                             const int32_t* sorted_gaussians, const void* background_rgb,
+                             const int32_t* num_splats_per_pixel, const void* final_weight_per_pixel,
+                             const void* grad_image, void* grad_rgb, void* grad_opacity, void* grad_uv,
+                             void* grad_conic, int W, int H, int n_sh, int tile_row0, int tile_row1, int dtype,
+                             void* stream) {
+    GS_REQUIRE(opacity != nullptr && conic != nullptr, "opacity and conic must not be null");
+    return launch_render_bwd(uvs, opacity, conic, rgb, view_dir_by_pixel, tile_ranges, sorted_gaussians,
+                             background_rgb, num_splats_per_pixel, final_weight_per_pixel, grad_image, W, H, n_sh,
+                             tile_row0, tile_row1, grad_rgb, grad_opacity, grad_uv, grad_conic, dtype, stream);
+}
+
+int gs_render_tiles_backward_packed(const void* packed, const void* rgb, const void* view_dir_by_pixel,
+                                    const int32_t* tile_ranges, const int32_t* sorted_gaussians,
+                                    const void* background_rgb, const int32_t* num_splats_per_pixel,
+                                    const void* final_weight_per_pixel, const void* grad_image, int W,
+                                    int H, int n_sh, int tile_row0, int tile_row1, void* grad_rgb,
+                                    void* grad_opacity, void* grad_uv, void* grad_conic, int dtype,
+                                    void* stream) {
+    return launch_render_bwd(packed, nullptr, nullptr, rgb, view_dir_by_pixel, tile_ranges, sorted_gaussians,
+                             background_rgb, num_splats_per_pixel, final_weight_per_pixel, grad_image, W, H, n_sh,
+                             tile_row0, tile_row1, grad_rgb, grad_opacity, grad_uv, grad_conic, dtype, stream);
 }
 
 int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int32_t* tile_ranges,
@@ -1370,7 +1436,7 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
         (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
         (const float*)background_rgb, num_splats_per_pixel, (const float*)final_weight_per_pixel,
         (const float*)grad_image, W, H, ntx, tile_row0 * ntx, nt, (float*)grad_slab, nullptr,
-        nullptr, nullptr, 1, g_backward_mode, ordered ? tile_order : nullptr);
+        nullptr, nullptr, 1, g_backward_mode, ordered ? tile_order : nullptr, nullptr, nullptr);
     return check_launch("render_tiles_backward_slab");
 }
 

@@ -7,7 +7,7 @@ Two autograd nodes instead of six-plus-glue:
 
     _Preprocess   gs_preprocess_forward + tile binning + per-tile sort   (parameters -> uv, conic,
                   opacity, colour; non-differentiable: packed records, tile lists, culling mask)
-    _Render       gs_render_tiles(_prefix) / gs_render_tiles_backward_slab
+    _Render       gs_render_tiles_prefix (_packed) / gs_render_tiles_backward_slab
 
 so `uv` is still an autograd intermediate between two nodes: `uv.retain_grad()` followed by
 `uv.grad` gives the render-backward grad_uv exactly as the trainer expects (trainer.py:360,379).
@@ -326,7 +326,7 @@ def render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, 
             _flag_log.append(flags)
     else:
         cost = torch.empty(0, dtype=torch.int32, device=dev)
-        _hip.call("gs_render_tiles", _p(packed), _p(rgb), None, _p(ranges), _p(sorted_g), _p(background_rgb),
+        _hip.call("gs_render_tiles_packed", _p(packed), _p(rgb), None, _p(ranges), _p(sorted_g), _p(background_rgb),
                   width, height, 1, row0, row1, _p(nsp), _p(fw), _p(image), _hip.GS_F32, stream)
     return image, nsp, fw, cost
 

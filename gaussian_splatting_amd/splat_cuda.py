@@ -294,11 +294,10 @@ def render_tiles_cuda(uvs, opacity, rgb, conic, view_dir_by_pixel, splat_start_e
     _require(splat_start_end_idx_by_tile_idx.shape[0] == ((W + 15) // 16) * nty + 1,
              "splat_start_end_idx_by_tile_idx must have n_tiles + 1 entries")
     row0, row1 = tile_rows if tile_rows is not None else (0, nty)
-    packed = _pack(uvs, opacity, conic, dt, rgb)
-    _hip.call("gs_render_tiles", _p(packed), _p(rgb), _p(view_dir_by_pixel), _p(splat_start_end_idx_by_tile_idx),
-                                     _p(gaussian_idx_by_splat_idx), _p(background_rgb), W, H, n_sh, row0, row1,
-                                     _p(num_splats_per_pixel), _p(final_weight_per_pixel), _p(rendered_image), dt,
-                                     _stream())
+    _hip.call("gs_render_tiles", _p(uvs), _p(opacity), _p(rgb), _p(conic), _p(view_dir_by_pixel),
+              _p(splat_start_end_idx_by_tile_idx), _p(gaussian_idx_by_splat_idx), _p(background_rgb),
+              _p(num_splats_per_pixel), _p(final_weight_per_pixel), _p(rendered_image), W, H, n_sh, row0, row1, dt,
+              _stream())
 
 
 def render_tiles_backward_cuda(uvs, opacity, rgb, conic, view_dir_by_pixel, splat_start_end_idx_by_tile_idx,
@@ -330,12 +329,10 @@ def render_tiles_backward_cuda(uvs, opacity, rgb, conic, view_dir_by_pixel, spla
     _int(splat_start_end_idx_by_tile_idx=splat_start_end_idx_by_tile_idx,
          gaussian_idx_by_splat_idx=gaussian_idx_by_splat_idx, num_splats_per_pixel=num_splats_per_pixel)
     row0, row1 = tile_rows if tile_rows is not None else (0, nty)
-    packed = _pack(uvs, opacity, conic, dt, rgb)
-    _hip.call("gs_render_tiles_backward", 
-        _p(packed), _p(rgb), _p(view_dir_by_pixel), _p(splat_start_end_idx_by_tile_idx),
-        _p(gaussian_idx_by_splat_idx), _p(background_rgb), _p(num_splats_per_pixel), _p(final_weight_per_pixel),
-        _p(grad_image), W, H, n_sh, row0, row1, _p(grad_rgb), _p(grad_opacity), _p(grad_uv), _p(grad_conic), dt,
-        _stream())
+    _hip.call("gs_render_tiles_backward", _p(uvs), _p(opacity), _p(rgb), _p(conic), _p(view_dir_by_pixel),
+              _p(splat_start_end_idx_by_tile_idx), _p(gaussian_idx_by_splat_idx), _p(background_rgb),
+              _p(num_splats_per_pixel), _p(final_weight_per_pixel), _p(grad_image), _p(grad_rgb), _p(grad_opacity),
+              _p(grad_uv), _p(grad_conic), W, H, n_sh, row0, row1, dt, _stream())
 
 
 def render_depth_cuda(xyz_camera_frame, uvs, opacity, conic, splat_start_end_idx_by_tile_idx,

@@ -194,19 +194,29 @@ int gs_preprocess_backward(const void* xyz, const void* quaternion, const void* 
  * uvs[V,2], opacity[V,1], conic[V,3], rgb[V,3] or NULL. */
 int gs_pack_splats(const void* uvs, const void* opacity, const void* conic, const void* rgb, int V,
                    void* packed, int dtype, void* stream);
-/* render_tiles_cuda (bindings.cpp:119; render.cu:8-422).  rgb[V,3,n_sh]; view_dir_by_pixel[H,W,3]
- * (ignored when n_sh==1); background_rgb[3] -> num_splats_per_pixel int32[H,W],
- * final_weight_per_pixel[H,W], image[H,W,3].  `packed` comes from gs_pack_splats. */
-int gs_render_tiles(const void* packed, const void* rgb, const void* view_dir_by_pixel,
-                    const int32_t* tile_ranges, const int32_t* sorted_gaussians,
-                    const void* background_rgb, int W, int H, int n_sh, int tile_row0,
-                    int tile_row1, int32_t* num_splats_per_pixel, void* final_weight_per_pixel,
-                    void* image, int dtype, void* stream);
+/* render_tiles_cuda (bindings.cpp:119; render.cu:8-422), the reference's arguments in the reference's order:
+ * uvs[V,2], opacity[V,1], rgb[V,3,n_sh], conic[V,3], view_dir_by_pixel[H,W,3] (ignored when n_sh==1),
+ * tile_ranges = splat_start_end_idx_by_tile_idx int32[n_tiles+1], sorted_gaussians =
+ * gaussian_idx_by_splat_idx int32[S], background_rgb[3] -> num_splats_per_pixel int32[H,W],
+ * final_weight_per_pixel[H,W], image[H,W,3]; then the sizes the tensors carry in the reference.  The
+ * per-splat record of the render loops is formed while the tile lists are staged (no packing pass). */
+int gs_render_tiles(const void* uvs, const void* opacity, const void* rgb, const void* conic,
+                    const void* view_dir_by_pixel, const int32_t* tile_ranges,
+                    const int32_t* sorted_gaussians, const void* background_rgb,
+                    int32_t* num_splats_per_pixel, void* final_weight_per_pixel, void* image, int W, int H,
+                    int n_sh, int tile_row0, int tile_row1, int dtype, void* stream);
+/* The same from packed records (gs_pack_splats, or the `packed` output of gs_preprocess_forward): one
+ * 48-byte gather per list entry instead of four partial ones -- the form the fused renderer uses. */
+int gs_render_tiles_packed(const void* packed, const void* rgb, const void* view_dir_by_pixel,
+                           const int32_t* tile_ranges, const int32_t* sorted_gaussians,
+                           const void* background_rgb, int W, int H, int n_sh, int tile_row0,
+                           int tile_row1, int32_t* num_splats_per_pixel, void* final_weight_per_pixel,
+                           void* image, int dtype, void* stream);
 /* The same kernel over lists produced with sort_prefix = GS_SORT_PREFIX (fp32, n_sh == 1).
  * Enqueues (1) a provisional render that reads at most the ordered prefix of a prefix-sorted tile
  * and writes tile_flags[t] = 1 if tile t ran out of it with an unsaturated pixel (0 otherwise),
  * (2) gs_tile_sort_flagged, (3) a second render of the flagged tiles from their full lists.
- * Afterwards every output equals what gs_render_tiles gives on fully sorted lists, and the
+ * Afterwards every output equals what gs_render_tiles_packed gives on fully sorted lists, and the
  * segments of the flagged tiles in sorted_gaussians are fully sorted (the backward pass reads them).
  * keys, S: as passed to gs_tile_emit_sort.  tile_flags: int32[n_tiles] scratch/out.
  * tile_cost (may be NULL): int32[n_tiles] out, the time each tile of [tile_row0, tile_row1) took to render
@@ -216,16 +226,24 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
                            const void* background_rgb, int W, int H, int tile_row0, int tile_row1,
                            int32_t* tile_flags, int32_t* num_splats_per_pixel,
                            void* final_weight_per_pixel, void* image, int32_t* tile_cost, void* stream);
-/* render_tiles_backward_cuda (bindings.cpp:120; render_backward.cu:12-595).
- * grad_rgb[V,3,n_sh], grad_opacity[V,1], grad_uv[V,2], grad_conic[V,3] are accumulated.
+/* render_tiles_backward_cuda (bindings.cpp:120; render_backward.cu:12-595), the reference's arguments in the
+ * reference's order.  grad_rgb[V,3,n_sh], grad_opacity[V,1], grad_uv[V,2], grad_conic[V,3] are accumulated.
  * Bug-compatible with render_backward.cu:185 by default; see gs_set_backward_mode. */
-int gs_render_tiles_backward(const void* packed, const void* rgb, const void* view_dir_by_pixel,
-                             const int32_t* tile_ranges, const int32_t* sorted_gaussians,
-                             const void* background_rgb, const int32_t* num_splats_per_pixel,
-                             const void* final_weight_per_pixel, const void* grad_image, int W,
-                             int H, int n_sh, int tile_row0, int tile_row1, void* grad_rgb,
-                             void* grad_opacity, void* grad_uv, void* grad_conic, int dtype,
+int gs_render_tiles_backward(const void* uvs, const void* opacity, const void* rgb, const void* conic,
+                             const void* view_dir_by_pixel, const int32_t* tile_ranges,
+                             const int32_t* sorted_gaussians, const void* background_rgb,
+                             const int32_t* num_splats_per_pixel, const void* final_weight_per_pixel,
+                             const void* grad_image, void* grad_rgb, void* grad_opacity, void* grad_uv,
+                             void* grad_conic, int W, int H, int n_sh, int tile_row0, int tile_row1, int dtype,
                              void* stream);
+/* The same from packed records (see gs_render_tiles_packed). */
+int gs_render_tiles_backward_packed(const void* packed, const void* rgb, const void* view_dir_by_pixel,
+                                    const int32_t* tile_ranges, const int32_t* sorted_gaussians,
+                                    const void* background_rgb, const int32_t* num_splats_per_pixel,
+                                    const void* final_weight_per_pixel, const void* grad_image, int W,
+                                    int H, int n_sh, int tile_row0, int tile_row1, void* grad_rgb,
+                                    void* grad_opacity, void* grad_uv, void* grad_conic, int dtype,
+                                    void* stream);
 /* The fused renderer's form of the above (fp32, n_sh == 1): the four gradients of a Gaussian are
  * accumulated into one row of grad_slab[V, 9] = (rgb 3 | opacity 1 | uv 2 | conic 3), which must be
  * zero-initialised (or hold values to accumulate onto).

@@ -18,13 +18,15 @@ def declared_symbols():
 def test_header_declares_the_boundary():
     names = declared_symbols()
     # one entry point per function of src/bindings.cpp:118-159 (get_sorted_gaussian_list is split
-    # in two, render takes the packed record from gs_pack_splats)
+    # in two; the two render entries take the reference's own argument lists, their _packed forms the
+    # record of gs_pack_splats)
     for n in ["gs_camera_projection", "gs_camera_projection_backward", "gs_compute_sigma_world",
               "gs_compute_sigma_world_backward", "gs_compute_projection_jacobian",
               "gs_compute_projection_jacobian_backward", "gs_compute_conic", "gs_compute_conic_backward",
               "gs_precompute_rgb_from_sh", "gs_precompute_rgb_from_sh_backward", "gs_tile_count", "gs_tile_workspace_ints",
               "gs_preprocess_forward", "gs_preprocess_backward",
               "gs_tile_emit_sort", "gs_pack_splats", "gs_render_tiles", "gs_render_tiles_backward",
+              "gs_render_tiles_packed", "gs_render_tiles_backward_packed",
               "gs_render_depth", "gs_last_error", "gs_abi_version"]:
         assert n in names
 
