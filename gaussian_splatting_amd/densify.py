@@ -246,7 +246,7 @@ class DensityController:
                   N0, _p(dst_self), _p(dst_clone), _p(spl_self), _p(spl_clone), _p(xyz_s), _p(scale_s), _p(quat_s),
                   _p(self.xyz_grad_accum), _p(self.grad_accum_count), _p(random_samples.contiguous()), int(P),
                   int(samples), int(sample_base), ctypes.c_float(cfg.split_scale_factor),
-                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                  _hip.current_stream())
         for k, d, m, v in zip(names, dst, dst_m, dst_v):
             self._swap(k, d, m, v)
         self.reset_grad_accum()

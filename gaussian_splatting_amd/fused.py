@@ -33,8 +33,8 @@ def _p(t):
 
 
 def _stream():
-    # torch.cuda.current_stream() costs ~10 us of host time: every stage asks once and passes it on
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # every stage asks once and passes it on
+    return _hip.current_stream()
 
 
 def _cf(x):

@@ -164,7 +164,7 @@ class HaloPlan:
             _hip.call("gs_halo_gather_sum", ctypes.c_void_p(self.mask.data_ptr()),
                       ctypes.c_void_p(workspace.data_ptr()), N, self.world_size, self.rank, self.v_lo, self.v_hi,
                       ctypes.c_void_p(recv.data_ptr()), offs, ctypes.c_void_p(out.data_ptr()),
-                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                      _hip.current_stream())
             return out
         mine = self.mask[self.v_lo:self.v_hi]
         off = 0

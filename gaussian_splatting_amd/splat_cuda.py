@@ -29,7 +29,7 @@ def _p(t):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _hip.current_stream()
 
 
 def _valid(**tensors):

@@ -57,7 +57,7 @@ class Adam(torch.optim.Adam):
                 grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 work.append((p, grad, state["exp_avg"], state["exp_avg_sq"], float(group["lr"]),
                              int(state["step"]), beta1, beta2, group["eps"]))
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = _hip.current_stream()
         i = 0
         while i < len(work):
             # one launch per run of tensors that share (beta1, beta2, eps): all of them, normally
@@ -103,7 +103,7 @@ def accumulate_grad_stats(uv_grad, culling_mask, xyz_grad, camera, uv_grad_accum
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     _hip.call("gs_accumulate_grad_stats", p(uv_grad), int(uv_grad.stride(0)) if uv_grad.shape[0] else 2, p(rank),
               p(xyz_grad), p(K), N, p(uv_grad_accum), p(xyz_grad_accum),
-              p(grad_accum_count), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+              p(grad_accum_count), _hip.current_stream())
 
 
 class _SsimL1Loss(torch.autograd.Function):
@@ -119,7 +119,7 @@ class _SsimL1Loss(torch.autograd.Function):
         grad = torch.empty_like(image) if need_grad else None
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         _hip.call("gs_ssim_l1_loss", p(image), p(target), H, W, ctypes.c_float(float(ssim_frac)), p(ws), p(out),
-                  p(grad), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                  p(grad), _hip.current_stream())
         ctx.grad = grad
         ctx.mark_non_differentiable(out)
         return out[0], out
