@@ -494,8 +494,8 @@ __device__ __forceinline__ void render_tile_fwd(
         GS_STAT(1, 1);      // chunks
         GS_STAT(8, cnt);    // list entries staged
         stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, nullptr, src_opacity, src_conic);
-        __syncthreads();
         GS_PHASE(0);
+        // (no barrier in between: thread t tests the record thread t staged)
         build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
         __syncthreads();
         GS_PHASE(1);
@@ -892,8 +892,8 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
         stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, s_idx, src_opacity, src_conic);
         if constexpr (!SLOTS)
             for (int k = tid; k < cnt * NV; k += RB) s_acc[k] = 0;
-        __syncthreads();
         GS_PHASE(0);
+        // (no barrier in between: thread t tests the record thread t staged)
         build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
         __syncthreads();
         GS_PHASE(1);
