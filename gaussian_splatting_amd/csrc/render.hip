@@ -101,7 +101,10 @@ __device__ unsigned long long g_timeline[2 * GS_TIMELINE_CAP * GS_TIMELINE_W];
 #define GS_BWD_GROUP 16   // lanes summed with DPP before the LDS atomic (measured: 16 -> 0.90 ms, 64 -> 1.03, 8 -> 1.52)
 #endif
 #ifndef GS_BWD_CHUNK
-#define GS_BWD_CHUNK 128   // splats staged per step by the fused renderer's backward (LDS: 25 KB -> 6 workgroups per CU)
+// splats staged per step by the fused renderer's backward.  64: 12.5 KB of LDS and 71 VGPRs = 7 waves per
+// SIMD (128: 25 KB and 78 VGPRs = 6; 0.514 -> 0.505 ms at D, 0.155 -> 0.149 at B; with amdgpu_waves_per_eu(8)
+// the compiler reaches 64 VGPRs without spilling but the kernel is no faster)
+#define GS_BWD_CHUNK 64
 #endif
 constexpr int RB = 256;      // workgroup size = pixels per tile
 
