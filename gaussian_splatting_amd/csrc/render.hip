@@ -110,8 +110,11 @@ constexpr int RB = 256;      // workgroup size = pixels per tile
 
 // splats staged in LDS per step (at most one per thread); smaller for the wide test-only
 // instantiations so that every kernel stays below 64 KiB of static LDS
+#ifndef GS_FWD_CHUNK
+#define GS_FWD_CHUNK 256   // the fp32 one-coefficient forward (the fused renderer's); 128: +3 %, 64: +9 % at D
+#endif
 template <typename T, int N_SH> struct Chunk {
-    static constexpr int value = (sizeof(T) * N_SH <= 8) ? 256 : (sizeof(T) * N_SH <= 36) ? 128 : 64;
+    static constexpr int value = (sizeof(T) * N_SH <= 4) ? GS_FWD_CHUNK : (sizeof(T) * N_SH <= 8) ? 256 : (sizeof(T) * N_SH <= 36) ? 128 : 64;
 };
 
 template <typename T> struct alignas(16) Vec4 { T x, y, z, w; };
