@@ -375,11 +375,14 @@ struct Render : public torch::autograd::Function<Render> {
         // the forward's per-tile costs and the order workspace sit behind the splat counts (render_forward)
         const int64_t T = (int64_t)((W + 15) / 16) * ((H + 15) / 16);
         int32_t* tile_cost = nsp.data_ptr<int32_t>() + (int64_t)W * H;
+        // longest-first only pays where a workgroup lives long enough for the kernel's tail to matter: lists of a
+        // few hundred entries per tile (workload B, 52 per tile: the order kernel's 6 us are not won back)
+        const bool ordered = sorted_g.size(0) >= 256 * T;
         timed("gs_render_tiles_backward_slab", stream, [&] {
             return gs_render_tiles_backward_slab(packed.data_ptr(), rgbr.data_ptr(), ranges.data_ptr<int32_t>(),
                                                  sorted_g.data_ptr<int32_t>(), bg.data_ptr(), nsp.data_ptr<int32_t>(),
                                                  fw.data_ptr(), grad_image.data_ptr(), W, H, row0, row1, slab.data_ptr(),
-                                                 tile_cost, tile_cost + T, stream);
+                                                 ordered ? tile_cost : nullptr, ordered ? tile_cost + T : nullptr, stream);
         });
         Tensor rows = slab.narrow(0, 0, V);
         out[0] = rows.narrow(1, 4, 2);   // uv

@@ -45,6 +45,8 @@ def _cf(x):
 # nearest entries of long tile lists and repair, on the device, the tiles that needed more.  Exact;
 # off only for callers that want the complete sorted lists back (return_aux=True).
 SORT_PREFIX = True
+# mean tile-list length from which the backward starts its tiles longest-first (render_backward)
+LPT_MIN_MEAN_LIST = 256
 # Enqueue the render on the speculative tile lists before waiting for the frame's host read.
 EARLY_RENDER = True
 
@@ -339,7 +341,9 @@ def render_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, grad
     row0, row1 = tile_rows if tile_rows is not None else (0, nty)
     slab = torch.zeros(max(V, 1), SLAB_WIDTH, dtype=torch.float32, device=packed.device)
     cost = order = None
-    if tile_cost is not None and tile_cost.numel() > 0:
+    # longest-first only pays where a workgroup lives long enough for the kernel's tail to matter: lists of a
+    # few hundred entries per tile (workload B, 52 per tile: the order kernel's 6 us are not won back)
+    if tile_cost is not None and tile_cost.numel() > 0 and sorted_g.shape[0] >= LPT_MIN_MEAN_LIST * tile_cost.numel():
         cost = tile_cost
         order = torch.empty(tile_cost.numel() + 8, dtype=torch.int32, device=packed.device)
     _hip.call("gs_render_tiles_backward_slab", _p(packed), _p(rgb), _p(ranges), _p(sorted_g), _p(background_rgb),

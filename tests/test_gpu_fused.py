@@ -543,7 +543,7 @@ def test_end_to_end_difference_is_flipped_threshold_decisions(N, W, H, deg, seed
 
 
 @pytest.mark.parametrize("W,H", [(1024, 592), (1040, 592)])   # 2368 tiles (a multiple of 8) and 2405 (not)
-def test_backward_longest_first_tile_order(W, H):
+def test_backward_longest_first_tile_order(W, H, monkeypatch):
     """gs_render_tiles_backward_slab with the forward's tile costs: the launch order is a permutation of the
     tiles, by non-increasing cost class within each XCD's eighth of the frame, and the gradients are those of
     the natural order (the atomics' summation order is the only difference)"""
@@ -551,6 +551,7 @@ def test_backward_longest_first_tile_order(W, H):
 
     from gaussian_splatting_amd import _hip
     N = 60000                                        # >= 2048 tiles: the order is used
+    monkeypatch.setattr(fused, "LPT_MIN_MEAN_LIST", 0)   # ... whatever the mean list length
     g, cam, T = make_scene(N, W, H, 0, seed=5, device=DEV)
     bg = torch.zeros(3, device=DEV)
     gi = make_grad_image(W, H, seed=6, device=DEV)
