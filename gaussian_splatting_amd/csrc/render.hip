@@ -9,27 +9,33 @@
 // are laid out so that each XCD renders a contiguous band of tiles (block b runs on XCD b%8):
 // neighbouring tiles share Gaussians and hit the same 4 MiB L2.
 //
-// Data flow.  Per chunk of 256 splats the workgroup gathers the packed geometry record
-// (gs_pack_splats: u, v, a, b, c, det, 1/det, opacity -- two 16-byte loads) and the colour
-// coefficients of the depth-sorted Gaussians into LDS; every pixel then walks the chunk with
-// wave-uniform (broadcast) LDS reads.  Barriers are uniform (Q2 of SURVEY.md is not replicated).
-// Forward leaves the chunk loop as soon as every pixel of the tile is saturated
-// (result-preserving: a saturated pixel ignores all later splats, render.cu:106).
+// Data flow.  Per chunk of splats (256 in the fp32 forward, 64 in its backward) the workgroup gathers the
+// 48-byte packed record (gs_pack_splats / gs_preprocess_forward: u v r2 opacity | a b c det | 1/det colour --
+// three 16-byte loads; or forms it from the reference's separate arrays, stage_chunk) and, for per-pixel SH,
+// the colour coefficients of the depth-sorted Gaussians into LDS; every thread then tests the record it
+// staged against the tile's four 8x8 patches (build_touch_masks) and a wave walks only the splats whose
+// cutoff ellipse reaches its patch, with wave-uniform (broadcast) LDS reads -- in the fp32 forward the next
+// visit's record is requested while the current one is composited (lds_record_fetch).  Barriers are uniform
+// (Q2 of SURVEY.md is not replicated).  Forward leaves the chunk loop as soon as every pixel of the tile is
+// saturated (result-preserving: a saturated pixel ignores all later splats, render.cu:106).
 //
 // Prefix mode (binning.hip "prefix sort"): a long tile list may have only its 1024 nearest entries
 // ordered; the forward reads no further, raises tile_flags[t] if a pixel is still unsaturated there,
 // and k_render_fwd_flagged renders such tiles again after their full sort -- results are exact.
 //
-// Backward starts at the tile's largest num_splats_per_pixel instead of the end of the list,
-// skips the reduction for waves none of whose lanes the splat reaches, reduces the 6+3*N_SH
-// per-splat gradient sums over 16-lane rows with DPP adds, combines rows and waves with LDS float
-// atomics and issues ONE global atomic per value per (splat, tile) -- the reference issues eight
-// (one per warp), unconditionally.  The fused path accumulates into one [V, 9] row per Gaussian.
+// Backward starts at the tile's largest num_splats_per_pixel instead of the end of the list and skips the
+// reduction for waves none of whose lanes the splat reaches.  The fused renderer's kernel (fp32, one colour
+// coefficient: SLOTS) sums the nine per-splat values over the wave with a transposing DPP / permlane-swap
+// reduction into a wave-private LDS slot (plain store, no LDS atomics), the flush adds the four waves' slots
+// and issues the global atomics nine lanes per 36-byte row of the [V, 9] slab; the other instantiations
+// (per-pixel SH, fp64) keep DPP row sums + LDS float atomics and one global atomic per value per
+// (splat, tile) -- the reference issues eight (one per warp), unconditionally.  The fused backward starts its
+// tiles longest-first from durations the forward measured (k_tile_order).
 //
 // Numerics.  The fp32 forward is bit-identical to the CPU restatement: same operation order and
-// operand precisions as render.cu (including its double-literal promotions), IEEE division,
-// det_expf in place of __expf.  Backward forms alpha and the skip decisions bit-identically
-// (render_backward.cu:141-170) and evaluates the gradient formulas in T.
+// operand precisions as render.cu (including its double-literal promotions), the IEEE quotient (formed
+// from the stored reciprocal, div_by_reciprocal), det_expf in place of __expf.  Backward forms alpha and
+// the skip decisions bit-identically (render_backward.cu:141-170) and evaluates the gradient formulas in T.
 #include "pg_math.h"
 
 namespace gs {
