@@ -75,3 +75,46 @@ def test_library_shares_the_hip_runtime_torch_loaded():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=300)
     assert out.returncode == 0, out.stderr
     assert out.stdout.strip().splitlines()[-1] == "1", out.stdout
+
+
+def _prototypes():
+    """{function name: number of parameters} of include/gsplat_hip.h"""
+    src = open(os.path.join(ROOT, "include", "gsplat_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(gs_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        params = m.group(2).strip()
+        out[m.group(1)] = 0 if params in ("", "void") else len(params.split(","))
+    return out
+
+
+def test_python_call_sites_pass_as_many_arguments_as_the_header_declares():
+    """ctypes calls carry no prototype: a call site that drifts from include/gsplat_hip.h would corrupt the
+    arguments silently.  Every `_hip.call("gs_...", ...)` / `lib.gs_...(...)` in the package, bench.py and the
+    scripts must pass exactly the declared number of arguments."""
+    import ast
+    protos = _prototypes()
+    assert len(protos) == len(declared_symbols()) and protos["gs_abi_version"] == 0 and protos["gs_camera_projection"] == 6
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    for d in ("gaussian_splatting_amd", "scripts", "tests"):
+        files += [os.path.join(ROOT, d, f) for f in sorted(os.listdir(os.path.join(ROOT, d))) if f.endswith(".py")]
+    checked, bad = 0, []
+    for path in files:
+        tree = ast.parse(open(path).read())
+        for node in ast.walk(tree):
+            if not isinstance(node, ast.Call):
+                continue
+            name, n_args = None, None
+            f = node.func
+            if isinstance(f, ast.Attribute) and f.attr == "call" and node.args and isinstance(node.args[0], ast.Constant) \
+                    and isinstance(node.args[0].value, str) and node.args[0].value.startswith("gs_"):
+                name, n_args = node.args[0].value, len(node.args) - 1          # _hip.call("gs_x", a, b, ...)
+            elif isinstance(f, ast.Attribute) and f.attr.startswith("gs_") and f.attr in protos:
+                name, n_args = f.attr, len(node.args)                            # lib.gs_x(a, b, ...)
+            if name is None or any(isinstance(a, ast.Starred) for a in node.args):
+                continue
+            checked += 1
+            if name not in protos or protos[name] != n_args:
+                bad.append((os.path.relpath(path, ROOT), node.lineno, name, n_args, protos.get(name)))
+    assert checked >= 40, checked
+    assert not bad, bad
