@@ -611,3 +611,49 @@ def test_second_backward_over_a_retained_graph():
     img.backward(gi)
     for k in PARAMS:
         assert scaled_err(getattr(g, k).grad, 2 * once[k]) < 2e-6, k
+
+
+@pytest.mark.parametrize("deg", [0, 1])
+def test_packed_render_entry_points_equal_the_reference_signature_ones(deg):
+    """gs_render_tiles_packed / gs_render_tiles_backward_packed (records of gs_pack_splats) against
+    gs_render_tiles / gs_render_tiles_backward (the reference's argument lists, record formed while staging):
+    the same kernels on the same record values -- images bit-equal, gradients equal up to the atomics' order"""
+    import ctypes
+
+    from gaussian_splatting_amd import _hip, splat_cuda
+    N, W, H = 8000, 200, 152
+    g, cam, T = make_scene(N, W, H, deg, seed=11, device=DEV)
+    bg = torch.full((3,), 0.25, device=DEV)
+    gi = make_grad_image(W, H, seed=12, device=DEV)
+    img0, mask, uv, aux = fused.rasterize(g, T, cam, 0.3, 500.0, 100, 3.0, True, bg, return_aux=True)
+    uv, opa, rgb, conic = uv.detach().contiguous(), aux["opacity"].contiguous(), aux["rgb"].contiguous(), aux["conic"].contiguous()
+    ranges, sorted_g = aux["tile_ranges"], aux["sorted_gaussians"]
+    V = uv.shape[0]
+    rays = torch.zeros(1, 1, 1, device=DEV)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    stream = _hip.current_stream()
+    nty = (H + 15) // 16
+
+    def outputs():
+        return (torch.zeros(H, W, dtype=torch.int32, device=DEV), torch.zeros(H, W, device=DEV), torch.zeros(H, W, 3, device=DEV))
+
+    def grads():
+        return [torch.zeros_like(x) for x in (rgb, opa, uv, conic)]
+
+    nsp_a, fw_a, img_a = outputs()
+    splat_cuda.render_tiles_cuda(uv, opa, rgb, conic, rays, ranges, sorted_g, bg, nsp_a, fw_a, img_a)
+    ga = grads()
+    splat_cuda.render_tiles_backward_cuda(uv, opa, rgb, conic, rays, ranges, sorted_g, bg, nsp_a, fw_a, gi, *ga)
+
+    packed = torch.empty(V, 12, device=DEV)
+    _hip.call("gs_pack_splats", p(uv), p(opa), p(conic), p(rgb), V, p(packed), _hip.GS_F32, stream)
+    nsp_b, fw_b, img_b = outputs()
+    _hip.call("gs_render_tiles_packed", p(packed), p(rgb), p(rays), p(ranges), p(sorted_g), p(bg), W, H, 1, 0, nty,
+              p(nsp_b), p(fw_b), p(img_b), _hip.GS_F32, stream)
+    gb = grads()
+    _hip.call("gs_render_tiles_backward_packed", p(packed), p(rgb), p(rays), p(ranges), p(sorted_g), p(bg), p(nsp_b),
+              p(fw_b), p(gi), W, H, 1, 0, nty, p(gb[0]), p(gb[1]), p(gb[2]), p(gb[3]), _hip.GS_F32, stream)
+    assert torch.equal(img_a, img_b) and torch.equal(nsp_a, nsp_b) and torch.equal(fw_a, fw_b)
+    assert torch.equal(img_a, img0.detach())
+    for a, b in zip(ga, gb):
+        assert scaled_err(b, a) < 2e-6
