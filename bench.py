@@ -29,7 +29,10 @@ emit/sort capacity missed and how many tiles the prefix sort had to repair.
 Prints ONE JSON line with the contract fields plus
   roofline      dominant entry point: algorithmic bytes / its mean GPU duration (events on the launch
                 stream, recorded inside the timed region) against the 8 TB/s HBM peak, next to the measured
-                device-copy bandwidth of this GPU, the pixel-splat evaluation rate E/s and a VALU issue view
+                device-copy bandwidth of this GPU, the pixel-splat evaluation rate E/s and a VALU issue view;
+                the other entry points' times (entry_ms_per_step) are taken over the W warm-up frames: an
+                event pair around a call costs the stream ~10 us, so only the dominant one is timed in the
+                timed region
   cpu_baseline  the CPU oracle (literal restatement of the reference algorithm; the reference ships no
                 CPU path) timed on this host's cores on a bounded sample of the same workload.
 """
