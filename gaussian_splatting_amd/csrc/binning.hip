@@ -301,8 +301,11 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_count(const float* __restric
 // 1024-thread workgroup = 64 tiles x 16 row segments of 32 rows: every thread sums its segment
 // (coalesced: a wave reads 64 consecutive tiles of one row), the 16 segment sums of a tile are
 // prefixed through LDS, then the thread re-walks its segment writing the exclusive offsets.
-constexpr int CS_TILES = 64;
-constexpr int CS_SEGS = 16;
+#ifndef GS_CS_TILES
+#define GS_CS_TILES 64   // 68 workgroups at workload D; 32 or 16 tiles per workgroup (more, narrower ones) are no faster
+#endif
+constexpr int CS_TILES = GS_CS_TILES;
+constexpr int CS_SEGS = 1024 / CS_TILES;
 constexpr int CS_ROWS = PRIV_NB / CS_SEGS;
 __global__ __launch_bounds__(CS_TILES * CS_SEGS) void k_bin_colscan(int* __restrict__ hist, int T,
                                                                    int* __restrict__ counts) {
