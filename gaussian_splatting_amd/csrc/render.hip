@@ -885,7 +885,6 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     if (n_used <= 0) return;
 
     const T pu = T(px.u), pv = T(px.v);
-    const T ygi[3] = {Y[0] * gi[0], Y[0] * gi[1], Y[0] * gi[2]};
     const int slot_off = slot_lane_offset(lane);
     T color_accum[3] = {0, 0, 0};
     bool bg_init = false;
@@ -951,8 +950,10 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                     // render_backward.cu:153-165 (multiplies by 1/det; the forward divides)
                     const T duv = du * dv;
                     const T mh = (g1.z * du * du - (g1.y + g1.y) * du * dv + g1.x * dv * dv) * g2.x;
-                    T norm_prob = 0;
-                    if (mh > T(0)) norm_prob = exp_neg_half(mh);
+                    // (a select, not a branch around the exponential: mh <= 0 does not occur for a positive
+                    // definite conic, and the branch costs every visit its exec-mask round trip)
+                    const T e = exp_neg_half(mh);
+                    const T norm_prob = (mh > T(0)) ? e : T(0);
                     T alpha = g0.w * norm_prob;
                     if (alpha > Thr<T>::sat_gt()) alpha = Thr<T>::alpha_cap();   // min(0.9999, .)
                     if (alpha >= Thr<T>::alpha_min()) {
@@ -993,7 +994,8 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                 GS_STAT(5, __popcll(cmask));
                 if (cmask == 0) continue;   // every reaching lane skipped the splat
                 T val[9];
-                val[0] = aw * ygi[0]; val[1] = aw * ygi[1]; val[2] = aw * ygi[2];
+                const T awy = aw * Y[0];   // (the compiler re-formed Y0 * gi[ch] at every visit to save registers)
+                val[0] = awy * gi[0]; val[1] = awy * gi[1]; val[2] = awy * gi[2];
                 val[3] = w; val[4] = w * du; val[5] = w * dv;
                 val[6] = q0; val[7] = q1; val[8] = q2;
                 reduce9_to_slot(val, lane, slot_off, &s_acc[(wave * RCHUNK + i) * NV]);
