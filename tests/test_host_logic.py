@@ -224,3 +224,18 @@ def test_bench_helpers():
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
     assert "127.0.0.1" in cmd and cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_committed_traffic_and_valu_json_follow_from_the_committed_pmc_passes(tmp_path):
+    """profiles/r02/hbm_traffic_D.json and valu_insts_D.json (what bench.py reports as roofline.traffic /
+    roofline.valu) are exactly what scripts/make_traffic_json.py derives from the committed rocprofv3 passes"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out, valu = tmp_path / "t.json", tmp_path / "v.json"
+    subprocess.run([sys.executable, os.path.join(root, "scripts", "make_traffic_json.py"), "profiles/r02/pmc_bench_D",
+                    str(out), "D", str(valu)], check=True, cwd=root, capture_output=True)
+    assert json.load(open(out)) == json.load(open(os.path.join(root, "profiles", "r02", "hbm_traffic_D.json")))
+    assert json.load(open(valu)) == json.load(open(os.path.join(root, "profiles", "r02", "valu_insts_D.json")))
