@@ -239,3 +239,32 @@ def test_committed_traffic_and_valu_json_follow_from_the_committed_pmc_passes(tm
                     str(out), "D", str(valu)], check=True, cwd=root, capture_output=True)
     assert json.load(open(out)) == json.load(open(os.path.join(root, "profiles", "r02", "hbm_traffic_D.json")))
     assert json.load(open(valu)) == json.load(open(os.path.join(root, "profiles", "r02", "valu_insts_D.json")))
+
+
+@pytest.mark.parametrize("name", ["bench_D.json", "bench_B.json", "bench_C.json", "bench_D_moving_camera.json"])
+def test_committed_bench_lines_keep_the_contract(name):
+    """the JSON lines under profiles/r02 are what `python bench.py` printed: the contract's fields, BASELINE.json's
+    metric verbatim, a roofline object whose fraction is achieved / peak and whose achieved rate is the algorithmic
+    bytes over the measured launch duration, and (workload D, default flags) the CPU baseline"""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "r02", name)))
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert d["metric"] == base["metric"] and d["unit"] == "Mpixels/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["steps"] >= 50 and "workload" in d["config"] and "model" not in d["config"]
+    P = d["config"]["P"]
+    assert abs(d["value"] - P / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * d["value"]
+    assert d["ms_per_step_min"] <= d["ms_per_step_median"] <= d["ms_per_step_max"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["launch_ms"] * 1e-3) / 1e9) < 1e-2 * r["achieved"]
+    assert r["kernel"] in r["entry_ms_per_step"] and r["launch_ms"] <= d["ms_per_step"]
+    assert sum(r["entry_ms_per_step"].values()) <= d["ms_per_step"] * 1.02      # the entries fit inside the step
+    if name == "bench_D.json":
+        c = d["cpu_baseline"]
+        assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mpixels/s" and c["sample"]
+        assert d["parity"]["image_max_abs_err"] == 0.0 and d["parity"]["grad_max_rel_err"] < 1e-4
+        assert r["traffic"] is not None and r["traffic_source"].startswith("profiles/")
