@@ -15,15 +15,22 @@ LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(_HERE, "libgsplat_hi
 GS_F32 = 0
 GS_F64 = 1
 GS_SORT_PREFIX = 1024
+GS_BACKWARD_DEFAULT = -1  # per-call argument of the render-backward entry points: the process default
 GS_BACKWARD_COMPAT = 0   # render backward bug-compatible with render_backward.cu:185 (default)
 GS_BACKWARD_EXACT = 1    # the exact gradient of the forward pass
 
 
 def set_backward_mode(mode):
     """"compat" (default: the reference's arithmetic including SURVEY.md Q1) or "exact" (global splat index
-    in the transmittance update: the mathematically exact gradient); process-wide"""
+    in the transmittance update: the mathematically exact gradient).  Sets the process-wide DEFAULT: the
+    render-backward entry points take the mode per call (ABI 5) and the fused frames pass the default that
+    was in force at their FORWARD, so changing it never affects a backward that is already queued"""
     code = {"compat": GS_BACKWARD_COMPAT, "exact": GS_BACKWARD_EXACT}.get(mode, mode)
     check(lib().gs_set_backward_mode(int(code)))
+
+
+def get_backward_mode():
+    return int(lib().gs_get_backward_mode())
 
 # every entry point include/gsplat_hip.h declares
 EXPORTS = [

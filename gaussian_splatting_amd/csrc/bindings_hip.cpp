@@ -10,6 +10,7 @@
 // get_sorted_gaussian_list performs exactly one 4-byte device-to-host read (the instance count that
 // sizes its result).  The GIL stays held, as in the reference (no gil_scoped_release).
 #include <ATen/hip/HIPContext.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/extension.h>
 
@@ -19,14 +20,32 @@
 
 namespace {
 
-void* cur_stream() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
+// The device of a call = the device of its first tensor: the guard makes it current for the launches (a
+// stream of device 1 under current device 0 is an invalid handle), every further tensor must live there
+// too, and the kernels are enqueued on THAT device's current stream.
+struct DeviceOf {
+    c10::OptionalDeviceGuard guard;
+    c10::Device device{c10::kCPU};
+    bool set = false;
+    void see(const torch::Tensor& t, const char* name) {
+        if (!set) {
+            device = t.device();
+            guard.reset_device(device);
+            set = true;
+        } else {
+            TORCH_CHECK(t.device() == device, name, " is on ", t.device(), " but the call's first tensor is on ", device);
+        }
+    }
+    void* stream() const { return (void*)c10::hip::getCurrentHIPStream(set ? device.index() : -1).stream(); }
+};
 
 void ok(int status) { TORCH_CHECK(status == GS_OK, gs_last_error()); }
 
 // CHECK_VALID_INPUT (checks.cuh:5-9)
 #define VALID(x)                                                                                   \
     TORCH_CHECK((x).is_cuda(), #x " is not a CUDA tensor");                                        \
-    TORCH_CHECK((x).is_contiguous(), #x " is not a contiguous tensor")
+    TORCH_CHECK((x).is_contiguous(), #x " is not a contiguous tensor");                            \
+    dev_.see((x), #x)
 #define IS_INT(x) TORCH_CHECK((x).scalar_type() == torch::kInt32, #x " is not an int tensor")
 
 int float_type(const torch::Tensor& first) {
@@ -53,12 +72,12 @@ bool has_shape(const torch::Tensor& t, std::initializer_list<int64_t> shape) {
 }
 
 torch::Tensor pack(const torch::Tensor& uvs, const torch::Tensor& opacity, const torch::Tensor& conic,
-                   const torch::Tensor* rgb, int dt) {
+                   const torch::Tensor* rgb, int dt, void* stream) {
     const int64_t V = uvs.size(0);
     torch::Tensor packed = torch::empty({V, GS_PACKED_WIDTH}, uvs.options());
     const void* col = (rgb != nullptr && n_sh_of(*rgb) == 1) ? rgb->data_ptr() : nullptr;
     ok(gs_pack_splats(uvs.data_ptr(), opacity.data_ptr(), conic.data_ptr(), col, (int)V, packed.data_ptr(), dt,
-                      cur_stream()));
+                      stream));
     return packed;
 }
 
@@ -83,6 +102,7 @@ void render_tiles_cuda(torch::Tensor uvs, torch::Tensor opacity, torch::Tensor r
                        torch::Tensor gaussian_idx_by_splat_idx, torch::Tensor background_rgb,
                        torch::Tensor num_splats_per_pixel, torch::Tensor final_weight_per_pixel,
                        torch::Tensor rendered_image) {
+    DeviceOf dev_;   // kernels go to the tensors' device and its current stream, whatever the caller's current device
     VALID(uvs); VALID(opacity); VALID(rgb); VALID(conic); VALID(view_dir_by_pixel);
     VALID(splat_start_end_idx_by_tile_idx); VALID(gaussian_idx_by_splat_idx); VALID(background_rgb);
     VALID(num_splats_per_pixel); VALID(final_weight_per_pixel); VALID(rendered_image);
@@ -105,7 +125,7 @@ void render_tiles_cuda(torch::Tensor uvs, torch::Tensor opacity, torch::Tensor r
                        splat_start_end_idx_by_tile_idx.data_ptr<int32_t>(),
                        gaussian_idx_by_splat_idx.data_ptr<int32_t>(), background_rgb.data_ptr(),
                        num_splats_per_pixel.data_ptr<int32_t>(), final_weight_per_pixel.data_ptr(),
-                       rendered_image.data_ptr(), W, H, n_sh, 0, nty, dt, cur_stream()));
+                       rendered_image.data_ptr(), W, H, n_sh, 0, nty, dt, dev_.stream()));
 }
 
 void render_tiles_backward_cuda(torch::Tensor uvs, torch::Tensor opacity, torch::Tensor rgb, torch::Tensor conic,
@@ -114,6 +134,7 @@ void render_tiles_backward_cuda(torch::Tensor uvs, torch::Tensor opacity, torch:
                                 torch::Tensor num_splats_per_pixel, torch::Tensor final_weight_per_pixel,
                                 torch::Tensor grad_image, torch::Tensor grad_rgb, torch::Tensor grad_opacity,
                                 torch::Tensor grad_uvs, torch::Tensor grad_conic) {
+    DeviceOf dev_;   // kernels go to the tensors' device and its current stream, whatever the caller's current device
     VALID(uvs); VALID(opacity); VALID(rgb); VALID(conic); VALID(view_dir_by_pixel);
     VALID(splat_start_end_idx_by_tile_idx); VALID(gaussian_idx_by_splat_idx); VALID(background_rgb);
     VALID(num_splats_per_pixel); VALID(final_weight_per_pixel); VALID(grad_image); VALID(grad_rgb);
@@ -143,12 +164,13 @@ void render_tiles_backward_cuda(torch::Tensor uvs, torch::Tensor opacity, torch:
                                 gaussian_idx_by_splat_idx.data_ptr<int32_t>(), background_rgb.data_ptr(),
                                 num_splats_per_pixel.data_ptr<int32_t>(), final_weight_per_pixel.data_ptr(),
                                 grad_image.data_ptr(), grad_rgb.data_ptr(), grad_opacity.data_ptr(), grad_uvs.data_ptr(),
-                                grad_conic.data_ptr(), W, H, n_sh, 0, nty, dt, cur_stream()));
+                                grad_conic.data_ptr(), W, H, n_sh, 0, nty, dt, GS_BACKWARD_DEFAULT, dev_.stream()));
 }
 
 void render_depth_cuda(torch::Tensor xyz_camera_frame, torch::Tensor uvs, torch::Tensor opacity, torch::Tensor conic,
                        torch::Tensor splat_start_end_idx_by_tile_idx, torch::Tensor gaussian_idx_by_splat_idx,
                        const float alpha_threshold, torch::Tensor depth_image) {
+    DeviceOf dev_;   // kernels go to the tensors' device and its current stream, whatever the caller's current device
     VALID(xyz_camera_frame); VALID(uvs); VALID(opacity); VALID(conic); VALID(splat_start_end_idx_by_tile_idx);
     VALID(gaussian_idx_by_splat_idx); VALID(depth_image);
     SAME_TYPE(GS_F32, xyz_camera_frame); SAME_TYPE(GS_F32, uvs); SAME_TYPE(GS_F32, opacity);
@@ -156,15 +178,16 @@ void render_depth_cuda(torch::Tensor xyz_camera_frame, torch::Tensor uvs, torch:
     IS_INT(splat_start_end_idx_by_tile_idx); IS_INT(gaussian_idx_by_splat_idx);
     TORCH_CHECK(depth_image.dim() == 3 && depth_image.size(2) == 1, "Depth Image must be HxWx1");   // depth.cu:148
     const int H = (int)depth_image.size(0), W = (int)depth_image.size(1);
-    torch::Tensor packed = pack(uvs, opacity, conic, nullptr, GS_F32);
+    torch::Tensor packed = pack(uvs, opacity, conic, nullptr, GS_F32, dev_.stream());
     ok(gs_render_depth(packed.data_ptr(), xyz_camera_frame.data_ptr(),
                        splat_start_end_idx_by_tile_idx.data_ptr<int32_t>(),
                        gaussian_idx_by_splat_idx.data_ptr<int32_t>(), W, H, alpha_threshold, depth_image.data_ptr(),
-                       cur_stream()));
+                       dev_.stream()));
 }
 
 // ---- projection.cu / projection_backward.cu --------------------------------------------------------------
 void camera_projection_cuda(torch::Tensor xyz, torch::Tensor K, torch::Tensor uv) {
+    DeviceOf dev_;   // kernels go to the tensors' device and its current stream, whatever the caller's current device
     VALID(xyz); VALID(K); VALID(uv);
     const int64_t N = xyz.size(0);
     TORCH_CHECK(xyz.dim() == 2 && xyz.size(1) == 3, "xyz must have shape Nx3");
@@ -172,11 +195,12 @@ void camera_projection_cuda(torch::Tensor xyz, torch::Tensor K, torch::Tensor uv
     TORCH_CHECK(has_shape(uv, {N, 2}), "uv must have shape Nx2");
     const int dt = float_type(xyz);
     SAME_TYPE(dt, K); SAME_TYPE(dt, uv);
-    ok(gs_camera_projection(xyz.data_ptr(), K.data_ptr(), (int)N, uv.data_ptr(), dt, cur_stream()));
+    ok(gs_camera_projection(xyz.data_ptr(), K.data_ptr(), (int)N, uv.data_ptr(), dt, dev_.stream()));
 }
 
 void camera_projection_backward_cuda(torch::Tensor xyz, torch::Tensor K, torch::Tensor uv_grad_out,
                                      torch::Tensor xyz_grad_in) {
+    DeviceOf dev_;   // kernels go to the tensors' device and its current stream, whatever the caller's current device
     VALID(xyz); VALID(K); VALID(uv_grad_out); VALID(xyz_grad_in);
     const int64_t N = xyz.size(0);
     TORCH_CHECK(xyz.dim() == 2 && xyz.size(1) == 3, "xyz must be of shape Nx3");
@@ -186,10 +210,11 @@ void camera_projection_backward_cuda(torch::Tensor xyz, torch::Tensor K, torch::
     const int dt = float_type(xyz);
     SAME_TYPE(dt, K); SAME_TYPE(dt, uv_grad_out); SAME_TYPE(dt, xyz_grad_in);
     ok(gs_camera_projection_backward(xyz.data_ptr(), K.data_ptr(), uv_grad_out.data_ptr(), (int)N,
-                                     xyz_grad_in.data_ptr(), dt, cur_stream()));
+                                     xyz_grad_in.data_ptr(), dt, dev_.stream()));
 }
 
 void compute_sigma_world_cuda(torch::Tensor quaternion, torch::Tensor scale, torch::Tensor sigma_world) {
+    DeviceOf dev_;   // kernels go to the tensors' device and its current stream, whatever the caller's current device
     VALID(quaternion); VALID(scale); VALID(sigma_world);
     const int64_t N = quaternion.size(0);
     TORCH_CHECK(quaternion.dim() == 2 && quaternion.size(1) == 4, "quaternion must have shape Nx4");
@@ -197,11 +222,12 @@ void compute_sigma_world_cuda(torch::Tensor quaternion, torch::Tensor scale, tor
     TORCH_CHECK(has_shape(sigma_world, {N, 3, 3}), "sigma_world must have shape Nx3x3");
     const int dt = float_type(quaternion);
     SAME_TYPE(dt, scale); SAME_TYPE(dt, sigma_world);
-    ok(gs_compute_sigma_world(quaternion.data_ptr(), scale.data_ptr(), (int)N, sigma_world.data_ptr(), dt, cur_stream()));
+    ok(gs_compute_sigma_world(quaternion.data_ptr(), scale.data_ptr(), (int)N, sigma_world.data_ptr(), dt, dev_.stream()));
 }
 
 void compute_sigma_world_backward_cuda(torch::Tensor quaternion, torch::Tensor scale, torch::Tensor sigma_world_grad_out,
                                        torch::Tensor quaternion_grad_in, torch::Tensor scale_grad_in) {
+    DeviceOf dev_;   // kernels go to the tensors' device and its current stream, whatever the caller's current device
     VALID(quaternion); VALID(scale); VALID(sigma_world_grad_out); VALID(quaternion_grad_in); VALID(scale_grad_in);
     const int64_t N = quaternion.size(0);
     TORCH_CHECK(quaternion.dim() == 2 && quaternion.size(1) == 4, "quaternion must have shape Nx4");
@@ -212,10 +238,11 @@ void compute_sigma_world_backward_cuda(torch::Tensor quaternion, torch::Tensor s
     const int dt = float_type(quaternion);
     SAME_TYPE(dt, scale); SAME_TYPE(dt, sigma_world_grad_out); SAME_TYPE(dt, quaternion_grad_in); SAME_TYPE(dt, scale_grad_in);
     ok(gs_compute_sigma_world_backward(quaternion.data_ptr(), scale.data_ptr(), sigma_world_grad_out.data_ptr(), (int)N,
-                                       quaternion_grad_in.data_ptr(), scale_grad_in.data_ptr(), dt, cur_stream()));
+                                       quaternion_grad_in.data_ptr(), scale_grad_in.data_ptr(), dt, dev_.stream()));
 }
 
 void compute_projection_jacobian_cuda(torch::Tensor xyz, torch::Tensor K, torch::Tensor J) {
+    DeviceOf dev_;   // kernels go to the tensors' device and its current stream, whatever the caller's current device
     VALID(xyz); VALID(K); VALID(J);
     const int64_t N = xyz.size(0);
     TORCH_CHECK(xyz.dim() == 2 && xyz.size(1) == 3, "xyz must have shape Nx3");
@@ -223,11 +250,12 @@ void compute_projection_jacobian_cuda(torch::Tensor xyz, torch::Tensor K, torch:
     TORCH_CHECK(has_shape(J, {N, 2, 3}), "J must have shape Nx2x3");
     const int dt = float_type(xyz);
     SAME_TYPE(dt, K); SAME_TYPE(dt, J);
-    ok(gs_compute_projection_jacobian(xyz.data_ptr(), K.data_ptr(), (int)N, J.data_ptr(), dt, cur_stream()));
+    ok(gs_compute_projection_jacobian(xyz.data_ptr(), K.data_ptr(), (int)N, J.data_ptr(), dt, dev_.stream()));
 }
 
 void compute_projection_jacobian_backward_cuda(torch::Tensor xyz, torch::Tensor K, torch::Tensor jac_grad_out,
                                                torch::Tensor xyz_grad_in) {
+    DeviceOf dev_;   // kernels go to the tensors' device and its current stream, whatever the caller's current device
     VALID(xyz); VALID(K); VALID(jac_grad_out); VALID(xyz_grad_in);
     const int64_t N = xyz.size(0);
     TORCH_CHECK(has_shape(jac_grad_out, {N, 2, 3}), "jac_grad_out must have shape Nx2x3");
@@ -235,10 +263,11 @@ void compute_projection_jacobian_backward_cuda(torch::Tensor xyz, torch::Tensor 
     const int dt = float_type(xyz);
     SAME_TYPE(dt, K); SAME_TYPE(dt, jac_grad_out); SAME_TYPE(dt, xyz_grad_in);
     ok(gs_compute_projection_jacobian_backward(xyz.data_ptr(), K.data_ptr(), jac_grad_out.data_ptr(), (int)N,
-                                               xyz_grad_in.data_ptr(), dt, cur_stream()));
+                                               xyz_grad_in.data_ptr(), dt, dev_.stream()));
 }
 
 void compute_conic_cuda(torch::Tensor sigma_world, torch::Tensor J, torch::Tensor camera_T_world, torch::Tensor conic) {
+    DeviceOf dev_;   // kernels go to the tensors' device and its current stream, whatever the caller's current device
     VALID(sigma_world); VALID(J); VALID(camera_T_world); VALID(conic);
     const int64_t N = sigma_world.size(0);
     TORCH_CHECK(has_shape(sigma_world, {N, 3, 3}), "sigma_world must have shape Nx3x3");
@@ -248,11 +277,12 @@ void compute_conic_cuda(torch::Tensor sigma_world, torch::Tensor J, torch::Tenso
     const int dt = float_type(sigma_world);
     SAME_TYPE(dt, J); SAME_TYPE(dt, camera_T_world); SAME_TYPE(dt, conic);
     ok(gs_compute_conic(sigma_world.data_ptr(), J.data_ptr(), camera_T_world.data_ptr(), (int)N, conic.data_ptr(), dt,
-                        cur_stream()));
+                        dev_.stream()));
 }
 
 void compute_conic_backward_cuda(torch::Tensor sigma_world, torch::Tensor J, torch::Tensor camera_T_world,
                                  torch::Tensor conic_grad_out, torch::Tensor sigma_world_grad_in, torch::Tensor J_grad_in) {
+    DeviceOf dev_;   // kernels go to the tensors' device and its current stream, whatever the caller's current device
     VALID(sigma_world); VALID(J); VALID(camera_T_world); VALID(conic_grad_out); VALID(sigma_world_grad_in); VALID(J_grad_in);
     const int64_t N = sigma_world.size(0);
     TORCH_CHECK(has_shape(sigma_world, {N, 3, 3}), "sigma_world must have shape Nx3x3");
@@ -265,7 +295,7 @@ void compute_conic_backward_cuda(torch::Tensor sigma_world, torch::Tensor J, tor
     SAME_TYPE(dt, J); SAME_TYPE(dt, camera_T_world); SAME_TYPE(dt, conic_grad_out); SAME_TYPE(dt, sigma_world_grad_in);
     SAME_TYPE(dt, J_grad_in);
     ok(gs_compute_conic_backward(sigma_world.data_ptr(), J.data_ptr(), camera_T_world.data_ptr(), conic_grad_out.data_ptr(),
-                                 (int)N, sigma_world_grad_in.data_ptr(), J_grad_in.data_ptr(), dt, cur_stream()));
+                                 (int)N, sigma_world_grad_in.data_ptr(), J_grad_in.data_ptr(), dt, dev_.stream()));
 }
 
 // ---- tile_culling.cu -----------------------------------------------------------------------------------
@@ -273,6 +303,7 @@ std::tuple<torch::Tensor, torch::Tensor> get_sorted_gaussian_list(const int max_
                                                                   torch::Tensor xyz_camera_frame, torch::Tensor conic,
                                                                   const int n_tiles_x, const int n_tiles_y,
                                                                   const float mh_dist) {
+    DeviceOf dev_;   // kernels go to the tensors' device and its current stream, whatever the caller's current device
     (void)max_tiles_per_gaussian;   // accepted and unused, as in the reference (tile_culling.cu:245)
     VALID(uvs); VALID(xyz_camera_frame); VALID(conic);
     SAME_TYPE(GS_F32, uvs); SAME_TYPE(GS_F32, xyz_camera_frame); SAME_TYPE(GS_F32, conic);
@@ -281,7 +312,7 @@ std::tuple<torch::Tensor, torch::Tensor> get_sorted_gaussian_list(const int max_
     auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(uvs.device());
     torch::Tensor workspace = torch::empty({(int64_t)gs_tile_workspace_ints((int)T)}, i32);
     torch::Tensor ranges = torch::empty({T + 1}, i32);
-    void* stream = cur_stream();
+    void* stream = dev_.stream();
     ok(gs_tile_count(uvs.data_ptr(), conic.data_ptr(), V, nullptr, nullptr, nullptr, n_tiles_x, n_tiles_y, mh_dist, 0,
                      n_tiles_y, workspace.data_ptr<int32_t>(), ranges.data_ptr<int32_t>(), stream));
     const int64_t S = ranges[T].item<int32_t>();   // the one host read: sizes the result
@@ -299,6 +330,7 @@ std::tuple<torch::Tensor, torch::Tensor> get_sorted_gaussian_list(const int max_
 // ---- precompute_sh.cu ------------------------------------------------------------------------------------
 void precompute_rgb_from_sh_cuda(const torch::Tensor xyz, const torch::Tensor sh_coeff, const torch::Tensor camera_T_world,
                                  torch::Tensor rgb) {
+    DeviceOf dev_;   // kernels go to the tensors' device and its current stream, whatever the caller's current device
     VALID(xyz); VALID(sh_coeff); VALID(camera_T_world); VALID(rgb);
     const int64_t N = xyz.size(0);
     TORCH_CHECK(xyz.dim() == 2 && xyz.size(1) == 3, "Input xyz should have 3 channels");
@@ -310,11 +342,12 @@ void precompute_rgb_from_sh_cuda(const torch::Tensor xyz, const torch::Tensor sh
     const int dt = float_type(xyz);
     SAME_TYPE(dt, sh_coeff); SAME_TYPE(dt, camera_T_world); SAME_TYPE(dt, rgb);
     ok(gs_precompute_rgb_from_sh(xyz.data_ptr(), sh_coeff.data_ptr(), camera_T_world.data_ptr(), (int)N, n_sh,
-                                 rgb.data_ptr(), dt, cur_stream()));
+                                 rgb.data_ptr(), dt, dev_.stream()));
 }
 
 void precompute_rgb_from_sh_backward_cuda(const torch::Tensor xyz, const torch::Tensor camera_T_world,
                                           const torch::Tensor grad_rgb, torch::Tensor grad_sh) {
+    DeviceOf dev_;   // kernels go to the tensors' device and its current stream, whatever the caller's current device
     VALID(xyz); VALID(camera_T_world); VALID(grad_rgb); VALID(grad_sh);
     const int64_t N = xyz.size(0);
     TORCH_CHECK(xyz.dim() == 2 && xyz.size(1) == 3, "Input xyz should have 3 channels");
@@ -325,7 +358,7 @@ void precompute_rgb_from_sh_backward_cuda(const torch::Tensor xyz, const torch::
     const int dt = float_type(xyz);
     SAME_TYPE(dt, camera_T_world); SAME_TYPE(dt, grad_rgb); SAME_TYPE(dt, grad_sh);
     ok(gs_precompute_rgb_from_sh_backward(xyz.data_ptr(), camera_T_world.data_ptr(), grad_rgb.data_ptr(), (int)N, n_sh,
-                                          grad_sh.data_ptr(), dt, cur_stream()));
+                                          grad_sh.data_ptr(), dt, dev_.stream()));
 }
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {

@@ -357,6 +357,9 @@ struct Render : public torch::autograd::Function<Render> {
         ctx->saved_data["row0"] = row0;
         ctx->saved_data["row1"] = row1;
         ctx->saved_data["V"] = uv.size(0);
+        // this frame's gradient mode = the default at its forward (a later gs_set_backward_mode cannot race
+        // the backward, which the autograd engine runs on its own thread)
+        ctx->saved_data["bwd_mode"] = (int64_t)gs_get_backward_mode();
         ctx->set_materialize_grads(false);
         return image;
     }
@@ -382,7 +385,8 @@ struct Render : public torch::autograd::Function<Render> {
             return gs_render_tiles_backward_slab(packed.data_ptr(), rgbr.data_ptr(), ranges.data_ptr<int32_t>(),
                                                  sorted_g.data_ptr<int32_t>(), bg.data_ptr(), nsp.data_ptr<int32_t>(),
                                                  fw.data_ptr(), grad_image.data_ptr(), W, H, row0, row1, slab.data_ptr(),
-                                                 ordered ? tile_cost : nullptr, ordered ? tile_cost + T : nullptr, stream);
+                                                 ordered ? tile_cost : nullptr, ordered ? tile_cost + T : nullptr,
+                                                 (int)ctx->saved_data["bwd_mode"].toInt(), stream);
         });
         Tensor rows = slab.narrow(0, 0, V);
         out[0] = rows.narrow(1, 4, 2);   // uv

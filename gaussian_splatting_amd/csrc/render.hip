@@ -37,6 +37,7 @@
 // from the stored reciprocal, div_by_reciprocal), det_expf in place of __expf.  Backward forms alpha and
 // the skip decisions bit-identically (render_backward.cu:141-170) and evaluates the gradient formulas in T.
 #include "pg_math.h"
+#include <atomic>
 
 namespace gs {
 
@@ -1269,16 +1270,27 @@ static int check_rows(int H, int row0, int row1) {
     return GS_OK;
 }
 
-static int g_backward_mode = GS_BACKWARD_COMPAT;
+// process-wide DEFAULT of the render backward's gradient mode; every entry point takes the mode per call
+// (ABI 5) and reads this only when asked for GS_BACKWARD_DEFAULT, once, at the call
+static std::atomic<int> g_backward_mode{GS_BACKWARD_COMPAT};
+static int resolve_backward_mode(int mode, int* exact) {
+    if (mode == GS_BACKWARD_DEFAULT) mode = g_backward_mode.load(std::memory_order_relaxed);
+    if (mode != GS_BACKWARD_COMPAT && mode != GS_BACKWARD_EXACT) {
+        gs::set_error("backward mode must be GS_BACKWARD_DEFAULT, GS_BACKWARD_COMPAT or GS_BACKWARD_EXACT");
+        return GS_EINVAL;
+    }
+    *exact = mode == GS_BACKWARD_EXACT;
+    return GS_OK;
+}
 
 extern "C" {
 
 int gs_set_backward_mode(int mode) {
     GS_REQUIRE(mode == GS_BACKWARD_COMPAT || mode == GS_BACKWARD_EXACT, "backward mode must be GS_BACKWARD_COMPAT or GS_BACKWARD_EXACT");
-    g_backward_mode = mode;
+    g_backward_mode.store(mode, std::memory_order_relaxed);
     return GS_OK;
 }
-int gs_get_backward_mode(void) { return g_backward_mode; }
+int gs_get_backward_mode(void) { return g_backward_mode.load(std::memory_order_relaxed); }
 
 #ifdef GS_STATS
 // instrumented build only: copies the 32 counters to the host (and clears them when reset != 0)
@@ -1385,9 +1397,11 @@ static int launch_render_bwd(const void* packed_or_uvs, const void* opacity, con
                              const int32_t* num_splats_per_pixel, const void* final_weight_per_pixel,
                              const void* grad_image, int W, int H, int n_sh, int tile_row0, int tile_row1,
                              void* grad_rgb, void* grad_opacity, void* grad_uv, void* grad_conic, int dtype,
-                             void* stream) {
+                             int backward_mode, void* stream) {
     GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
     if (int e = check_rows(H, tile_row0, tile_row1)) return e;
+    int exact = 0;
+    if (int e = resolve_backward_mode(backward_mode, &exact)) return e;
     hipStream_t s = (hipStream_t)stream;
     const int ntx = (W + 15) / 16;
     const int nt = (tile_row1 - tile_row0) * ntx;
@@ -1400,7 +1414,7 @@ static int launch_render_bwd(const void* packed_or_uvs, const void* opacity, con
                                      num_splats_per_pixel, (const T*)final_weight_per_pixel,
                                      (const T*)grad_image, W, H, ntx, tile_row0 * ntx, nt,
                                      (T*)grad_rgb, (T*)grad_opacity, (T*)grad_uv,
-                                     (T*)grad_conic, 0, g_backward_mode, nullptr, (const T*)opacity,
+                                     (T*)grad_conic, 0, exact, nullptr, (const T*)opacity,
                                      (const T*)conic))));
     return check_launch("render_tiles_backward");
 }
@@ -1411,11 +1425,12 @@ int gs_render_tiles_backward(const void* uvs, const void* opacity, const void* r
                              const int32_t* num_splats_per_pixel, const void* final_weight_per_pixel,
                              const void* grad_image, void* grad_rgb, void* grad_opacity, void* grad_uv,
                              void* grad_conic, int W, int H, int n_sh, int tile_row0, int tile_row1, int dtype,
-                             void* stream) {
+                             int backward_mode, void* stream) {
     GS_REQUIRE(opacity != nullptr && conic != nullptr, "opacity and conic must not be null");
     return launch_render_bwd(uvs, opacity, conic, rgb, view_dir_by_pixel, tile_ranges, sorted_gaussians,
                              background_rgb, num_splats_per_pixel, final_weight_per_pixel, grad_image, W, H, n_sh,
-                             tile_row0, tile_row1, grad_rgb, grad_opacity, grad_uv, grad_conic, dtype, stream);
+                             tile_row0, tile_row1, grad_rgb, grad_opacity, grad_uv, grad_conic, dtype, backward_mode,
+                             stream);
 }
 
 int gs_render_tiles_backward_packed(const void* packed, const void* rgb, const void* view_dir_by_pixel,
@@ -1424,10 +1439,11 @@ int gs_render_tiles_backward_packed(const void* packed, const void* rgb, const v
                                     const void* final_weight_per_pixel, const void* grad_image, int W,
                                     int H, int n_sh, int tile_row0, int tile_row1, void* grad_rgb,
                                     void* grad_opacity, void* grad_uv, void* grad_conic, int dtype,
-                                    void* stream) {
+                                    int backward_mode, void* stream) {
     return launch_render_bwd(packed, nullptr, nullptr, rgb, view_dir_by_pixel, tile_ranges, sorted_gaussians,
                              background_rgb, num_splats_per_pixel, final_weight_per_pixel, grad_image, W, H, n_sh,
-                             tile_row0, tile_row1, grad_rgb, grad_opacity, grad_uv, grad_conic, dtype, stream);
+                             tile_row0, tile_row1, grad_rgb, grad_opacity, grad_uv, grad_conic, dtype, backward_mode,
+                             stream);
 }
 
 int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int32_t* tile_ranges,
@@ -1435,10 +1451,13 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
                                   const int32_t* num_splats_per_pixel,
                                   const void* final_weight_per_pixel, const void* grad_image, int W,
                                   int H, int tile_row0, int tile_row1, void* grad_slab,
-                                  const int32_t* tile_cost, int32_t* tile_order, void* stream) {
+                                  const int32_t* tile_cost, int32_t* tile_order, int backward_mode,
+                                  void* stream) {
     GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
     GS_REQUIRE((tile_cost == nullptr) == (tile_order == nullptr), "tile_cost and tile_order go together");
     if (int e = check_rows(H, tile_row0, tile_row1)) return e;
+    int exact = 0;
+    if (int e = resolve_backward_mode(backward_mode, &exact)) return e;
     hipStream_t s = (hipStream_t)stream;
     const int ntx = (W + 15) / 16;
     const int nt = (tile_row1 - tile_row0) * ntx;
@@ -1450,7 +1469,7 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
         (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
         (const float*)background_rgb, num_splats_per_pixel, (const float*)final_weight_per_pixel,
         (const float*)grad_image, W, H, ntx, tile_row0 * ntx, nt, (float*)grad_slab, nullptr,
-        nullptr, nullptr, 1, g_backward_mode, ordered ? tile_order : nullptr, nullptr, nullptr);
+        nullptr, nullptr, 1, exact, ordered ? tile_order : nullptr, nullptr, nullptr);
     return check_launch("render_tiles_backward_slab");
 }
 

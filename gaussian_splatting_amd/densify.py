@@ -95,9 +95,13 @@ class DensityController:
         group = self._group(name)
         return self.optimizer.state.get(group["params"][0], None) if group["params"] else None
 
-    def _swap(self, name, new_tensor, exp_avg=None, exp_avg_sq=None):
+    def _swap(self, name, new_tensor, exp_avg=None, exp_avg_sq=None, restart=False):
         """puts new_tensor (as a Parameter) into the Gaussians struct and the optimizer group `name`, moving
-        the parameter's state entry to the new key with the given moments (None: keep the old ones)"""
+        the parameter's state entry to the new key with the given moments (None: keep the old ones).
+        restart: Adam's step count of the entry goes back to 0 as well -- the reference stores the reset state
+        under the integer keys optimizer.state[3] / [5] (optimizer_manager.py:57,76), which orphans it, so its
+        optimizer re-initialises the new parameter at the next step(): zero moments AND step 0 (bias
+        correction restarts; with the old step count the first updates would be ~3.2x smaller)"""
         group = self._group(name)
         old = group["params"][0]
         state = self.optimizer.state.pop(old, None)
@@ -106,6 +110,8 @@ class DensityController:
         if state:
             if exp_avg is not None:
                 state["exp_avg"], state["exp_avg_sq"] = exp_avg, exp_avg_sq
+            if restart and "step" in state:
+                state["step"] = torch.zeros_like(state["step"]) if torch.is_tensor(state["step"]) else 0
             self.optimizer.state[param] = state
         setattr(self.gaussians, name, param)
 
@@ -115,7 +121,8 @@ class DensityController:
         old = self.gaussians.opacity
         st = self._state("opacity")
         zeros = (torch.zeros_like(old), torch.zeros_like(old)) if st else (None, None)
-        self._swap("opacity", torch.ones_like(old) * inverse_sigmoid(self.config.reset_opacity_value), *zeros)
+        self._swap("opacity", torch.ones_like(old) * inverse_sigmoid(self.config.reset_opacity_value), *zeros,
+                   restart=True)
         self.reset_grad_accum()
 
     # ---- trainer.py:77-112 -----------------------------------------------------------------------------------
@@ -138,7 +145,7 @@ class DensityController:
         new_sh[:, :, :width] = g.sh.detach()
         st = self._state("sh")
         zeros = (torch.zeros_like(new_sh), torch.zeros_like(new_sh)) if st else (None, None)
-        self._swap("sh", new_sh, *zeros)
+        self._swap("sh", new_sh, *zeros, restart=True)
 
     # ---- trainer.py:208-295 ----------------------------------------------------------------------------------
     @torch.no_grad()

@@ -334,9 +334,10 @@ def render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, 
 
 
 def render_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, grad_image, height, width, tile_rows,
-                    V, tile_cost=None):
+                    V, tile_cost=None, backward_mode=None):
     """-> the slab [V, 9] of accumulated render gradients (rgb 3 | opacity 1 | uv 2 | conic 3).
-    tile_cost: render_forward's fourth output (the tiles are then started longest-first)"""
+    tile_cost: render_forward's fourth output (the tiles are then started longest-first).
+    backward_mode: _hip.GS_BACKWARD_COMPAT / _EXACT, per call (ABI 5); None = the process default at the call"""
     nty = (height + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
     row0, row1 = tile_rows if tile_rows is not None else (0, nty)
     slab = torch.zeros(max(V, 1), SLAB_WIDTH, dtype=torch.float32, device=packed.device)
@@ -348,7 +349,8 @@ def render_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, grad
         order = torch.empty(tile_cost.numel() + 8, dtype=torch.int32, device=packed.device)
     _hip.call("gs_render_tiles_backward_slab", _p(packed), _p(rgb), _p(ranges), _p(sorted_g), _p(background_rgb),
               _p(nsp), _p(fw), _p(grad_image), width, height, row0, row1, _p(slab),
-              _p(cost) if cost is not None else None, _p(order) if order is not None else None, _stream())
+              _p(cost) if cost is not None else None, _p(order) if order is not None else None,
+              _hip.GS_BACKWARD_DEFAULT if backward_mode is None else int(backward_mode), _stream())
     return slab[:V]
 
 
@@ -420,6 +422,9 @@ class _Render(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.dims = (height, width, tile_rows, uv.shape[0])
         ctx.slab_sync = slab_sync
+        # the gradient mode of THIS frame is the default at its forward: a later set_backward_mode() cannot
+        # race the backward the autograd engine runs on its own thread
+        ctx.backward_mode = _hip.get_backward_mode()
         return image
 
     @staticmethod
@@ -429,7 +434,7 @@ class _Render(torch.autograd.Function):
         if grad_image is None:
             return (None,) * 15
         slab = render_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, grad_image.contiguous(),
-                               height, width, tile_rows, V, cost)
+                               height, width, tile_rows, V, cost, ctx.backward_mode)
         if ctx.slab_sync is not None:
             ctx.slab_sync(slab.view(-1))   # multi-GPU: sum the partial gradients of all bands in place
         # the four gradients are views of the one slab; _Preprocess.backward recognises that

@@ -318,8 +318,9 @@ class _OwnerPreprocess(torch.autograd.Function):
         full = tuple(None if t is None else (t if t.is_contiguous() else t.contiguous())
                      for t in (g.xyz, g.quaternion, g.scale, g.opacity, g.rgb, g.sh))   # values only (no_grad here)
         bounds = list(rast.bounds)
+        tile_rows = fr.tile_rows = rast.tile_rows   # this frame's band, whatever a later rasterize() makes of rast.bounds
         f = fused.preprocess_forward(*full, camera_T_world, K, width, height, near_thresh, far_thresh,
-                                     cull_mask_padding, mh_dist, rast.tile_rows, sort_prefix,
+                                     cull_mask_padding, mh_dist, tile_rows, sort_prefix,
                                      plan=lambda frm: enqueue_hip_plan(frm, G, me, bounds),
                                      plan_ints=plan_record_ints(G), defer=True)
         if not DEFER_HOST_READ:
@@ -327,7 +328,7 @@ class _OwnerPreprocess(torch.autograd.Function):
 
         def render():
             return fused.render_forward(f.packed, f.rgb_render, f.ranges, f.sorted_buf, f.keys_buf, background_rgb,
-                                        height, width, rast.tile_rows, sort_prefix, image_rows=rast.buffer_rows())
+                                        height, width, tile_rows, sort_prefix, image_rows=rast.buffer_rows())
 
         # the render is enqueued on the speculative tile lists before the host looks at the frame's
         # counts, so the GPU does not wait for the host; a too small capacity repeats it (rare)
@@ -354,6 +355,18 @@ class _OwnerPreprocess(torch.autograd.Function):
         f, plan = fr.f, fr.plan
         camera_T_world, K = fr.cam
         i0, i1 = owner_range(f.N, rast.world_size, rast.rank)
+        # a loss term applied directly to the returned uv arrives here on top of what _OwnerRender.backward
+        # handed over: g_uv = (render rows of the owned Gaussians | the stride-0 zero placeholder) + that
+        # term; the render part is already in owned_rows, the rest is added for the owned rows (every rank
+        # evaluates the same loss, so each owner takes its own slice -- as in the replicated mode)
+        rendered = fr.rendered_uv_grad
+        fr.rendered_uv_grad = None
+        if g_uv is not None and g_uv is not rendered and g_uv.stride() != (0, 0) and plan.v_hi > plan.v_lo:
+            extra = g_uv[plan.v_lo:plan.v_hi]
+            if rendered is not None and rendered.stride() != (0, 0):
+                extra = extra - rendered[plan.v_lo:plan.v_hi]
+            fr.owned_rows = fr.owned_rows.clone()
+            fr.owned_rows[:, 4:6] += extra
         grads = fused.preprocess_backward(fr.full[0], fr.full[1], fr.full[2], camera_T_world, K, f, fr.owned_rows,
                                           v_base=plan.v_lo, i0=i0, i1=i1)
         fr.owned_rows = None
@@ -374,6 +387,11 @@ class _OwnerRender(torch.autograd.Function):
         V = f.V
         ctx.save_for_backward(f.packed, f.rgb_render[:V], f.ranges, f.sorted_g, fr.background, nsp, fw, cost)
         ctx.fr, ctx.rast, ctx.dims = fr, rast, (height, width)
+        # the band and the gradient mode of THIS frame: under band_policy="cost" rast.tile_rows moves with every
+        # rasterize() call, and a second forward before this frame's backward (an eval render, gradient
+        # accumulation over views) must not change the rows the backward covers
+        ctx.tile_rows = fr.tile_rows
+        ctx.backward_mode = _hip.get_backward_mode()
         ctx.set_materialize_grads(False)
         return rast.gather(image, height, ranges=f.ranges, ntx=f.ntx)
 
@@ -387,7 +405,8 @@ class _OwnerRender(torch.autograd.Function):
         f, plan = fr.f, fr.plan
         height, width = ctx.dims
         slab = fused.render_backward(packed, rgb_v, ranges, sorted_g, background_rgb, nsp, fw,
-                                     grad_image.contiguous(), height, width, rast.tile_rows, f.V, cost)
+                                     grad_image.contiguous(), height, width, ctx.tile_rows, f.V, cost,
+                                     ctx.backward_mode)
         owned = plan.exchange(slab, group=rast.group, all_to_all=rast.all_to_all)
         rast.last_owned_render_grads = fr.owned_rows = owned
         uv_out = fr.uv_ref() if fr.uv_ref is not None else None
@@ -396,6 +415,7 @@ class _OwnerRender(torch.autograd.Function):
             g_uv[plan.v_lo:plan.v_hi] = owned[:, 4:6]
         else:   # nobody reads uv.grad: a stride-0 zero costs nothing and still routes the backward
             g_uv = torch.zeros(1, dtype=owned.dtype, device=owned.device).expand(f.V, 2)
+        fr.rendered_uv_grad = g_uv   # _OwnerPreprocess.backward tells it from a gradient a loss put on uv
         return g_uv, None, None, None, None
 
 
@@ -621,7 +641,7 @@ class ShardedRasterizer:
                 raise ValueError("grad_mode 'owner' needs owned= (the parameter slices of this rank)")
             o = (owned.xyz, owned.quaternion, owned.scale, owned.opacity, owned.rgb, owned.sh)
             if use_fused:
-                fr = SimpleNamespace(owned_rows=None, uv_ref=None)
+                fr = SimpleNamespace(owned_rows=None, uv_ref=None, rendered_uv_grad=None, tile_rows=None)
                 uv, culling_mask = _OwnerPreprocess.apply(
                     *o, self, fr, gaussians, camera_T_world.contiguous(), camera.K.contiguous(), int(camera.width),
                     int(camera.height), near_thresh, far_thresh, cull_mask_padding, mh_dist,

@@ -33,12 +33,22 @@ def _stream():
 
 
 def _valid(**tensors):
-    # CHECK_VALID_INPUT (checks.cuh:5-9)
+    # CHECK_VALID_INPUT (checks.cuh:5-9); plus: one device per call, and it is the current one -- the kernels
+    # are launched on the calling thread's current device and its current stream (the compiled module
+    # csrc/bindings_hip.cpp switches devices itself; ctypes has no guard to offer)
+    first = None
     for name, t in tensors.items():
         if not t.is_cuda:
             raise RuntimeError(f"{name} is not a CUDA tensor")
         if not t.is_contiguous():
             raise RuntimeError(f"{name} is not a contiguous tensor")
+        if first is None:
+            first = t.device
+            if first.index != torch.cuda.current_device():
+                raise RuntimeError(f"{name} is on {first} but the current device is cuda:{torch.cuda.current_device()}: "
+                                   "call under torch.cuda.device(...) of the tensors' device")
+        elif t.device != first:
+            raise RuntimeError(f"{name} is on {t.device} but the call's first tensor is on {first}")
 
 
 def _dtype(first, **others):
@@ -332,7 +342,7 @@ def render_tiles_backward_cuda(uvs, opacity, rgb, conic, view_dir_by_pixel, spla
     _hip.call("gs_render_tiles_backward", _p(uvs), _p(opacity), _p(rgb), _p(conic), _p(view_dir_by_pixel),
               _p(splat_start_end_idx_by_tile_idx), _p(gaussian_idx_by_splat_idx), _p(background_rgb),
               _p(num_splats_per_pixel), _p(final_weight_per_pixel), _p(grad_image), _p(grad_rgb), _p(grad_opacity),
-              _p(grad_uv), _p(grad_conic), W, H, n_sh, row0, row1, dt, _stream())
+              _p(grad_uv), _p(grad_conic), W, H, n_sh, row0, row1, dt, _hip.GS_BACKWARD_DEFAULT, _stream())
 
 
 def render_depth_cuda(xyz_camera_frame, uvs, opacity, conic, splat_start_end_idx_by_tile_idx,

@@ -228,14 +228,15 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
                            void* final_weight_per_pixel, void* image, int32_t* tile_cost, void* stream);
 /* render_tiles_backward_cuda (bindings.cpp:120; render_backward.cu:12-595), the reference's arguments in the
  * reference's order.  grad_rgb[V,3,n_sh], grad_opacity[V,1], grad_uv[V,2], grad_conic[V,3] are accumulated.
- * Bug-compatible with render_backward.cu:185 by default; see gs_set_backward_mode. */
+ * backward_mode: GS_BACKWARD_DEFAULT / _COMPAT / _EXACT (below); COMPAT is bug-compatible with
+ * render_backward.cu:185. */
 int gs_render_tiles_backward(const void* uvs, const void* opacity, const void* rgb, const void* conic,
                              const void* view_dir_by_pixel, const int32_t* tile_ranges,
                              const int32_t* sorted_gaussians, const void* background_rgb,
                              const int32_t* num_splats_per_pixel, const void* final_weight_per_pixel,
                              const void* grad_image, void* grad_rgb, void* grad_opacity, void* grad_uv,
                              void* grad_conic, int W, int H, int n_sh, int tile_row0, int tile_row1, int dtype,
-                             void* stream);
+                             int backward_mode, void* stream);
 /* The same from packed records (see gs_render_tiles_packed). */
 int gs_render_tiles_backward_packed(const void* packed, const void* rgb, const void* view_dir_by_pixel,
                                     const int32_t* tile_ranges, const int32_t* sorted_gaussians,
@@ -243,7 +244,7 @@ int gs_render_tiles_backward_packed(const void* packed, const void* rgb, const v
                                     const void* final_weight_per_pixel, const void* grad_image, int W,
                                     int H, int n_sh, int tile_row0, int tile_row1, void* grad_rgb,
                                     void* grad_opacity, void* grad_uv, void* grad_conic, int dtype,
-                                    void* stream);
+                                    int backward_mode, void* stream);
 /* The fused renderer's form of the above (fp32, n_sh == 1): the four gradients of a Gaussian are
  * accumulated into one row of grad_slab[V, 9] = (rgb 3 | opacity 1 | uv 2 | conic 3), which must be
  * zero-initialised (or hold values to accumulate onto).
@@ -255,8 +256,12 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
                                   const int32_t* num_splats_per_pixel,
                                   const void* final_weight_per_pixel, const void* grad_image, int W,
                                   int H, int tile_row0, int tile_row1, void* grad_slab,
-                                  const int32_t* tile_cost, int32_t* tile_order, void* stream);
-/* Gradient mode of the render backward (both entry points above; process-wide, default COMPAT).
+                                  const int32_t* tile_cost, int32_t* tile_order, int backward_mode,
+                                  void* stream);
+/* Gradient mode of the render backward: the `backward_mode` argument of the three entry points above
+ * (ABI 5: per call, so that a trainer switching modes cannot race a backward that the autograd engine's
+ * own thread has queued).  GS_BACKWARD_DEFAULT takes the process-wide default, which gs_set_backward_mode
+ * sets (initially COMPAT) and which is read once, at the call.
  *   GS_BACKWARD_COMPAT  the reference's arithmetic, including render_backward.cu:185: the transmittance is
  *                       divided back by (1 - alpha) only while the CHUNK-LOCAL splat index is below
  *                       num_splats - 1, so for pixels that composite deeper than the reference's first
@@ -264,6 +269,7 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
  *                       the later chunks are off by a factor 1 / (1 - alpha_last)
  *   GS_BACKWARD_EXACT   the same with the GLOBAL splat index: the mathematically exact gradient of the
  *                       forward pass.  Identical to COMPAT whenever no pixel composites past the first chunk. */
+#define GS_BACKWARD_DEFAULT (-1)
 #define GS_BACKWARD_COMPAT 0
 #define GS_BACKWARD_EXACT 1
 int gs_set_backward_mode(int mode);

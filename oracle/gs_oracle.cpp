@@ -56,6 +56,12 @@ int g_sh_band1_mode = 0;
 //   alpha >= 1/255 test before the pixel saturated (render.cu:145-163) -- two runs whose inputs differ
 //   in the last ulp took the same decisions at a pixel iff this count and num_splats agree.
 int g_bwd_abs = 0;
+// g_bwd_sum: how render_tiles_backward sums the per-pixel fp32 terms of a gradient element.  0 (the checker's
+// default): in double, rounded once.  1 / 2: in fp32, as every GPU implementation must (the reference: warp
+// reduce + atomicAdd, order unspecified) -- 1 = pixels of a tile in ascending row-major order, tiles ascending;
+// 2 = both descending.  Two equally valid fp32 summation orders of the SAME terms: their difference is the
+// summation-order noise of the criterion SURVEY.md 8(d) writes down (tests/test_grad_noise_floor.py).
+int g_bwd_sum = 0;
 int g_q1_exact = 0;   // 1: the transmittance update uses the global splat index (exact gradient) instead of
                       // render_backward.cu:185's chunk-local one -- the checker of GS_BACKWARD_EXACT
 int* g_contrib_count = nullptr;
@@ -540,6 +546,7 @@ void orc_set_modes(int exp_mode, int trig_mode) {
 void orc_set_sh_band1_mode(int m) { g_sh_band1_mode = m; }
 void orc_set_backward_abs(int on) { g_bwd_abs = on; }
 void orc_set_backward_exact(int on) { g_q1_exact = on; }
+void orc_set_backward_sum(int mode) { g_bwd_sum = mode; }
 void orc_set_contrib_count(int* per_pixel) { g_contrib_count = per_pixel; }
 int orc_num_threads() {
 #ifdef _OPENMP
@@ -800,6 +807,12 @@ void render_tiles_backward(const T* uvs, const T* opacity, const T* rgb, const T
                            T* g_opacity, T* g_uv, T* g_conic, int tile_y0, int tile_y1) {
     const bool fast = RenderMode<T>::fast;
     const bool abs_mode = g_bwd_abs != 0;
+    const int sum_mode = g_bwd_sum;   // 0: double; 1, 2: fp32 in a fixed order (ascending / descending)
+    // acc += term in the selected arithmetic (fp32: one IEEE float addition per term)
+    auto add = [sum_mode](double& acc, double term) {
+        if (sum_mode == 0) acc += term;
+        else { float t = (float)acc; t += (float)term; acc = (double)t; }
+    };
     const int CH = ref_chunk<T>(n_sh);
     const int ntx = (W + 15) / 16;
     const int nty = (H + 15) / 16;
@@ -807,6 +820,10 @@ void render_tiles_backward(const T* uvs, const T* opacity, const T* rgb, const T
     const int C = 3 * n_sh;
     std::vector<double> acc_rgb((size_t)V * C, 0.0), acc_opa((size_t)V, 0.0),
         acc_uv((size_t)V * 2, 0.0), acc_con((size_t)V * 3, 0.0);
+    // fixed-order fp32 modes: the tiles' sums are kept per instance and combined serially afterwards
+    const int band_s0 = tile_ranges[std::min(tile_y0, nty) * ntx], band_s1 = tile_ranges[tile_y1 * ntx];
+    std::vector<float> inst;
+    if (sum_mode != 0) inst.assign((size_t)std::max(0, band_s1 - band_s0) * (C + 6), 0.0f);
 #pragma omp parallel
     {
         std::vector<double> loc;   // per-tile per-splat accumulators: [n_tile][C + 6]
@@ -820,8 +837,10 @@ void render_tiles_backward(const T* uvs, const T* opacity, const T* rgb, const T
                 const int RW = C + 6;
                 loc.assign((size_t)n_tile * RW, 0.0);
                 int max_used = 0;
-                for (int py = 0; py < 16; py++)
-                    for (int px = 0; px < 16; px++) {
+                for (int pp = 0; pp < 256; pp++) {
+                    {
+                        const int pi = sum_mode == 2 ? 255 - pp : pp;
+                        const int py = pi >> 4, px = pi & 15;
                         const int u_px = tx * 16 + px, v_px = ty * 16 + py;
                         if (u_px >= W || v_px >= H) continue;
                         const size_t p = (size_t)v_px * W + u_px;
@@ -899,7 +918,7 @@ void render_tiles_backward(const T* uvs, const T* opacity, const T* rgb, const T
                             }
                             for (int s = 0; s < n_sh; s++)
                                 for (int ch = 0; ch < 3; ch++)
-                                    L[n_sh * ch + s] += (double)(T)(Y[s] * grl[ch]);
+                                    add(L[n_sh * ch + s], (double)(T)(Y[s] * grl[ch]));
                             T grad_alpha = 0.0;
                             for (int ch = 0; ch < 3; ch++)
                                 grad_alpha += (col[ch] * weight - color_accum[ch] * r1ma) * gi[ch];
@@ -916,16 +935,23 @@ void render_tiles_backward(const T* uvs, const T* opacity, const T* rgb, const T
                             const T gc0 = (-c * cf + v_diff * v_diff * rdet) * grad_mh;
                             const T gc1 = (b * cf - u_diff * v_diff * rdet) * grad_mh;
                             const T gc2 = (-a * cf + u_diff * u_diff * rdet) * grad_mh;
-                            L[C + 0] += (double)grad_opa;
-                            L[C + 1] += (double)grad_u;
-                            L[C + 2] += (double)grad_v;
-                            L[C + 3] += (double)gc0;
-                            L[C + 4] += (double)gc1;
-                            L[C + 5] += (double)gc2;
+                            add(L[C + 0], (double)grad_opa);
+                            add(L[C + 1], (double)grad_u);
+                            add(L[C + 2], (double)grad_v);
+                            add(L[C + 3], (double)gc0);
+                            add(L[C + 4], (double)gc1);
+                            add(L[C + 5], (double)gc2);
                             for (int ch = 0; ch < 3; ch++) color_accum[ch] += col[ch] * alpha * weight;
                         }
                     }
+                }
                 max_used = std::min(max_used, n_tile);
+                if (sum_mode != 0) {
+                    for (int k = 0; k < max_used; k++)
+                        for (int j = 0; j < RW; j++)
+                            inst[(size_t)(s0 - band_s0 + k) * RW + j] = (float)loc[(size_t)k * RW + j];
+                    continue;
+                }
                 for (int k = 0; k < max_used; k++) {
                     const int g = sorted[s0 + k];
                     const double* L = &loc[(size_t)k * RW];
@@ -945,6 +971,22 @@ void render_tiles_backward(const T* uvs, const T* opacity, const T* rgb, const T
                     }
                 }
             }
+    }
+    if (sum_mode != 0) {   // the tiles' fp32 sums, added in fp32 in ascending / descending tile order
+        const int RW = C + 6;
+        const int t_lo = tile_y0 * ntx, t_hi = tile_y1 * ntx;
+        for (int q = t_lo; q < t_hi; q++) {
+            const int tile = sum_mode == 2 ? t_hi - 1 - (q - t_lo) : q;
+            for (int s = tile_ranges[tile]; s < tile_ranges[tile + 1]; s++) {
+                const int g = sorted[s];
+                const float* L = &inst[(size_t)(s - band_s0) * RW];
+                for (int j = 0; j < C; j++) add(acc_rgb[(size_t)g * C + j], L[j]);
+                add(acc_opa[g], L[C]);
+                add(acc_uv[g * 2 + 0], L[C + 1]);
+                add(acc_uv[g * 2 + 1], L[C + 2]);
+                for (int j = 0; j < 3; j++) add(acc_con[g * 3 + j], L[C + 3 + j]);
+            }
+        }
     }
     // accumulate into the caller's buffers (atomicAdd semantics, render_backward.cu:269-281)
     for (size_t j = 0; j < (size_t)V * C; j++) g_rgb[j] += (T)acc_rgb[j];

@@ -227,6 +227,13 @@ def set_backward_exact(on):
     lib().orc_set_backward_exact(int(bool(on)))
 
 
+def set_backward_sum(mode):
+    """how render_tiles_backward_cuda sums a gradient element's per-pixel fp32 terms: 0 = in double, rounded
+    once (default); 1 = in fp32, pixels and tiles ascending; 2 = in fp32, both descending (two equally valid
+    fp32 summation orders of the same terms: their difference is pure summation-order noise)"""
+    lib().orc_set_backward_sum(int(mode))
+
+
 def render_tiles_backward_abs(*args, **kw):
     """render_tiles_backward_cuda with |term| accumulated instead of term: per gradient element the sum
     of the magnitudes of its per-pixel terms (checker aid, no reference counterpart)."""

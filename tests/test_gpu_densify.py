@@ -127,11 +127,14 @@ def test_reset_opacity_and_sh_band_growth_match_the_reference_lines():
     dens.reset_opacity(st, ctrl.config)
     ctrl.reset_opacity()
     compare(g, opt, ctrl, st, g.xyz.shape[0])
+    # the reference orphans the reset state (optimizer_manager.py:57), i.e. Adam restarts for this parameter:
+    # zero moments AND step 0
+    assert float(opt.state[g.opacity]["step"]) == 0.0 and float(opt.state[g.xyz]["step"]) > 0.0
     for _ in range(3):   # 3 -> 8 -> 15 coefficients, then nothing more
         dens.add_sh_band(st, ctrl.config)
         ctrl.add_sh_band()
         compare(g, opt, ctrl, st, g.xyz.shape[0])
-    assert g.sh.shape[2] == 15
+    assert g.sh.shape[2] == 15 and float(opt.state[g.sh]["step"]) == 0.0
     # from no SH at all: a new parameter group appears
     g, opt, ctrl, cam, T = build(3000, 0, seed=12)
     ctrl.add_sh_band()

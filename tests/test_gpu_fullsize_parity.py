@@ -1,0 +1,158 @@
+"""Parity at BASELINE.json's FULL sizes (configs B, C, D) against the CPU oracle run on the WHOLE scene.
+
+tests/test_gpu_scale.py checks the full-size frames by properties and lets the oracle render a few tile rows from
+the GPU's own per-splat inputs and the GPU's own tile lists -- a tile instance the HIP binning dropped at 2.86 M
+Gaussians would pass there.  Here the oracle does the per-Gaussian stage (projection.cu:9-257, the cull of
+rasterize.py:33-75) and get_sorted_gaussian_list (tile_culling.cu:124-340) for every Gaussian of the scene
+(about 3 s of host time at D) and the fused HIP path must reproduce, bit for bit: culling mask, uv,
+xyz_camera_frame, conic, opacity, the visible index, tile_ranges and sorted_gaussians.  The band checks then feed the
+ORACLE's per-splat values and the ORACLE's lists to the oracle's renderer and compare the GPU frame -- the
+product's default path (native orchestration, prefix sort) -- with that."""
+import pytest
+import torch
+
+from gaussian_splatting_amd import fused
+from gaussian_splatting_amd.synthetic import DEFAULTS, WORKLOADS, make_grad_image, make_scene
+
+from .helpers import grad_errors, rel_err, report
+from .test_gpu_fused import cpu_expected_stages
+from .test_gpu_scale import RENDER_GRADS, check_band_backward, oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BAND = {"B": (30, 33), "C": (25, 27), "D": (26, 28)}
+
+
+def expected(workload):
+    N, W, H, deg = WORKLOADS[workload]
+    g, cam, T = make_scene(N, W, H, deg, seed=0)
+    d = DEFAULTS
+    return cpu_expected_stages(g, cam, T, d["near_thresh"], d["far_thresh"], d["cull_mask_padding"], d["mh_dist"])
+
+
+def oracle_band(exp, rgb, W, H, rows, bg, grad_image=None, sum_mode=0):
+    """the oracle's render (+ backward) of tile rows from the ORACLE's own per-splat values and lists"""
+    orc = oracle()
+    img = torch.zeros(H, W, 3)
+    nsp = torch.zeros(H, W, dtype=torch.int32)
+    fw = torch.zeros(H, W)
+    rays = torch.zeros(1, 1, 1)
+    args = (exp["uv"], exp["opacity"].reshape(-1, 1).contiguous(), rgb, exp["conic"], rays, exp["ranges"], exp["sorted"], bg)
+    orc.render_tiles_cuda(*args, nsp, fw, img, tile_rows=rows)
+    out = dict(image=img, nsp=nsp)
+    if grad_image is not None:
+        V = exp["V"]
+        shapes = ((V, 3), (V, 1), (V, 2), (V, 3))
+        g = [torch.zeros(*s) for s in shapes]
+        orc.set_backward_sum(sum_mode)
+        try:
+            orc.render_tiles_backward_cuda(*args, nsp, fw, grad_image, *g, tile_rows=rows)
+        finally:
+            orc.set_backward_sum(0)
+        out.update(g_rgb=g[0], g_opa=g[1], g_uv=g[2], g_conic=g[3])
+        if sum_mode == 0:
+            a = [torch.zeros(*s) for s in shapes]
+            orc.render_tiles_backward_abs(*args, nsp, fw, grad_image, *a, tile_rows=rows)
+            out.update(a_rgb=a[0], a_opa=a[1], a_uv=a[2], a_conic=a[3])
+    return out
+
+
+@pytest.mark.parametrize("workload", ["B", "C", "D"])
+def test_full_scene_stages_and_tile_lists_equal_the_oracle(workload):
+    N, W, H, deg = WORKLOADS[workload]
+    exp = expected(workload)
+    g, cam, T = make_scene(N, W, H, deg, seed=0, device=DEV)
+    bg = torch.full((3,), 0.5, device=DEV)
+    image, mask, uv, aux = fused.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, return_aux=True,
+                                           **DEFAULTS)
+    V = exp["V"]
+    S = int(exp["sorted"].numel())
+    report(f"full_scene_parity[{workload}]", N=N, V=V, S=S)
+    assert 0 < V < N
+    assert torch.equal(mask.cpu(), exp["culled"])
+    assert torch.equal(uv.detach().cpu(), exp["uv"])
+    assert torch.equal(aux["xyz_camera_frame"].cpu(), exp["xyz_c"])
+    assert torch.equal(aux["conic"].detach().cpu(), exp["conic"])
+    assert torch.equal(aux["opacity"].detach().cpu().reshape(-1), exp["opacity"].reshape(-1))
+    assert torch.equal(aux["vis_idx"].cpu().long(), torch.nonzero(~exp["culled"]).flatten())
+    # every tile instance of the frame, in the oracle's order (tile_culling.cu:124-340)
+    assert torch.equal(aux["tile_ranges"].cpu(), exp["ranges"])
+    assert torch.equal(aux["sorted_gaussians"].cpu(), exp["sorted"])
+    # SH colour: identity camera, so the camera centre is (0, 0, 0) on both sides
+    rgb_gpu = aux["rgb"].detach().cpu().contiguous()
+    assert (rgb_gpu - exp["rgb"]).abs().max() < 2e-6
+    rgb = exp["rgb"] if torch.equal(rgb_gpu, exp["rgb"]) else rgb_gpu
+    report(f"full_scene_parity[{workload}]", sh_colour_bit_equal=float(rgb is exp["rgb"]))
+    # the image of the band from the oracle's values and lists
+    rows = BAND[workload]
+    ref = oracle_band(exp, rgb, W, H, rows, bg.cpu())
+    y0, y1 = rows[0] * 16, rows[1] * 16
+    assert torch.equal(image.detach().cpu()[y0:y1], ref["image"][y0:y1])
+    # the product's default path (native orchestration, prefix sort, no aux) renders the same frame
+    image2, mask2, uv2 = fused.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, **DEFAULTS)
+    assert torch.equal(image2, image) and torch.equal(mask2, mask) and torch.equal(uv2, uv)
+
+
+@pytest.mark.parametrize("workload", ["B", "C", "D"])
+def test_band_backward_from_the_oracles_own_inputs(workload):
+    """render backward of a band: GPU (its own pipeline end to end) vs the oracle fed with the oracle's
+    per-splat values and the oracle's tile lists"""
+    N, W, H, deg = WORKLOADS[workload]
+    rows = BAND[workload]
+    exp = expected(workload)
+    g, cam, T = make_scene(N, W, H, deg, seed=0, device=DEV)
+    for k in ("xyz", "rgb", "opacity", "scale", "quaternion", "sh"):
+        getattr(g, k).requires_grad_(True)
+    bg = torch.full((3,), 0.5, device=DEV)
+    img, mask, uv, aux = fused.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, tile_rows=rows,
+                                         return_aux=True, **DEFAULTS)
+    for k in ("conic", "opacity", "rgb"):
+        aux[k].retain_grad()
+    uv.retain_grad()
+    gi = make_grad_image(W, H, seed=1)
+    img.backward(gi.to(DEV))
+    grads = dict(uv=uv.grad, conic=aux["conic"].grad, opacity_act=aux["opacity"].grad, rgb_render=aux["rgb"].grad)
+    rgb_gpu = aux["rgb"].detach().cpu().contiguous()
+    rgb = exp["rgb"] if torch.equal(rgb_gpu, exp["rgb"]) else rgb_gpu
+    ref = oracle_band(exp, rgb, W, H, rows, bg.cpu(), gi)
+    assert torch.equal(img.detach().cpu(), ref["image"])
+    check_band_backward(f"band_backward_from_oracle_inputs[{workload}] rows {rows[0]}-{rows[1]}", grads, ref)
+
+
+def test_gradient_error_is_within_the_fp32_reorder_spread():
+    """SURVEY.md 8(d) writes the gradient criterion with a floor of 1e-6 of the tensor's maximum; the HIP kernel
+    reads ~3e-3 there at workload D (the first parity number of bench.py's line), target 1e-4.  Evidence that this
+    is fp32 summation order and not a kernel error: the oracle sums ITS OWN per-pixel terms (bit-identical terms)
+    in fp32 in two fixed orders (tests/test_grad_noise_floor.py); the criterion between either of those and the
+    double sum is the figure an error-free fp32 implementation gets.  The kernel must stay within 2x of it --
+    per tensor, at the 1e-6 floor, on the D band the bench reports."""
+    workload = "D"
+    N, W, H, deg = WORKLOADS[workload]
+    rows = BAND[workload]
+    exp = expected(workload)
+    g, cam, T = make_scene(N, W, H, deg, seed=0, device=DEV)
+    for k in ("xyz", "rgb", "opacity", "scale", "quaternion", "sh"):
+        getattr(g, k).requires_grad_(True)
+    bg = torch.full((3,), 0.5, device=DEV)
+    img, mask, uv, aux = fused.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, tile_rows=rows,
+                                         return_aux=True, **DEFAULTS)
+    for k in ("conic", "opacity", "rgb"):
+        aux[k].retain_grad()
+    uv.retain_grad()
+    gi = make_grad_image(W, H, seed=1)
+    img.backward(gi.to(DEV))
+    grads = dict(uv=uv.grad, conic=aux["conic"].grad, opacity_act=aux["opacity"].grad, rgb_render=aux["rgb"].grad)
+    rgb_gpu = aux["rgb"].detach().cpu().contiguous()
+    rgb = exp["rgb"] if torch.equal(rgb_gpu, exp["rgb"]) else rgb_gpu
+    ref64 = oracle_band(exp, rgb, W, H, rows, bg.cpu(), gi, sum_mode=0)
+    ref_a = oracle_band(exp, rgb, W, H, rows, bg.cpu(), gi, sum_mode=1)
+    ref_b = oracle_band(exp, rgb, W, H, rows, bg.cpu(), gi, sum_mode=2)
+    for name, key, _ in RENDER_GRADS:
+        spread = max(rel_err(ref_a[key], ref64[key], 1e-6), rel_err(ref_b[key], ref64[key], 1e-6))
+        between = rel_err(ref_a[key], ref_b[key], 1e-6)
+        kernel = rel_err(grads[name], ref64[key], 1e-6)
+        report("fp32_reorder_spread[D rows 26-28]", tensor=name, kernel_vs_double_floor_1e6=kernel,
+               fp32_order_vs_double_floor_1e6=spread, fp32_order_a_vs_b_floor_1e6=between,
+               kernel_floor_1e2=rel_err(grads[name], ref64[key], 1e-2),
+               fp32_order_floor_1e2=max(rel_err(ref_a[key], ref64[key], 1e-2), rel_err(ref_b[key], ref64[key], 1e-2)))
+        assert kernel <= 2.0 * spread, (name, kernel, spread)

@@ -371,3 +371,35 @@ def test_config_D_faint_exact_mode_matches_the_oracle_exact_mode():
     check_band_backward("config_D_faint_band_backward row 26 (exact mode)", grads, ref)
     _, _, _, _, compat, _ = frame("D", tile_rows=rows, opacity_shift=-4.0)
     assert scaled_err(compat["opacity_act"], grads["opacity_act"]) > 1e-3
+
+
+def test_backward_mode_of_a_frame_is_the_mode_at_its_forward():
+    """ABI 5: the render backward takes the gradient mode per call and a fused frame passes the default that was
+    in force at its FORWARD -- switching the default while a backward is still to run (the autograd engine
+    runs it on its own thread) cannot change that frame's gradients.  D-faint band: the two modes differ."""
+    from gaussian_splatting_amd import _hip
+    rows = (26, 27)
+    N, W, H, deg = WORKLOADS["D"]
+    gi = make_grad_image(W, H, seed=1, device=DEV)
+    bg = torch.full((3,), 0.5, device=DEV)
+
+    def run(mode_at_forward, mode_at_backward, aux):
+        g, cam, T = make_scene(N, W, H, deg, seed=0, device=DEV)
+        g.opacity.add_(-4.0)
+        g.opacity.requires_grad_(True)
+        try:
+            _hip.set_backward_mode(mode_at_forward)
+            out = fused.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, tile_rows=rows, return_aux=aux,
+                                  **DEFAULTS)
+            _hip.set_backward_mode(mode_at_backward)
+            out[0].backward(gi)
+        finally:
+            _hip.set_backward_mode("compat")
+        return g.opacity.grad
+
+    for aux in (True, False):   # the Python orchestration and the native one (csrc/frame_hip.cpp)
+        exact = run("exact", "exact", aux)
+        compat = run("compat", "compat", aux)
+        assert scaled_err(compat, exact) > 1e-3
+        assert scaled_err(run("exact", "compat", aux), exact) < 1e-5
+        assert scaled_err(run("compat", "exact", aux), compat) < 1e-5

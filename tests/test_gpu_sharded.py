@@ -73,8 +73,22 @@ def test_halo_plan_matches_reference_and_oracle(G):
 @pytest.mark.parametrize("G,deg,N,W,H,near,policy", [(2, 3, 20000, 640, 472, 2.0, "equal"), (3, 0, 20000, 640, 472, 2.0, "equal"),
                                                       (8, 3, 60000, 800, 608, 2.0, "equal"), (4, 1, 3000, 96, 40, 2.0, "equal"),
                                                       (2, 0, 3000, 96, 40, 1e4, "equal"), (3, 3, 20000, 640, 472, 2.0, "cost"),
-                                                      (8, 0, 60000, 800, 608, 2.0, "cost")])
+                                                      (8, 0, 60000, 800, 608, 2.0, "cost"),
+                                                      # forward, bands move, second forward, THEN the first frame's backward
+                                                      (3, 3, 20000, 640, 472, 2.0, "cost-ffb"),
+                                                      # a loss term directly on the returned uv, next to the image loss
+                                                      (2, 3, 20000, 640, 472, 2.0, "equal-uvloss")])
 def test_owner_mode_with_simulated_ranks(G, deg, N, W, H, near, policy):
+    ffb = policy == "cost-ffb"
+    uvloss = policy == "equal-uvloss"
+    policy = "cost" if ffb else ("equal" if uvloss else policy)
+    uv_dir = torch.randn(N, 2, generator=torch.Generator().manual_seed(5)).to(DEV) * 1e-7
+
+    def backward(img, uv):
+        if uvloss:   # every rank evaluates the same un-averaged loss (the ShardedRasterizer contract)
+            torch.autograd.backward([img, (uv * uv_dir[:uv.shape[0]]).sum()], [gi, None])
+        else:
+            img.backward(gi)
     bg = torch.full((3,), 0.5, device=DEV)
     nty = (H + 15) // 16
     row_costs = [1 + 40 * (r % 5 == 0) + r for r in range(nty)]   # cost policy: an uneven split, the same on every rank
@@ -86,7 +100,7 @@ def test_owner_mode_with_simulated_ranks(G, deg, N, W, H, near, policy):
             getattr(g0, k).requires_grad_(True)
     ref_img, ref_mask, ref_uv = fused.rasterize(g0, T0, cam0, *args, True, bg)
     ref_uv.retain_grad()
-    ref_img.backward(gi)
+    backward(ref_img, ref_uv)
     ref_img = ref_img.detach()
     ref_grads = {k: getattr(g0, k).grad for k in PARAMS if getattr(g0, k) is not None}
     sent = {}
@@ -101,10 +115,19 @@ def test_owner_mode_with_simulated_ranks(G, deg, N, W, H, near, policy):
         img, mask, uv = rast.rasterize(g, T, cam, *args, True, bg, owned=owned)
         if want_uv_grad:
             uv.retain_grad()
-        img.backward(gi)
+        plan = rast.last_plan
+        if ffb:
+            # an eval render (or the next view of a gradient-accumulation step) on other bands before this
+            # frame's backward: the backward must still cover the rows its forward rendered
+            first = rast.bounds
+            rast.set_row_costs(list(reversed(row_costs)))
+            assert rast.bounds != first
+            with torch.no_grad():
+                rast.rasterize(g, T, cam, *args, True, bg, owned=owned)
+        backward(img, uv)
+        rast.last_plan = plan
         if want_uv_grad:
             # trainer.py:360,379: uv.grad = the render-backward grad_uv -- complete for the owned Gaussians
-            plan = rast.last_plan
             assert uv.grad is not None and uv.grad.shape == ref_uv.grad.shape
             if plan.v_hi > plan.v_lo:
                 assert scaled_err(uv.grad[plan.v_lo:plan.v_hi], ref_uv.grad[plan.v_lo:plan.v_hi]) < 1e-5
@@ -134,7 +157,7 @@ def test_owner_mode_with_simulated_ranks(G, deg, N, W, H, near, policy):
         run(r, recorder(r))
     images, sparse_rows = [], 0
     for r in range(G):
-        img, mask, owned, rast = run(r, router(r), want_uv_grad=(r % 2 == 0))
+        img, mask, owned, rast = run(r, router(r), want_uv_grad=(r % 2 == 0 and not uvloss))
         images.append(img)
         assert torch.equal(mask, ref_mask)
         i0, i1 = owner_range(N, G, r)
