@@ -386,7 +386,15 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_emit(
         // trip overlaps the following separating-axis test, changes nothing: 0.293 vs 0.291 ms)
         wave_for_each_tile(active, tw, ntx, key, [&](int tile, uint64_t k) {
             const int pos = atomicAdd(&s_cursor[tile], 1);
+#if defined(GS_EMIT_NOSTORE)      // experiment builds (timing only): the walk + LDS cursors without the key stores
+            if (pos < 0) keys[pos] = k;
+#elif defined(GS_EMIT_CELL)       // ... and with the stores going to (4x4-tile cell, workgroup) runs instead of tile segments
+            const int cell = ((tile / ntx) >> 2) * ((ntx + 3) >> 2) + ((tile % ntx) >> 2);
+            const int64_t at = ((int64_t)cell * PRIV_NB + sl) * 40 + (pos % 40);
+            if (at < cap) keys[at] = k;
+#else
             if (pos < cap) keys[pos] = k;
+#endif
         });
     }
 }

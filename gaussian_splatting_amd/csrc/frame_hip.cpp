@@ -57,6 +57,13 @@ struct Counters {
 std::vector<Tensor> g_flag_log;
 Tensor g_last_flags;   // tile_flags of the latest prefix-mode render (tests / tools)
 bool g_sort_prefix = true, g_early_render = true;
+// depth segments of the backward (include/gsplat_hip.h: gs_render_segment_workspace_bytes): 0 = auto (frames /
+// bands of fewer than 1500 tiles whose lists average >= 192 entries: a multi-GPU rank's band), 1 = always, -1 = never
+int g_segments = 0;
+bool want_segments(int64_t n_instances, int64_t n_tiles) {
+    if (g_segments == 0) return n_tiles > 0 && n_tiles < 1500 && n_instances >= 192 * n_tiles;
+    return g_segments > 0 && n_tiles > 0;
+}
 
 // optional per-entry-point timing (bench.py): events on the launch stream around every C-ABI call, so the
 // elapsed time of one entry point is the GPU time of the kernels it enqueues
@@ -135,7 +142,7 @@ void require_f32_cuda(const Tensor& t, const char* name, c10::Device dev, std::i
 }
 
 struct RenderOut {
-    Tensor buf, image, fw, nsp;
+    Tensor buf, image, fw, nsp, seg;   // seg: state for the depth-segmented backward (empty: not segmented)
 };
 
 RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* ranges, Tensor& sorted, Tensor& keys,
@@ -154,13 +161,16 @@ RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* 
     r.fw = r.buf.narrow(0, 3 * P, P).view({H, W});
     r.nsp = r.buf.narrow(0, 4 * P, P).view(torch::kInt32).view({H, W});
     int32_t* tile_cost = reinterpret_cast<int32_t*>(r.buf.data_ptr<float>()) + 5 * P;
+    const bool segments = want_segments(sorted.size(0), (int64_t)(row1 - row0) * ntx);
+    r.seg = torch::empty({segments ? (int64_t)(gs_render_segment_workspace_bytes(W, H) / 4) : 0}, opt);
+    void* seg_p = segments ? r.seg.data_ptr() : nullptr;
     if (sort_prefix && sorted.size(0) > sort_prefix) {
         Tensor flags = torch::empty({(int64_t)ntx * nty}, opt.dtype(torch::kInt32));
         timed("gs_render_tiles_prefix", stream, [&] {
             return gs_render_tiles_prefix(packed, rgbr, ranges, sorted.data_ptr<int32_t>(),
                                           (const uint64_t*)keys.data_ptr<int64_t>(), sorted.size(0), bg.data_ptr(), W, H, row0,
                                           row1, flags.data_ptr<int32_t>(), r.nsp.data_ptr<int32_t>(), r.fw.data_ptr(),
-                                          r.image.data_ptr(), tile_cost, stream);
+                                          r.image.data_ptr(), tile_cost, seg_p, stream);
         });
         std::lock_guard<std::mutex> lock(g_mutex);
         if (g_flag_log.size() < 512) g_flag_log.push_back(flags);
@@ -171,7 +181,7 @@ RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* 
                     "hipMemsetAsync failed");
         timed("gs_render_tiles_packed", stream, [&] {
             return gs_render_tiles_packed(packed, rgbr, nullptr, ranges, sorted.data_ptr<int32_t>(), bg.data_ptr(), W, H, 1, row0, row1,
-                                   r.nsp.data_ptr<int32_t>(), r.fw.data_ptr(), r.image.data_ptr(), GS_F32, stream);
+                                   r.nsp.data_ptr<int32_t>(), r.fw.data_ptr(), r.image.data_ptr(), GS_F32, seg_p, stream);
         });
     }
     return r;
@@ -286,8 +296,8 @@ struct Preprocess : public torch::autograd::Function<Preprocess> {
         ctx->saved_data["n_sh"] = (int64_t)n_sh;
         ctx->saved_data["V"] = V;
         ctx->set_materialize_grads(false);
-        ctx->mark_non_differentiable({packed_t, ranges_t, sorted_g, mask_t, out.image, out.fw, out.nsp});
-        return {uv_t, conic_t, opa_t, rgbr_t, packed_t, ranges_t, sorted_g, mask_t, out.image, out.fw, out.nsp};
+        ctx->mark_non_differentiable({packed_t, ranges_t, sorted_g, mask_t, out.image, out.fw, out.nsp, out.seg});
+        return {uv_t, conic_t, opa_t, rgbr_t, packed_t, ranges_t, sorted_g, mask_t, out.image, out.fw, out.nsp, out.seg};
     }
 
     static variable_list backward(AutogradContext* ctx, variable_list g) {
@@ -351,9 +361,9 @@ struct Preprocess : public torch::autograd::Function<Preprocess> {
 // ---- node 2: the per-splat quantities + lists -> image (already enqueued by node 1) ------------------------
 struct Render : public torch::autograd::Function<Render> {
     static Tensor forward(AutogradContext* ctx, Tensor uv, Tensor conic, Tensor opacity, Tensor rgbr, Tensor packed,
-                          Tensor ranges, Tensor sorted_g, Tensor bg, Tensor image, Tensor fw, Tensor nsp, int64_t row0,
-                          int64_t row1) {
-        ctx->save_for_backward({packed, rgbr, ranges, sorted_g, bg, nsp, fw});
+                          Tensor ranges, Tensor sorted_g, Tensor bg, Tensor image, Tensor fw, Tensor nsp, Tensor seg,
+                          int64_t row0, int64_t row1) {
+        ctx->save_for_backward({packed, rgbr, ranges, sorted_g, bg, nsp, fw, seg});
         ctx->saved_data["row0"] = row0;
         ctx->saved_data["row1"] = row1;
         ctx->saved_data["V"] = uv.size(0);
@@ -365,10 +375,11 @@ struct Render : public torch::autograd::Function<Render> {
     }
 
     static variable_list backward(AutogradContext* ctx, variable_list g) {
-        variable_list out(13);
+        variable_list out(14);
         if (!g[0].defined()) return out;
         auto s = ctx->get_saved_variables();
-        const Tensor &packed = s[0], &rgbr = s[1], &ranges = s[2], &sorted_g = s[3], &bg = s[4], &nsp = s[5], &fw = s[6];
+        const Tensor &packed = s[0], &rgbr = s[1], &ranges = s[2], &sorted_g = s[3], &bg = s[4], &nsp = s[5], &fw = s[6],
+                     &seg = s[7];
         const int64_t V = ctx->saved_data["V"].toInt();
         const int H = (int)nsp.size(0), W = (int)nsp.size(1);
         Tensor grad_image = g[0].contiguous();
@@ -380,12 +391,14 @@ struct Render : public torch::autograd::Function<Render> {
         int32_t* tile_cost = nsp.data_ptr<int32_t>() + (int64_t)W * H;
         // longest-first only pays where a workgroup lives long enough for the kernel's tail to matter: lists of a
         // few hundred entries per tile (workload B, 52 per tile: the order kernel's 6 us are not won back)
-        const bool ordered = sorted_g.size(0) >= 256 * T;
+        const bool segmented = seg.numel() > 0;
+        const bool ordered = !segmented && sorted_g.size(0) >= 256 * T;
         timed("gs_render_tiles_backward_slab", stream, [&] {
             return gs_render_tiles_backward_slab(packed.data_ptr(), rgbr.data_ptr(), ranges.data_ptr<int32_t>(),
                                                  sorted_g.data_ptr<int32_t>(), bg.data_ptr(), nsp.data_ptr<int32_t>(),
                                                  fw.data_ptr(), grad_image.data_ptr(), W, H, row0, row1, slab.data_ptr(),
                                                  ordered ? tile_cost : nullptr, ordered ? tile_cost + T : nullptr,
+                                                 segmented ? seg.data_ptr() : nullptr,
                                                  (int)ctx->saved_data["bwd_mode"].toInt(), stream);
         });
         Tensor rows = slab.narrow(0, 0, V);
@@ -428,7 +441,7 @@ std::tuple<Tensor, Tensor, Tensor> rasterize(Tensor xyz, Tensor quaternion, Tens
                                rgb.contiguous(), sh, camera_T_world.contiguous(), K.contiguous(), background_rgb.contiguous(),
                                width, height, near_thresh, far_thresh, cull_mask_padding, mh_dist, row0, row1);
     Tensor image = Render::apply(o[0], o[1], o[2], o[3], o[4], o[5], o[6], background_rgb.contiguous(), o[8], o[9], o[10],
-                                 row0, row1);
+                                 o[11], row0, row1);
     return std::make_tuple(image, o[7], o[0]);
 }
 
@@ -502,6 +515,8 @@ py::dict collect_timing() {
     return d;
 }
 
+void set_segments(int mode) { g_segments = mode; }
+
 void set_modes(bool sort_prefix, bool early_render) {
     g_sort_prefix = sort_prefix;
     g_early_render = early_render;
@@ -518,6 +533,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("counters", &counters);
     m.def("reset_counters", &reset_counters);
     m.def("set_modes", &set_modes, py::arg("sort_prefix"), py::arg("early_render"));
+    m.def("set_segments", &set_segments, py::arg("mode"));
     m.def("last_tile_flags", &last_tile_flags, py::arg("clear") = false);
     m.def("enable_timing", &enable_timing, py::arg("on"), py::arg("only") = std::string());
     m.def("reserve_events", &reserve_events);

@@ -438,20 +438,72 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int* __restrict__ cos
     }
 }
 
+// ---- depth segments of the fused backward ------------------------------------------------------------
+// The backward of a tile is a serial walk over its list, back to front; one workgroup per tile lives
+// ~150 us, the chip drains for the last fifth of the kernel (4b of DESIGN.md) and a multi-GPU rank's band of
+// ~540 tiles is two workgroups per CU.  Splitting the walk by DEPTH gives 3-4x more, 3-4x shorter work
+// items -- but a segment that starts in the middle of a pixel's list needs the state the walk would have
+// there: the transmittance in front of it and the colour accumulated behind it.  The forward knows both
+// and leaves them behind (CK instantiation of the fp32 one-coefficient kernel):
+//   per (tile, segment s, pixel)  rec = (P_s, E_s): P_s = product of (1 - alpha) over the segment's contributors,
+//                                 E_s = sum of colour * alpha * (product of (1 - alpha) over the segment's EARLIER
+//                                 contributors) -- the segment's transmittance and colour as seen from its near
+//                                 boundary; 16 bytes, written when the forward crosses into the next segment
+//   per pixel                     kend = index after its last contributing splat, and -- evaluated in the
+//                                 epilogue for that one splat with the BACKWARD's arithmetic -- 1 - alpha
+//                                 and the background weight the backward's first contributor adds
+// The backward's walk multiplies weight by 1 / (1 - alpha) per contributor, starting from final_weight (x the
+// factor q that render_backward.cu:185 applies -- or not -- at the first contributor, SURVEY.md Q1, which
+// then stays in every weight of the walk).  Its weight at the near boundary of segment s' is therefore
+//   w(s') = w(s' + 1) / P_s'      from      w(e) = final_weight q (1 - alpha_last) / P_e     (e: the segment
+// of the last contributor, whose own factor is in P_e), the colour the walk has accumulated behind segment s is
+// bg_weight bg + sum_{s' > s} w(s') E_s', and a workgroup (tile, s) starts every pixel whose list goes deeper
+// than its segment from those two; pixels that end inside the segment start as before, pixels that ended in
+// front of it do nothing.  (Why products of the (1 - alpha) and not the forward's own transmittance 1 - acc:
+// the reference's walk starts from final_weight = 1 - acc of a nearly saturated pixel, whose cancellation error
+// -- up to 1e-3 relative -- it carries into every weight of the pixel; a segment that started from the
+// forward's accurate 1 - acc at its boundary would be closer to the true derivative and 3e-4 away from the
+// reference.  Measured.)
+// "Contributor" means: in the BACKWARD's arithmetic -- its alpha differs from the forward's in the last ulp
+// and the two can disagree at the 1/255 threshold; the forward evaluates the backward's form where they could
+// (see its visit), so the state it leaves describes exactly the walk the unsegmented kernel would do.
+constexpr int SEG_LEN = 128;   // entries per segment (a multiple of the 64-entry mask words)
+constexpr int SEG_MAX = 8;     // segments per tile; the last one is open-ended
+struct SegState {              // views into the caller's workspace (gs_render_segment_workspace_bytes)
+    int* kend;                 // [H W]
+    float* oma_last;           // [H W]
+    float* bgw;                // [H W]
+    Vec4<float>* rec;          // [tiles][SEG_MAX][256]
+};
+__host__ __device__ inline SegState seg_state_of(void* ws, int W, int H) {
+    SegState st{nullptr, nullptr, nullptr, nullptr};
+    if (ws == nullptr) return st;
+    const size_t P = (size_t)W * H;
+    char* p = (char*)ws;
+    st.rec = (Vec4<float>*)p;   // first: 16-byte aligned
+    p += (size_t)((W + 15) / 16) * ((H + 15) / 16) * SEG_MAX * 256 * sizeof(Vec4<float>);
+    st.kend = (int*)p;
+    st.oma_last = (float*)(p + 4 * P);
+    st.bgw = (float*)(p + 8 * P);
+    return st;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
 // One tile by one workgroup.  sort_prefix > 0: prefix mode (binning.hip "prefix sort"), only the
 // first sort_prefix entries of a prefix-sorted tile's segment are there; tile_flags[tile] is set to
 // whether the tile ran out of them.  flagged_only: the repair call, full list, flags untouched.
-template <typename T, int N_SH>
+template <typename T, int N_SH, bool CK = false>
 __device__ __forceinline__ void render_tile_fwd(
     const int tile, const T* __restrict__ packed, const T* __restrict__ rgb,
     const T* __restrict__ view_dir, const int* __restrict__ ranges, const int* __restrict__ sorted,
     const T* __restrict__ bg, int W, int H, int ntx, int* __restrict__ nsp_out,
     T* __restrict__ fw_out, T* __restrict__ image, int sort_prefix, int* __restrict__ tile_flags,
     bool flagged_only, int64_t cap, int* __restrict__ tile_cost = nullptr,
-    const T* __restrict__ src_opacity = nullptr, const T* __restrict__ src_conic = nullptr) {
+    const T* __restrict__ src_opacity = nullptr, const T* __restrict__ src_conic = nullptr,
+    const SegState seg = SegState{nullptr, nullptr, nullptr, nullptr}) {
+    static_assert(!CK || (sizeof(T) == 4 && N_SH == 1), "segment checkpoints: the fused renderer's kernel only");
     constexpr bool fast = sizeof(T) == 4;
     // the tile's own duration in 16-cycle units: the launch-order key of the backward (k_tile_order)
     const unsigned long long cost_c0 = tile_cost ? __builtin_readcyclecounter() : 0ull;
@@ -498,6 +550,23 @@ __device__ __forceinline__ void render_tile_fwd(
     constexpr int NW = RCHUNK / 64 > 0 ? RCHUNK / 64 : 1;
     __shared__ unsigned long long s_mask[4][NW];
 
+    // CK: state for the depth-segmented backward (see "depth segments" above)
+    T segL = 1;                    // product of (1 - alpha) over the current segment's contributors so far
+    T sg0 = 0, sg1 = 0, sg2 = 0;   // sum of colour * alpha * (that product before the splat): the segment's colour
+    int kend = 0;                  // index after the last contributing splat
+    int b_cur = 0;                 // current segment (wave-uniform)
+    bool wave_fin = false;         // the wave's last record is written (every pixel of the patch saturated)
+    auto write_record = [&]() {
+        if constexpr (CK) {
+            Vec4<float> r4;
+            r4.x = segL; r4.y = sg0; r4.z = sg1; r4.w = sg2;
+#ifndef GS_CK_NOREC   // (A/B builds that time the parts of the extra work; wrong gradients)
+            seg.rec[((size_t)tile * SEG_MAX + b_cur) * RB + tid] = r4;
+#endif
+            segL = 1; sg0 = 0; sg1 = 0; sg2 = 0;
+        }
+    };
+
     bool all_done = false;
     GS_STAT_DECL;
     GS_STAT(0, 1);          // waves
@@ -524,9 +593,39 @@ __device__ __forceinline__ void render_tile_fwd(
                     if (!(du * du + dv * dv > r.g0.z)) {
                         GS_STAT_SET(st_in);
                         const T a = r.g1.x, b = r.g1.y, c = r.g1.z, det = r.g1.w;
-                        const T mh = div_by_reciprocal(c * du * du - (b + b) * du * dv + a * dv * dv, det, r.g2.x);
+                        const T mh_num = c * du * du - (b + b) * du * dv + a * dv * dv;
+                        const T mh = div_by_reciprocal(mh_num, det, r.g2.x);
                         T alpha = r.g0.w * exp_neg_half(mh);
                         alpha = (mh > T(0)) ? alpha : T(0);                 // render.cu:133
+                        if constexpr (CK) {
+                            // What the BACKWARD's walk will see at this entry.  It forms alpha from mh * (1 / det)
+                            // (render_backward.cu:153-157; the forward divides), a last-ulp difference that matters
+                            // in two places: next to the 1/255 threshold, where the two forms can disagree on whether
+                            // the splat contributes at all (~50 (pixel, splat) pairs of a frame at workload D; the
+                            // reference's walk then carries one factor 1 / (1 - 1/255) more or less than its forward
+                            // did, and so must the segments), and in 1 - alpha for alpha near 1 (6e-8 / (1 - alpha)
+                            // relative on the walk's factor).  There the backward's alpha is evaluated as well
+                            // (a few percent of the visits); elsewhere the forward's is within 6e-7 of it.
+                            // Values for the backward only: contraction allowed.
+#pragma clang fp contract(fast)
+                            T ab = alpha;
+                            const bool near = __builtin_fabsf(alpha - Thr<T>::alpha_min()) < T(4e-8) || alpha > T(0.9);
+                            if (near) {   // (skipped by the whole wave when no lane is near: s_cbranch_execz)
+                                const T mh_b = mh_num * r.g2.x;
+                                const T e_b = exp_neg_half(mh_b);
+                                ab = r.g0.w * ((mh_b > T(0)) ? e_b : T(0));
+                            }
+                            // branch-free: a splat the backward skips enters with alpha 0 (changes nothing)
+                            const bool cb = ab >= Thr<T>::alpha_min();
+                            const T cap = Thr<T>::alpha_cap();
+                            if (b_cur > 0) {   // (wave-uniform; nobody reads segment 0's record: no segment lies in front of it)
+                                const T ac = cb ? ((ab > cap) ? cap : ab) : T(0);   // the backward caps alpha
+                                const T aL = ac * segL;
+                                sg0 += r.g2.y * aL; sg1 += r.g2.z * aL; sg2 += r.g2.w * aL;
+                                segL -= aL;   // segL (1 - ac)
+                            }
+                            kend = cb ? base + i + 1 : kend;
+                        }
                         if (!(alpha < Thr<T>::alpha_min())) {               // render.cu:145
                             GS_STAT_SET(st_hit);
                             fw = 1.0 - acc;
@@ -547,7 +646,21 @@ __device__ __forceinline__ void render_tile_fwd(
                 GS_STAT(5, __popcll(ballot(st_hit)));
             };
             for (int word = 0; word < NW && word * 64 < cnt; word++) {
-                if (ballot(!done) == 0) break;   // wave-uniform: every pixel of the patch saturated
+                if constexpr (CK) {
+                    // crossing into the next depth segment: leave the state at the boundary behind
+                    const int sidx = min((base + word * 64) / SEG_LEN, SEG_MAX - 1);
+                    if (sidx != b_cur && !wave_fin) {
+                        write_record();
+                        b_cur = sidx;
+                    }
+                }
+                if (ballot(!done) == 0) {   // wave-uniform: every pixel of the patch saturated
+                    if constexpr (CK) {
+                        if (!wave_fin) write_record();
+                        wave_fin = true;
+                    }
+                    break;
+                }
                 unsigned long long m = wave_uniform(s_mask[wave][word]);
                 if (m == 0) continue;
                 LdsRecord ra, rb;
@@ -632,6 +745,35 @@ __device__ __forceinline__ void render_tile_fwd(
     // an unsaturated pixel at the end of the prefix: the tile is redone from its full list
     if (tile_flags != nullptr && !flagged_only && tid == 0) tile_flags[tile] = prefix_only && !all_done;
 
+    if constexpr (CK) {
+        if (!wave_fin) write_record();   // the segment the list (or its ordered prefix) ended in
+        if (valid) {
+            // the pixel's last contributor once more, in the BACKWARD's arithmetic (k_render_bwd: alpha from
+            // mh * (1 / det), capped at 0.9999): what its first step does to weight and colour_accum
+            T oma_last = 1, bgw = 0;
+#ifdef GS_CK_NOEPI
+            if (kend < 0) {
+#else
+            if (kend > 0) {
+#endif
+                const int g = sorted[s0 + kend - 1];
+                const Vec4<T>* rec = reinterpret_cast<const Vec4<T>*>(packed + (size_t)g * GS_PACKED_WIDTH);
+                const Vec4<T> g0 = rec[0], g1 = rec[1], g2 = rec[2];
+                const T du = pu - g0.x, dv = pv - g0.y;
+                const T mh = (g1.z * du * du - (g1.y + g1.y) * du * dv + g1.x * dv * dv) * g2.x;
+                const T e = exp_neg_half(mh);
+                T alpha = g0.w * ((mh > T(0)) ? e : T(0));
+                if (alpha > Thr<T>::sat_gt()) alpha = Thr<T>::alpha_cap();
+                const T bw = 1.0 - (alpha * fw + 1.0 - fw);   // render_backward.cu:172-181
+                if (bw > Thr<T>::bgw_gt()) bgw = bw;
+                oma_last = T(1) - alpha;
+            }
+            const size_t p = (size_t)px.v * W + px.u;
+            seg.kend[p] = kend;
+            seg.oma_last[p] = oma_last;
+            seg.bgw[p] = bgw;
+        }
+    }
     if (valid) {
         if (acc < Thr<T>::bg_lt()) {   // render.cu:169
 #pragma unroll
@@ -660,17 +802,35 @@ __global__ __launch_bounds__(RB) void k_render_fwd(
                              src_conic);
 }
 
+// the fused renderer's forward that also leaves the state for the depth-segmented backward
+#ifndef GS_FWD_CK_WAVES
+#define GS_FWD_CK_WAVES 5   // no spills at 5 (90 VGPRs); the kernel runs where a band leaves 2-3 waves per SIMD anyway
+#endif
+__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(GS_FWD_CK_WAVES, 8))) void k_render_fwd_ck(
+    const float* __restrict__ packed, const float* __restrict__ rgb, const int* __restrict__ ranges,
+    const int* __restrict__ sorted, const float* __restrict__ bg, int W, int H, int ntx, int tile0, int nt,
+    int* __restrict__ nsp_out, float* __restrict__ fw_out, float* __restrict__ image, int sort_prefix,
+    int* __restrict__ tile_flags, int64_t cap, int* __restrict__ tile_cost, const SegState seg) {
+    const int t_local = tile_of_block(blockIdx.x, nt);
+    if (t_local >= nt) return;
+    render_tile_fwd<float, 1, true>(tile0 + t_local, packed, rgb, nullptr, ranges, sorted, bg, W, H, ntx, nsp_out,
+                                    fw_out, image, sort_prefix, tile_flags, false, cap, tile_cost, nullptr, nullptr,
+                                    seg);
+}
+
 // repair pass of the prefix mode: a small grid walks the flags and renders the flagged tiles again,
 // now from their fully sorted lists
-__global__ __launch_bounds__(RB) void k_render_fwd_flagged(
+template <bool CK>
+__global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(GS_FWD_CK_WAVES, 8))) void k_render_fwd_flagged(
     const float* __restrict__ packed, const float* __restrict__ rgb, const int* __restrict__ ranges,
     const int* __restrict__ sorted, const float* __restrict__ bg, int W, int H, int ntx, int tile0,
     int nt, int* __restrict__ nsp_out, float* __restrict__ fw_out, float* __restrict__ image,
-    int* __restrict__ tile_flags, int64_t cap, int* __restrict__ tile_cost) {
+    int* __restrict__ tile_flags, int64_t cap, int* __restrict__ tile_cost, const SegState seg) {
     for (int t = blockIdx.x; t < nt; t += gridDim.x) {
         if (tile_flags[tile0 + t] == 0) continue;
-        render_tile_fwd<float, 1>(tile0 + t, packed, rgb, nullptr, ranges, sorted, bg, W, H, ntx,
-                                  nsp_out, fw_out, image, 0, tile_flags, true, cap, tile_cost);
+        render_tile_fwd<float, 1, CK>(tile0 + t, packed, rgb, nullptr, ranges, sorted, bg, W, H, ntx,
+                                      nsp_out, fw_out, image, 0, tile_flags, true, cap, tile_cost, nullptr, nullptr,
+                                      seg);
         __syncthreads();
     }
 }
@@ -825,7 +985,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     const int* __restrict__ nsp_in, const T* __restrict__ fw_in, const T* __restrict__ grad_image,
     int W, int H, int ntx, int tile0, int nt, T* __restrict__ g_rgb, T* __restrict__ g_opa,
     T* __restrict__ g_uv, T* __restrict__ g_conic, int slab, int exact, const int* __restrict__ tile_order,
-    const T* __restrict__ src_opacity, const T* __restrict__ src_conic) {
+    const T* __restrict__ src_opacity, const T* __restrict__ src_conic, const SegState seg) {
     constexpr bool fast = sizeof(T) == 4;
     constexpr int CW = ColW<N_SH>::value;
     constexpr int C = 3 * N_SH;
@@ -846,7 +1006,16 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     __shared__ unsigned long long s_mask[4][NWORD];
     __shared__ unsigned long long s_hit[SLOTS ? 4 : 1][NWORD];   // SLOTS: slots written by each wave
 
-    const int t_local = tile_order ? tile_order[blockIdx.x] : tile_of_block(blockIdx.x, nt);
+    // depth segments (fused renderer, seg.rec != nullptr): work item = (tile, segment), block index =
+    // segment * grid + block of the tile; segment 0 -- every pixel active, the most work -- starts first
+    int seg_id = 0, blk = blockIdx.x;
+    const bool seg_on = SLOTS && seg.rec != nullptr;
+    if (seg_on) {
+        const int g0 = render_grid(nt);
+        seg_id = blockIdx.x / g0;
+        blk = blockIdx.x - seg_id * g0;
+    }
+    const int t_local = tile_order ? tile_order[blk] : tile_of_block(blk, nt);
     if (t_local < 0 || t_local >= nt) return;
     const int tile = tile0 + t_local;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -860,12 +1029,21 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     T weight = 0;
     T gi[3] = {0, 0, 0};
     T Y[N_SH];
+    int kend = 0;                 // segments: index after the pixel's last contributor, and what the backward's
+    float oma_last = 1, bgw = 0;  // first step at that splat does (written by the forward's epilogue)
     {
         T d[3] = {0, 0, 0};
         if (valid) {
             const size_t p = (size_t)px.v * W + px.u;
             nsp = nsp_in[p];
             weight = fw_in[p];
+            if constexpr (SLOTS) {
+                if (seg_on) {
+                    kend = seg.kend[p];
+                    oma_last = seg.oma_last[p];
+                    bgw = seg.bgw[p];
+                }
+            }
             gi[0] = grad_image[p * 3 + 0];
             gi[1] = grad_image[p * 3 + 1];
             gi[2] = grad_image[p * 3 + 2];
@@ -895,10 +1073,47 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     GS_STAT(0, 1);          // waves
     GS_STAT(7, n_tile);
     GS_STAT(8, n_used);
-    const int last_chunk = (n_used - 1) / RCHUNK;
-    for (int chunk = last_chunk; chunk >= 0; chunk--) {
+    // the workgroup's part of the list: [seg_lo, seg_hi) (the whole used part without segments)
+    int seg_lo = 0, seg_hi = n_used;
+    int reach_end = nsp;   // the lane looks at list entries k < reach_end (render_backward.cu:131)
+    if constexpr (SLOTS) {
+        if (seg_on) {
+            seg_lo = seg_id * SEG_LEN;
+            if (seg_lo >= n_used) return;
+            if (seg_id < SEG_MAX - 1) seg_hi = min(n_used, seg_lo + SEG_LEN);
+            if (kend <= seg_lo) {
+                reach_end = 0;   // the pixel's walk ended in front of this segment
+            } else if (kend > seg_hi) {
+                // the pixel's walk comes from behind: resume it with the state it has at the boundary
+                const Vec4<float>* rec = seg.rec + (size_t)tile * SEG_MAX * RB + tid;
+                const int e_p = min((kend - 1) / SEG_LEN, SEG_MAX - 1);        // segment of its last contributor
+                const int e_tile = min((n_used - 1) / SEG_LEN, SEG_MAX - 1);   // wave-uniform bound
+                const int k_m = kend - 1;
+                const bool first_divides = (exact ? k_m : k_m % REF_CH) < nsp - 1;   // Q1 at the first contributor
+                // weight after the walk's first step, with the last contributor's own factor taken out again
+                // (it is inside P of its segment)
+                T wb = (first_divides ? weight * fast_rcp(oma_last) : weight) * oma_last;
+                T d0 = 0, d1 = 0, d2 = 0;
+                for (int s2 = e_tile; s2 > seg_id; s2--) {   // deepest first, as the walk accumulates
+                    if (s2 <= e_p) {
+                        const Vec4<float> r4 = rec[s2 * RB];
+                        wb = wb * fast_rcp(r4.x);   // the walk's weight at the near boundary of segment s2
+                        d0 += wb * r4.y; d1 += wb * r4.z; d2 += wb * r4.w;
+                    }
+                }
+                weight = wb;
+                color_accum[0] = bg0 * bgw + d0;
+                color_accum[1] = bg1 * bgw + d1;
+                color_accum[2] = bg2 * bgw + d2;
+                bg_init = true;
+            }
+        }
+    }
+    const int first_chunk = seg_lo / RCHUNK;
+    const int last_chunk = (seg_hi - 1) / RCHUNK;
+    for (int chunk = last_chunk; chunk >= first_chunk; chunk--) {
         const int base = chunk * RCHUNK;
-        const int cnt = min(RCHUNK, n_used - base);
+        const int cnt = min(RCHUNK, seg_hi - base);
         GS_STAT(1, 1);
         __syncthreads();   // previous chunk fully flushed
         stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, s_idx, src_opacity, src_conic);
@@ -919,7 +1134,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
             m &= ~(1ull << bit);
             const int i = (word << 6) + bit;
             const int k = base + i;
-            const bool reach = k < nsp;   // render_backward.cu:131 (nsp == 0 outside the image)
+            const bool reach = k < reach_end;   // render_backward.cu:131 (nsp == 0 outside the image)
             GS_STAT(2, 1);                          // visits
             if (ballot(reach) == 0) continue;      // wave-uniform: no lane reaches this splat
             GS_STAT(9, 1);                          // visits with a reaching lane
@@ -970,7 +1185,13 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                         // values only from here on (no threshold depends on them): contraction allowed
                         {
 #pragma clang fp contract(fast)
+#ifdef GS_BWD_RCP_REFINE   // A/B build: one Newton step on the hardware reciprocal (tests/test_gpu_fullsize_parity.py)
+                            const T x1ma = T(1) - alpha;
+                            const T r0 = fast_rcp(x1ma);
+                            const T r1ma = __builtin_fmaf(r0, __builtin_fmaf(-x1ma, r0, 1.0f), r0);
+#else
                             const T r1ma = fast_rcp(T(1) - alpha);
+#endif
                             if ((exact ? k : k % REF_CH) < nsp - 1) weight = weight * r1ma;   // Q1 (chunk-local index) unless exact
                             aw = alpha * weight;
                             // grad_alpha (render_backward.cu:196-203); the record's colour is Y0 * coefficient
@@ -1322,7 +1543,8 @@ static int launch_render_fwd(const void* packed_or_uvs, const void* opacity, con
                              const void* view_dir_by_pixel, const int32_t* tile_ranges,
                              const int32_t* sorted_gaussians, const void* background_rgb, int W, int H, int n_sh,
                              int tile_row0, int tile_row1, int32_t* num_splats_per_pixel,
-                             void* final_weight_per_pixel, void* image, int dtype, void* stream) {
+                             void* final_weight_per_pixel, void* image, int dtype, void* stream,
+                             void* segment_state = nullptr) {
     GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
     if (int e = check_rows(H, tile_row0, tile_row1)) return e;
     hipStream_t s = (hipStream_t)stream;
@@ -1330,6 +1552,17 @@ static int launch_render_fwd(const void* packed_or_uvs, const void* opacity, con
     const int nt = (tile_row1 - tile_row0) * ntx;
     if (nt == 0) return GS_OK;
     const int grid = render_grid(nt);
+    if (segment_state != nullptr) {   // the fused renderer's kernel with the state for the segmented backward
+        GS_REQUIRE(dtype == GS_F32 && n_sh == 1 && opacity == nullptr,
+                   "segment_state needs float32 packed records and one colour coefficient per channel");
+        GS_REQUIRE(((uintptr_t)segment_state & 15) == 0, "segment_state must be 16-byte aligned");
+        k_render_fwd_ck<<<grid, RB, 0, s>>>(
+            (const float*)packed_or_uvs, (const float*)rgb, tile_ranges, sorted_gaussians,
+            (const float*)background_rgb, W, H, ntx, tile_row0 * ntx, nt, num_splats_per_pixel,
+            (float*)final_weight_per_pixel, (float*)image, 0, nullptr, INT64_MAX, nullptr,
+            seg_state_of(segment_state, W, H));
+        return check_launch("render_tiles");
+    }
     DISPATCH_T(dtype, DISPATCH_SH(n_sh, (k_render_fwd<T, N_SH><<<grid, RB, 0, s>>>(
                                             (const T*)packed_or_uvs, (const T*)rgb,
                                             (const T*)view_dir_by_pixel, tile_ranges,
@@ -1355,19 +1588,27 @@ int gs_render_tiles_packed(const void* packed, const void* rgb, const void* view
                            const int32_t* tile_ranges, const int32_t* sorted_gaussians,
                            const void* background_rgb, int W, int H, int n_sh, int tile_row0,
                            int tile_row1, int32_t* num_splats_per_pixel, void* final_weight_per_pixel,
-                           void* image, int dtype, void* stream) {
+                           void* image, int dtype, void* segment_state, void* stream) {
     return launch_render_fwd(packed, nullptr, nullptr, rgb, view_dir_by_pixel, tile_ranges, sorted_gaussians,
                              background_rgb, W, H, n_sh, tile_row0, tile_row1, num_splats_per_pixel,
-                             final_weight_per_pixel, image, dtype, stream);
+                             final_weight_per_pixel, image, dtype, stream, segment_state);
+}
+
+size_t gs_render_segment_workspace_bytes(int W, int H) {
+    if (W <= 0 || H <= 0) return 0;
+    const size_t T = (size_t)((W + 15) / 16) * ((H + 15) / 16);
+    return T * SEG_MAX * 256 * sizeof(Vec4<float>) + (size_t)W * H * 12;
 }
 
 int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* tile_ranges,
                            int32_t* sorted_gaussians, const uint64_t* keys, int64_t S,
                            const void* background_rgb, int W, int H, int tile_row0, int tile_row1,
                            int32_t* tile_flags, int32_t* num_splats_per_pixel,
-                           void* final_weight_per_pixel, void* image, int32_t* tile_cost, void* stream) {
+                           void* final_weight_per_pixel, void* image, int32_t* tile_cost, void* segment_state,
+                           void* stream) {
     GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
     GS_REQUIRE(tile_flags != nullptr, "tile_flags must not be null");
+    GS_REQUIRE(segment_state == nullptr || ((uintptr_t)segment_state & 15) == 0, "segment_state must be 16-byte aligned");
     if (int e = check_rows(H, tile_row0, tile_row1)) return e;
     hipStream_t s = (hipStream_t)stream;
     const int ntx = (W + 15) / 16;
@@ -1375,18 +1616,26 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
     if (nt == 0) return GS_OK;
     const int grid = render_grid(nt);
     const int t0 = tile_row0 * ntx;
+    const SegState seg = seg_state_of(segment_state, W, H);
     // 1. provisional pass over the ordered prefixes; raises the flags
-    k_render_fwd<float, 1><<<grid, RB, 0, s>>>(
-        (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
-        (const float*)background_rgb, W, H, ntx, t0, nt, num_splats_per_pixel,
-        (float*)final_weight_per_pixel, (float*)image, GS_SORT_PREFIX, tile_flags, S, tile_cost, nullptr, nullptr);
+    if (segment_state)
+        k_render_fwd_ck<<<grid, RB, 0, s>>>(
+            (const float*)packed, (const float*)rgb, tile_ranges, sorted_gaussians, (const float*)background_rgb, W, H,
+            ntx, t0, nt, num_splats_per_pixel, (float*)final_weight_per_pixel, (float*)image, GS_SORT_PREFIX,
+            tile_flags, S, tile_cost, seg);
+    else
+        k_render_fwd<float, 1><<<grid, RB, 0, s>>>(
+            (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
+            (const float*)background_rgb, W, H, ntx, t0, nt, num_splats_per_pixel,
+            (float*)final_weight_per_pixel, (float*)image, GS_SORT_PREFIX, tile_flags, S, tile_cost, nullptr, nullptr);
     if (S > GS_SORT_PREFIX) {
         // 2. + 3. flagged tiles: full sort, render again (no-ops on a dense scene)
         sort_flagged_tiles(tile_ranges, keys, sorted_gaussians, t0, nt, S, tile_flags, s);
-        k_render_fwd_flagged<<<nt < 512 ? nt : 512, RB, 0, s>>>(
+        auto again = segment_state ? k_render_fwd_flagged<true> : k_render_fwd_flagged<false>;
+        again<<<nt < 512 ? nt : 512, RB, 0, s>>>(
             (const float*)packed, (const float*)rgb, tile_ranges, sorted_gaussians,
             (const float*)background_rgb, W, H, ntx, t0, nt, num_splats_per_pixel,
-            (float*)final_weight_per_pixel, (float*)image, tile_flags, S, tile_cost);
+            (float*)final_weight_per_pixel, (float*)image, tile_flags, S, tile_cost, seg);
     }
     return check_launch("render_tiles_prefix");
 }
@@ -1415,7 +1664,7 @@ static int launch_render_bwd(const void* packed_or_uvs, const void* opacity, con
                                      (const T*)grad_image, W, H, ntx, tile_row0 * ntx, nt,
                                      (T*)grad_rgb, (T*)grad_opacity, (T*)grad_uv,
                                      (T*)grad_conic, 0, exact, nullptr, (const T*)opacity,
-                                     (const T*)conic))));
+                                     (const T*)conic, SegState{nullptr, nullptr, nullptr, nullptr}))));
     return check_launch("render_tiles_backward");
 }
 
@@ -1451,10 +1700,11 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
                                   const int32_t* num_splats_per_pixel,
                                   const void* final_weight_per_pixel, const void* grad_image, int W,
                                   int H, int tile_row0, int tile_row1, void* grad_slab,
-                                  const int32_t* tile_cost, int32_t* tile_order, int backward_mode,
-                                  void* stream) {
+                                  const int32_t* tile_cost, int32_t* tile_order, const void* segment_state,
+                                  int backward_mode, void* stream) {
     GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
     GS_REQUIRE((tile_cost == nullptr) == (tile_order == nullptr), "tile_cost and tile_order go together");
+    GS_REQUIRE(segment_state == nullptr || ((uintptr_t)segment_state & 15) == 0, "segment_state must be 16-byte aligned");
     if (int e = check_rows(H, tile_row0, tile_row1)) return e;
     int exact = 0;
     if (int e = resolve_backward_mode(backward_mode, &exact)) return e;
@@ -1463,13 +1713,24 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
     const int nt = (tile_row1 - tile_row0) * ntx;
     if (nt == 0) return GS_OK;
     const int grid = render_grid(nt);
+    if (segment_state != nullptr) {
+        // (tile, depth segment) work items from the state the forward left (gs_render_tiles_prefix / _packed
+        // with the same segment_state); segment-major launch order = most work first, no order kernel
+        k_render_bwd<float, 1><<<grid * SEG_MAX, RB, 0, s>>>(
+            (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
+            (const float*)background_rgb, num_splats_per_pixel, (const float*)final_weight_per_pixel,
+            (const float*)grad_image, W, H, ntx, tile_row0 * ntx, nt, (float*)grad_slab, nullptr,
+            nullptr, nullptr, 1, exact, nullptr, nullptr, nullptr, seg_state_of((void*)segment_state, W, H));
+        return check_launch("render_tiles_backward_slab");
+    }
     const bool ordered = tile_cost != nullptr && nt >= GS_LPT_MIN_TILES;
     if (ordered) k_tile_order<<<1, 1024, 0, s>>>(tile_cost, tile_row0 * ntx, nt, grid, tile_order);
     k_render_bwd<float, 1><<<grid, RB, 0, s>>>(
         (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
         (const float*)background_rgb, num_splats_per_pixel, (const float*)final_weight_per_pixel,
         (const float*)grad_image, W, H, ntx, tile_row0 * ntx, nt, (float*)grad_slab, nullptr,
-        nullptr, nullptr, 1, exact, ordered ? tile_order : nullptr, nullptr, nullptr);
+        nullptr, nullptr, 1, exact, ordered ? tile_order : nullptr, nullptr, nullptr,
+        SegState{nullptr, nullptr, nullptr, nullptr});
     return check_launch("render_tiles_backward_slab");
 }
 

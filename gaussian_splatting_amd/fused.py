@@ -294,12 +294,39 @@ def preprocess_backward(xyz, quaternion, scale, camera_T_world, K, f, slab, v_ba
     return grad_xyz, grad_q, grad_scale, grad_opacity, grad_rgb, grad_sh
 
 
+# Depth segments of the backward (csrc/render.hip "depth segments"): the forward leaves, per (tile, 128-entry
+# segment of its list, pixel), the state a backward walk has at the segment boundary, and the backward runs one
+# workgroup per (tile, segment).  "auto": for frames / bands of fewer than SEGMENT_MAX_TILES tiles whose lists
+# average SEGMENT_MIN_MEAN_LIST entries or more -- a multi-GPU rank's band is two workgroups per CU otherwise.
+# Measured at workload D, forward + backward: 1/8 band 0.259 -> 0.205 ms (backward 0.173 -> 0.093, the forward pays
+# 0.086 -> 0.112 for the extra state), 1/4 band 0.321 -> 0.298, half frame 0.463 -> 0.489: on below 1500 tiles.
+# True / False force it.
+SEGMENTS = "auto"
+SEGMENT_MAX_TILES = 1500
+SEGMENT_MIN_MEAN_LIST = 192
+_EMPTY = {}
+
+
+def _empty(dev, dtype=torch.float32):
+    key = (dev, dtype)
+    if key not in _EMPTY:
+        _EMPTY[key] = torch.empty(0, dtype=dtype, device=dev)
+    return _EMPTY[key]
+
+
+def want_segments(n_instances, n_tiles):
+    if SEGMENTS == "auto":
+        return 0 < n_tiles < SEGMENT_MAX_TILES and n_instances >= SEGMENT_MIN_MEAN_LIST * n_tiles
+    return bool(SEGMENTS) and n_tiles > 0
+
+
 def render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, width, tile_rows, sort_prefix,
-                   image_rows=None):
-    """-> image, splat counts, final weights, tile costs.  image_rows > height: the image buffer gets that
-    many rows (the multi-GPU gather wants equal-sized bands); the kernels only see the first `height`.
+                   image_rows=None, segments=None):
+    """-> image, splat counts, final weights, tile costs, segment state.  image_rows > height: the image buffer
+    gets that many rows (the multi-GPU gather wants equal-sized bands); the kernels only see the first `height`.
     tile costs: int32[n_tiles], how long each tile took (prefix mode; empty otherwise) -- the launch-order
-    hint render_backward hands back to the library."""
+    hint render_backward hands back to the library.  segment state: the workspace for the depth-segmented
+    backward (empty when segments are off; `segments` None = the module's policy), for render_backward."""
     dev = packed.device
     ntx = (width + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
     nty = (height + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
@@ -314,6 +341,13 @@ def render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, 
     fw = buf[3 * PI:3 * PI + P].view(height, width)
     nsp = buf[3 * PI + P:].view(torch.int32).view(height, width)
     stream = _stream()
+    if segments is None:
+        segments = want_segments(sorted_g.shape[0], (row1 - row0) * ntx)
+    seg = _empty(dev)
+    if segments:
+        seg = torch.empty(_hip.lib().gs_render_segment_workspace_bytes(width, height) // 4, dtype=torch.float32,
+                          device=dev)
+    seg_p = _p(seg) if segments else None
     if sort_prefix and sorted_g.shape[0] > sort_prefix:
         # provisional render from the ordered prefixes; tiles that ran out of prefix are flagged,
         # sorted in full and rendered again -- one call, the host never looks at the flags
@@ -321,35 +355,39 @@ def render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, 
         flags, cost = scratch[:ntx * nty], scratch[ntx * nty:]
         _hip.call("gs_render_tiles_prefix", _p(packed), _p(rgb), _p(ranges), _p(sorted_g), _p(keys),
                   ctypes.c_int64(sorted_g.shape[0]), _p(background_rgb), width, height, row0, row1, _p(flags),
-                  _p(nsp), _p(fw), _p(image), _p(cost), stream)
+                  _p(nsp), _p(fw), _p(image), _p(cost), seg_p, stream)
         global last_tile_flags
         last_tile_flags = flags
         if len(_flag_log) < 512:
             _flag_log.append(flags)
     else:
-        cost = torch.empty(0, dtype=torch.int32, device=dev)
+        cost = _empty(dev, torch.int32)
         _hip.call("gs_render_tiles_packed", _p(packed), _p(rgb), None, _p(ranges), _p(sorted_g), _p(background_rgb),
-                  width, height, 1, row0, row1, _p(nsp), _p(fw), _p(image), _hip.GS_F32, stream)
-    return image, nsp, fw, cost
+                  width, height, 1, row0, row1, _p(nsp), _p(fw), _p(image), _hip.GS_F32, seg_p, stream)
+    return image, nsp, fw, cost, seg
 
 
 def render_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, grad_image, height, width, tile_rows,
-                    V, tile_cost=None, backward_mode=None):
+                    V, tile_cost=None, backward_mode=None, seg_state=None):
     """-> the slab [V, 9] of accumulated render gradients (rgb 3 | opacity 1 | uv 2 | conic 3).
     tile_cost: render_forward's fourth output (the tiles are then started longest-first).
+    seg_state: render_forward's fifth output; non-empty -> one workgroup per (tile, depth segment).
     backward_mode: _hip.GS_BACKWARD_COMPAT / _EXACT, per call (ABI 5); None = the process default at the call"""
     nty = (height + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
     row0, row1 = tile_rows if tile_rows is not None else (0, nty)
     slab = torch.zeros(max(V, 1), SLAB_WIDTH, dtype=torch.float32, device=packed.device)
     cost = order = None
+    seg_on = seg_state is not None and seg_state.numel() > 0
     # longest-first only pays where a workgroup lives long enough for the kernel's tail to matter: lists of a
     # few hundred entries per tile (workload B, 52 per tile: the order kernel's 6 us are not won back)
-    if tile_cost is not None and tile_cost.numel() > 0 and sorted_g.shape[0] >= LPT_MIN_MEAN_LIST * tile_cost.numel():
+    if (not seg_on and tile_cost is not None and tile_cost.numel() > 0
+            and sorted_g.shape[0] >= LPT_MIN_MEAN_LIST * tile_cost.numel()):
         cost = tile_cost
         order = torch.empty(tile_cost.numel() + 8, dtype=torch.int32, device=packed.device)
     _hip.call("gs_render_tiles_backward_slab", _p(packed), _p(rgb), _p(ranges), _p(sorted_g), _p(background_rgb),
               _p(nsp), _p(fw), _p(grad_image), width, height, row0, row1, _p(slab),
               _p(cost) if cost is not None else None, _p(order) if order is not None else None,
+              _p(seg_state) if seg_on else None,
               _hip.GS_BACKWARD_DEFAULT if backward_mode is None else int(backward_mode), _stream())
     return slab[:V]
 
@@ -415,10 +453,10 @@ class _Render(torch.autograd.Function):
     @staticmethod
     def forward(ctx, uv, conic, opacity, rgb, packed, ranges, sorted_g, background_rgb, height, width, tile_rows,
                 slab_sync=None, keys=None, sort_prefix=0, rendered=None):
-        # rendered: (image, nsp, fw, cost) when _Preprocess.forward already enqueued this node's kernels
-        image, nsp, fw, cost = rendered if rendered else render_forward(
+        # rendered: (image, nsp, fw, cost, seg) when _Preprocess.forward already enqueued this node's kernels
+        image, nsp, fw, cost, seg = rendered if rendered else render_forward(
             packed, rgb, ranges, sorted_g, keys, background_rgb, height, width, tile_rows, sort_prefix)
-        ctx.save_for_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, cost)
+        ctx.save_for_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, cost, seg)
         ctx.set_materialize_grads(False)
         ctx.dims = (height, width, tile_rows, uv.shape[0])
         ctx.slab_sync = slab_sync
@@ -429,12 +467,12 @@ class _Render(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_image):
-        packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, cost = ctx.saved_tensors
+        packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, cost, seg = ctx.saved_tensors
         height, width, tile_rows, V = ctx.dims
         if grad_image is None:
             return (None,) * 15
         slab = render_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, grad_image.contiguous(),
-                               height, width, tile_rows, V, cost, ctx.backward_mode)
+                               height, width, tile_rows, V, cost, ctx.backward_mode, seg)
         if ctx.slab_sync is not None:
             ctx.slab_sync(slab.view(-1))   # multi-GPU: sum the partial gradients of all bands in place
         # the four gradients are views of the one slab; _Preprocess.backward recognises that
@@ -492,6 +530,7 @@ def rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_m
     nat = native() if not (return_aux or grad_sync or slab_sync or frame_hook) else None
     if nat is not None:
         nat.set_modes(bool(SORT_PREFIX), bool(EARLY_RENDER))
+        nat.set_segments(0 if SEGMENTS == "auto" else (1 if SEGMENTS else -1))
         row0, row1 = tile_rows if tile_rows is not None else (0, -1)
         return nat.rasterize(g.xyz, g.quaternion, g.scale, g.opacity, g.rgb, g.sh, camera_T_world, camera.K,
                              int(camera.width), int(camera.height), near_thresh, far_thresh, cull_mask_padding, mh_dist,

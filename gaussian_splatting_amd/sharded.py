@@ -381,15 +381,16 @@ class _OwnerRender(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, uv, rast, fr, height, width):
-        image, nsp, fw, cost = fr.rendered
+        image, nsp, fw, cost, seg = fr.rendered
         fr.rendered = None
         f = fr.f
         V = f.V
-        ctx.save_for_backward(f.packed, f.rgb_render[:V], f.ranges, f.sorted_g, fr.background, nsp, fw, cost)
+        ctx.save_for_backward(f.packed, f.rgb_render[:V], f.ranges, f.sorted_g, fr.background, nsp, fw, cost, seg)
         ctx.fr, ctx.rast, ctx.dims = fr, rast, (height, width)
         # the band and the gradient mode of THIS frame: under band_policy="cost" rast.tile_rows moves with every
         # rasterize() call, and a second forward before this frame's backward (an eval render, gradient
         # accumulation over views) must not change the rows the backward covers
+        from . import _hip
         ctx.tile_rows = fr.tile_rows
         ctx.backward_mode = _hip.get_backward_mode()
         ctx.set_materialize_grads(False)
@@ -400,13 +401,13 @@ class _OwnerRender(torch.autograd.Function):
         from . import fused
         if grad_image is None:
             return (None,) * 5
-        packed, rgb_v, ranges, sorted_g, background_rgb, nsp, fw, cost = ctx.saved_tensors
+        packed, rgb_v, ranges, sorted_g, background_rgb, nsp, fw, cost, seg = ctx.saved_tensors
         fr, rast = ctx.fr, ctx.rast
         f, plan = fr.f, fr.plan
         height, width = ctx.dims
         slab = fused.render_backward(packed, rgb_v, ranges, sorted_g, background_rgb, nsp, fw,
                                      grad_image.contiguous(), height, width, ctx.tile_rows, f.V, cost,
-                                     ctx.backward_mode)
+                                     ctx.backward_mode, seg)
         owned = plan.exchange(slab, group=rast.group, all_to_all=rast.all_to_all)
         rast.last_owned_render_grads = fr.owned_rows = owned
         uv_out = fr.uv_ref() if fr.uv_ref is not None else None

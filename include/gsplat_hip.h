@@ -211,7 +211,7 @@ int gs_render_tiles_packed(const void* packed, const void* rgb, const void* view
                            const int32_t* tile_ranges, const int32_t* sorted_gaussians,
                            const void* background_rgb, int W, int H, int n_sh, int tile_row0,
                            int tile_row1, int32_t* num_splats_per_pixel, void* final_weight_per_pixel,
-                           void* image, int dtype, void* stream);
+                           void* image, int dtype, void* segment_state, void* stream);
 /* The same kernel over lists produced with sort_prefix = GS_SORT_PREFIX (fp32, n_sh == 1).
  * Enqueues (1) a provisional render that reads at most the ordered prefix of a prefix-sorted tile
  * and writes tile_flags[t] = 1 if tile t ran out of it with an unsaturated pixel (0 otherwise),
@@ -225,7 +225,17 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
                            int32_t* sorted_gaussians, const uint64_t* keys, int64_t S,
                            const void* background_rgb, int W, int H, int tile_row0, int tile_row1,
                            int32_t* tile_flags, int32_t* num_splats_per_pixel,
-                           void* final_weight_per_pixel, void* image, int32_t* tile_cost, void* stream);
+                           void* final_weight_per_pixel, void* image, int32_t* tile_cost, void* segment_state,
+                           void* stream);
+/* Depth segments of the fused backward (fp32, n_sh == 1; ABI 5).  segment_state (may be NULL): a 16-byte aligned
+ * device workspace of gs_render_segment_workspace_bytes(W, H) bytes that gs_render_tiles_packed /
+ * gs_render_tiles_prefix fill -- per (tile, 128-entry segment of its list, pixel) the transmittance at the
+ * segment's far boundary and the colour the segment contributed, per pixel where its walk ends and what the
+ * backward's first step does there -- and that gs_render_tiles_backward_slab, given the same pointer, uses to
+ * launch one workgroup per (tile, segment) instead of one per tile: 3-4x more, shorter work items, the same
+ * gradients up to fp32 rounding (what a multi-GPU rank's band of a few hundred tiles needs to fill the chip;
+ * no reference counterpart).  The contents are private to the library. */
+size_t gs_render_segment_workspace_bytes(int W, int H);
 /* render_tiles_backward_cuda (bindings.cpp:120; render_backward.cu:12-595), the reference's arguments in the
  * reference's order.  grad_rgb[V,3,n_sh], grad_opacity[V,1], grad_uv[V,2], grad_conic[V,3] are accumulated.
  * backward_mode: GS_BACKWARD_DEFAULT / _COMPAT / _EXACT (below); COMPAT is bug-compatible with
@@ -250,14 +260,16 @@ int gs_render_tiles_backward_packed(const void* packed, const void* rgb, const v
  * zero-initialised (or hold values to accumulate onto).
  * tile_cost / tile_order (both NULL, or both given): with the costs gs_render_tiles_prefix measured and an
  * int32[n_tiles + 8] workspace, the tiles' workgroups are started longest-first (shorter drain at the end of
- * the kernel; grids below 2048 tiles keep the natural order).  The gradients do not depend on it. */
+ * the kernel; grids below 2048 tiles keep the natural order).  The gradients do not depend on it.
+ * segment_state (may be NULL): the workspace the forward filled -> (tile, depth segment) work items, see
+ * gs_render_segment_workspace_bytes; tile_cost / tile_order are then not used. */
 int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int32_t* tile_ranges,
                                   const int32_t* sorted_gaussians, const void* background_rgb,
                                   const int32_t* num_splats_per_pixel,
                                   const void* final_weight_per_pixel, const void* grad_image, int W,
                                   int H, int tile_row0, int tile_row1, void* grad_slab,
-                                  const int32_t* tile_cost, int32_t* tile_order, int backward_mode,
-                                  void* stream);
+                                  const int32_t* tile_cost, int32_t* tile_order, const void* segment_state,
+                                  int backward_mode, void* stream);
 /* Gradient mode of the render backward: the `backward_mode` argument of the three entry points above
  * (ABI 5: per call, so that a trainer switching modes cannot race a backward that the autograd engine's
  * own thread has queued).  GS_BACKWARD_DEFAULT takes the process-wide default, which gs_set_backward_mode

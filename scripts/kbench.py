@@ -32,6 +32,10 @@ def main():
     ap.add_argument("--full", action="store_true", help="also time preprocess / binning / per-Gaussian backward")
     ap.add_argument("--tag", default="")
     ap.add_argument("--natural-order", action="store_true", help="backward without the longest-first tile order")
+    ap.add_argument("--binning-only", action="store_true")
+    ap.add_argument("--segments", type=int, default=0, help="1: depth-segmented backward (forward leaves the state)")
+    ap.add_argument("--rows", type=int, nargs=2, default=None, metavar=("R0", "R1"),
+                    help="render forward / backward only the tile rows [R0, R1) (a multi-GPU rank's band)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     _hip.lib()
@@ -46,30 +50,48 @@ def main():
                                         d["near_thresh"], d["far_thresh"], d["cull_mask_padding"], d["mh_dist"], None,
                                         _hip.GS_SORT_PREFIX)
 
+    rows = tuple(args.rows) if args.rows else None
+    if args.binning_only:
+        # experiment builds of binning.hip whose emit writes elsewhere (timing only): the lists are garbage, so
+        # nothing downstream of the sort may run
+        for _ in range(3):
+            stage1()
+        torch.cuda.synchronize()
+        _hip.reserve_events(2 * 16 * args.reps)
+        _hip.enable_timing(True)
+        for _ in range(args.reps):
+            stage1()
+        timing = _hip.collect_timing()
+        _hip.enable_timing(False)
+        print(json.dumps({"lib": os.path.basename(_hip.LIB_PATH), "tag": args.tag, "workload": args.workload,
+                          "median_ms": {k: round(statistics.median(v), 4) for k, v in sorted(timing.items())}}))
+        return
     f = stage1()
     V = f.V
     rgb_v = f.rgb_render[:V]
 
     def fwd():
-        return fused.render_forward(f.packed, rgb_v, f.ranges, f.sorted_g, f.keys, bg, H, W, None, _hip.GS_SORT_PREFIX)
+        return fused.render_forward(f.packed, rgb_v, f.ranges, f.sorted_g, f.keys, bg, H, W, rows, _hip.GS_SORT_PREFIX,
+                                    segments=args.segments)
 
-    def bwd(nsp, fw, cost=None):
-        return fused.render_backward(f.packed, rgb_v, f.ranges, f.sorted_g, bg, nsp, fw, gi, H, W, None, V, cost)
+    def bwd(nsp, fw, cost=None, seg=None):
+        return fused.render_backward(f.packed, rgb_v, f.ranges, f.sorted_g, bg, nsp, fw, gi, H, W, rows, V, cost,
+                                     seg_state=seg)
 
-    image, nsp, fw, cost = fwd()
-    slab = bwd(nsp, fw, None if args.natural_order else cost)
+    image, nsp, fw, cost, seg = fwd()
+    slab = bwd(nsp, fw, None if args.natural_order else cost, seg)
     torch.cuda.synchronize()
     for _ in range(3):
-        image, nsp, fw, cost = fwd()
-        slab = bwd(nsp, fw, None if args.natural_order else cost)
+        image, nsp, fw, cost, seg = fwd()
+        slab = bwd(nsp, fw, None if args.natural_order else cost, seg)
     torch.cuda.synchronize()
     _hip.reserve_events(2 * 16 * args.reps)
     _hip.enable_timing(True)
     for _ in range(args.reps):
         if args.full:
             f2 = stage1()
-        image, nsp, fw, cost = fwd()
-        slab = bwd(nsp, fw, None if args.natural_order else cost)
+        image, nsp, fw, cost, seg = fwd()
+        slab = bwd(nsp, fw, None if args.natural_order else cost, seg)
         if args.full:
             fused.preprocess_backward(g.xyz, g.quaternion, g.scale, T, cam.K, f, slab)
     timing = _hip.collect_timing()

@@ -559,8 +559,8 @@ def test_backward_longest_first_tile_order(W, H, monkeypatch):
                                  3.0, None, _hip.GS_SORT_PREFIX)
     V = f.V
     rgb_v = f.rgb_render[:V]
-    image, nsp, fw, cost = fused.render_forward(f.packed, rgb_v, f.ranges, f.sorted_g, f.keys, bg, H, W, None,
-                                                _hip.GS_SORT_PREFIX)
+    image, nsp, fw, cost, _ = fused.render_forward(f.packed, rgb_v, f.ranges, f.sorted_g, f.keys, bg, H, W, None,
+                                                   _hip.GS_SORT_PREFIX, segments=False)
     nt = ((W + 15) // 16) * ((H + 15) // 16)
     assert cost.shape == (nt,) and int(cost.min()) > 0
     natural = fused.render_backward(f.packed, rgb_v, f.ranges, f.sorted_g, bg, nsp, fw, gi, H, W, None, V)
@@ -572,7 +572,7 @@ def test_backward_longest_first_tile_order(W, H, monkeypatch):
     order = torch.full((nt + 8,), -7, dtype=torch.int32, device=DEV)
     slab = torch.zeros(V, 9, device=DEV)
     _hip.call("gs_render_tiles_backward_slab", p(f.packed), p(rgb_v), p(f.ranges), p(f.sorted_g), p(bg), p(nsp), p(fw),
-              p(gi), W, H, 0, (H + 15) // 16, p(slab), p(cost), p(order), _hip.GS_BACKWARD_DEFAULT,
+              p(gi), W, H, 0, (H + 15) // 16, p(slab), p(cost), p(order), None, _hip.GS_BACKWARD_DEFAULT,
               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     o = order.cpu()
@@ -591,12 +591,12 @@ def test_backward_longest_first_tile_order(W, H, monkeypatch):
     # cost without order (or the reverse) is refused
     with pytest.raises(RuntimeError, match="go together"):
         _hip.call("gs_render_tiles_backward_slab", p(f.packed), p(rgb_v), p(f.ranges), p(f.sorted_g), p(bg), p(nsp),
-                  p(fw), p(gi), W, H, 0, (H + 15) // 16, p(slab), p(cost), None, _hip.GS_BACKWARD_DEFAULT,
+                  p(fw), p(gi), W, H, 0, (H + 15) // 16, p(slab), p(cost), None, None, _hip.GS_BACKWARD_DEFAULT,
                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     # the gradient mode is an argument of the call (ABI 5): anything but DEFAULT / COMPAT / EXACT is refused
     with pytest.raises(RuntimeError, match="backward mode"):
         _hip.call("gs_render_tiles_backward_slab", p(f.packed), p(rgb_v), p(f.ranges), p(f.sorted_g), p(bg), p(nsp),
-                  p(fw), p(gi), W, H, 0, (H + 15) // 16, p(slab), None, None, 7,
+                  p(fw), p(gi), W, H, 0, (H + 15) // 16, p(slab), None, None, None, 7,
                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
 
 
@@ -654,7 +654,7 @@ def test_packed_render_entry_points_equal_the_reference_signature_ones(deg):
     _hip.call("gs_pack_splats", p(uv), p(opa), p(conic), p(rgb), V, p(packed), _hip.GS_F32, stream)
     nsp_b, fw_b, img_b = outputs()
     _hip.call("gs_render_tiles_packed", p(packed), p(rgb), p(rays), p(ranges), p(sorted_g), p(bg), W, H, 1, 0, nty,
-              p(nsp_b), p(fw_b), p(img_b), _hip.GS_F32, stream)
+              p(nsp_b), p(fw_b), p(img_b), _hip.GS_F32, None, stream)
     gb = grads()
     _hip.call("gs_render_tiles_backward_packed", p(packed), p(rgb), p(rays), p(ranges), p(sorted_g), p(bg), p(nsp_b),
               p(fw_b), p(gi), W, H, 1, 0, nty, p(gb[0]), p(gb[1]), p(gb[2]), p(gb[3]), _hip.GS_F32,
