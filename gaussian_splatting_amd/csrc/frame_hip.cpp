@@ -15,6 +15,7 @@
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
 #include <torch/extension.h>
+#include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 
 #include <map>
 #include <string>
@@ -106,7 +107,7 @@ std::pair<int32_t*, hipEvent_t> pinned_slot(int dev) {
     PinnedRing& ring = g_pinned[dev];
     if (ring.bufs.empty()) {
         for (int i = 0; i < 4; i++) {
-            ring.bufs.push_back(torch::empty({4}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true)));
+            ring.bufs.push_back(torch::empty({32}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true)));
             hipEvent_t ev;
             hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             ring.events.push_back(ev);
@@ -146,8 +147,12 @@ struct RenderOut {
 };
 
 RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* ranges, Tensor& sorted, Tensor& keys,
-                         const Tensor& bg, int W, int H, int row0, int row1, bool whole, int sort_prefix, void* stream) {
+                         const Tensor& bg, int W, int H, int row0, int row1, bool whole, int sort_prefix, void* stream,
+                         int64_t image_rows = 0) {
     const int64_t P = (int64_t)W * H;
+    // image_rows > H (multi-GPU, equal bands): the image block holds world_size full bands so that the band
+    // images can be all-gathered in place; the kernels only see the first H rows
+    const int64_t PI = std::max<int64_t>(image_rows, H) * W;
     auto opt = torch::TensorOptions().dtype(torch::kFloat32).device(bg.device());
     RenderOut r;
     // one allocation: image [H,W,3] | final weight [H,W] | splat count [H,W] (int32 view) | per-tile render
@@ -156,11 +161,11 @@ RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* 
     // restricted
     const int ntx = (W + 15) / 16, nty = (H + 15) / 16;
     const int64_t T = (int64_t)ntx * nty;
-    r.buf = whole ? torch::empty({5 * P + 2 * T + 8}, opt) : torch::zeros({5 * P + 2 * T + 8}, opt);
-    r.image = r.buf.narrow(0, 0, 3 * P).view({H, W, 3});
-    r.fw = r.buf.narrow(0, 3 * P, P).view({H, W});
-    r.nsp = r.buf.narrow(0, 4 * P, P).view(torch::kInt32).view({H, W});
-    int32_t* tile_cost = reinterpret_cast<int32_t*>(r.buf.data_ptr<float>()) + 5 * P;
+    r.buf = whole ? torch::empty({3 * PI + 2 * P + 2 * T + 8}, opt) : torch::zeros({3 * PI + 2 * P + 2 * T + 8}, opt);
+    r.image = r.buf.narrow(0, 0, 3 * PI).view({-1, W, 3});
+    r.fw = r.buf.narrow(0, 3 * PI, P).view({H, W});
+    r.nsp = r.buf.narrow(0, 3 * PI + P, P).view(torch::kInt32).view({H, W});
+    int32_t* tile_cost = reinterpret_cast<int32_t*>(r.buf.data_ptr<float>()) + 3 * PI + 2 * P;
     const bool segments = want_segments(sorted.size(0), (int64_t)(row1 - row0) * ntx);
     r.seg = torch::empty({segments ? (int64_t)(gs_render_segment_workspace_bytes(W, H) / 4) : 0}, opt);
     void* seg_p = segments ? r.seg.data_ptr() : nullptr;
@@ -445,6 +450,420 @@ std::tuple<Tensor, Tensor, Tensor> rasterize(Tensor xyz, Tensor quaternion, Tens
     return std::make_tuple(image, o[7], o[0]);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// multi-GPU: the tile-row sharded frame with owner-sliced gradients (gaussian_splatting_amd/sharded.py:
+// _OwnerPreprocess / _OwnerRender, band policy "equal"), natively.  One rank's frame is ~0.4 ms of kernels at 8
+// ranks; its Python orchestration cost 0.7 ms of host time per frame (profiles/r02/host_profile_world8.txt).
+//   node 1   per-Gaussian stage for all N (replicated; SH colour only where the candidate window reaches the band)
+//            -> gs_halo_plan (who sends which render-gradient rows to whom; its send list is the subset the
+//            band's binning walks) -> binning + sort of the band, render of the band enqueued before the frame's one
+//            host read (S, V + the plan's split sizes)            -> uv, culling mask
+//   node 2   uv -> image: all-gather of the band images (in place, equal bands) through c10d (RCCL)
+//   backward node 2: render backward over the band (depth-segmented when the band is small) -> rows of the send
+//            list -> ONE all_to_all with the plan's splits -> gs_halo_gather_sum: the complete rows of the
+//            Gaussians this rank owns; node 1: per-Gaussian backward of the owned slice.
+// The record shared by the two nodes lives behind a one-byte "guard" tensor whose deleter frees it.
+struct ShardSpec {
+    int G = 1, rank = 0;
+    std::vector<int32_t> bounds, owner_blocks;          // G + 1 each
+    c10::intrusive_ptr<c10d::ProcessGroup> pg;          // null with the test hook
+    py::object a2a_hook;                                // tests: stands in for all_to_all_single, no image gather
+    int64_t band_pixel_rows = 0, padded_height = 0;
+    ~ShardSpec() {   // the record may die on an autograd thread: Python references are dropped under the GIL
+        py::gil_scoped_acquire gil;
+        a2a_hook = py::object();
+    }
+};
+struct FrameRec {
+    ShardSpec spec;
+    Tensor xyz, quaternion, scale, opacity, rgb, sh, camera_T_world, K, bg;   // the replicated values
+    int N = 0, n_sh = 1, W = 0, H = 0, row0 = 0, row1 = 0, i0 = 0, i1 = 0;
+    double near_thresh = 0, far_thresh = 0, padding = 0, mh_dist = 0;
+    Tensor ibuf, fbuf, hbuf;   // arenas (kept alive: everything below points into them)
+    Tensor packed, rgbr, ranges, sorted_g, center, rank_t, opa_act, halo_mask, halo_send, halo_ws;
+    RenderOut out;
+    int64_t V = 0, S = 0, v_lo = 0, v_hi = 0;
+    std::vector<int64_t> send_splits, recv_splits;
+    Tensor owned_rows, rendered_uv_grad;
+    // the uv output (weak: the record must not keep its own graph alive), to see whether its gradient is retained
+    c10::weak_intrusive_ptr<c10::TensorImpl, c10::UndefinedTensorImpl> uv_weak{
+        c10::intrusive_ptr<c10::TensorImpl, c10::UndefinedTensorImpl>()};
+    int bwd_mode = GS_BACKWARD_COMPAT;
+};
+using FramePtr = std::shared_ptr<FrameRec>;
+Tensor make_guard(const FramePtr& fr) {
+    auto* holder = new FramePtr(fr);
+    return torch::from_blob(holder, {1}, [](void* p) { delete reinterpret_cast<FramePtr*>(p); }, torch::kUInt8);
+}
+FrameRec& frame_of(const Tensor& guard) { return **reinterpret_cast<FramePtr*>(guard.data_ptr()); }
+
+struct PlanInfo {
+    int64_t v_lo = 0, v_hi = 0, V = 0, S = 0;
+    std::vector<int64_t> send_splits, recv_splits;
+} g_last_plan;
+
+template <typename F> void timed_region(const char* name, void* stream, F&& call) {
+    timed(name, stream, [&] {
+        call();
+        return (int)GS_OK;
+    });
+}
+
+struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
+    static variable_list forward(AutogradContext* ctx, Tensor o_xyz, Tensor o_quaternion, Tensor o_scale, Tensor o_opacity,
+                                 Tensor o_rgb, c10::optional<Tensor> o_sh, Tensor guard) {
+        FrameRec& fr = frame_of(guard);
+        const ShardSpec& sp = fr.spec;
+        const auto dev = fr.xyz.device();
+        const int N = fr.N, G = sp.G, me = sp.rank;
+        const bool has_sh = fr.sh.defined();
+        const int n_sh = fr.n_sh, W = fr.W, H = fr.H;
+        const int ntx = (W + 15) / 16, nty = (H + 15) / 16, T = ntx * nty;
+        const int row0 = fr.row0, row1 = fr.row1;
+        const int sort_prefix = g_sort_prefix ? GS_SORT_PREFIX : 0;
+        const int plan_ints = 4 + 2 * G;
+        void* stream = cur_stream();
+
+        const int64_t n_ws = (int64_t)gs_preprocess_workspace_ints(N), n_tc = (int64_t)gs_tile_workspace_ints(T);
+        Arena iar(torch::kInt32, dev, {n_ws, 1, N, N, n_tc, T + 2 + plan_ints, (N + 3) / 4});
+        Arena far(torch::kFloat32, dev, {3, 2 * (int64_t)N, 3 * (int64_t)N, 3 * (int64_t)N, N, 3 * (int64_t)N, 12 * (int64_t)N});
+        int32_t *ws = iar.ptr<int32_t>(0), *count = iar.ptr<int32_t>(1), *rank = iar.ptr<int32_t>(2),
+                *vis_idx = iar.ptr<int32_t>(3), *tile_counts = iar.ptr<int32_t>(4), *ranges_buf = iar.ptr<int32_t>(5);
+        uint8_t* mask = (uint8_t*)iar.ptr<int32_t>(6);
+        float *center = far.ptr<float>(0), *uv = far.ptr<float>(1), *xyz_cam = far.ptr<float>(2), *conic = far.ptr<float>(3),
+              *opa = far.ptr<float>(4), *rgbr = far.ptr<float>(5), *packed = far.ptr<float>(6);
+        timed("gs_preprocess_forward", stream, [&] {
+            return gs_preprocess_forward(fr.xyz.data_ptr(), fr.quaternion.data_ptr(), fr.scale.data_ptr(), fr.opacity.data_ptr(),
+                                         fr.rgb.data_ptr(), has_sh ? fr.sh.data_ptr() : nullptr, n_sh,
+                                         fr.camera_T_world.data_ptr(), fr.K.data_ptr(), N, W, H, (float)fr.near_thresh,
+                                         (float)fr.far_thresh, (float)fr.padding, (float)fr.mh_dist, row0, row1, ws, center,
+                                         count, mask, rank, vis_idx, uv, xyz_cam, conic, opa, rgbr, packed, stream);
+        });
+        // the exchange plan; its record rides on the frame's one host read, its send list is the binning's subset
+        const int64_t n_hw = (int64_t)gs_halo_workspace_ints(N, G);
+        Tensor hbuf = torch::empty({2 * (int64_t)N + n_hw}, torch::TensorOptions().dtype(torch::kInt32).device(dev));
+        int32_t* h = hbuf.data_ptr<int32_t>();
+        int32_t* record = ranges_buf + T + 2;
+        timed("gs_halo_plan", stream, [&] {
+            return gs_halo_plan(uv, conic, N, count, ws, ntx, nty, (float)fr.mh_dist, sp.bounds.data(), sp.owner_blocks.data(), G,
+                                me, (uint32_t*)h, h + 2 * (int64_t)N, h + N, record, stream);
+        });
+        const int32_t* subset = G > 1 ? h + N : nullptr;
+        const int32_t* subset_n = G > 1 ? record : nullptr;
+        timed("gs_tile_count", stream, [&] {
+            return gs_tile_count(uv, conic, N, count, subset, subset_n, ntx, nty, (float)fr.mh_dist, row0, row1, tile_counts,
+                                 ranges_buf, stream);
+        });
+        auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(dev);
+        Tensor sorted, keys;
+        auto emit_sort = [&](int64_t capacity) {
+            sorted = torch::empty({capacity}, i32);
+            keys = torch::empty({capacity}, i32.dtype(torch::kInt64));
+            if (capacity > 0)
+                timed("gs_tile_emit_sort", stream, [&] {
+                    return gs_tile_emit_sort(uv, xyz_cam, conic, N, count, subset, subset_n, ntx, nty, (float)fr.mh_dist, row0,
+                                             row1, ranges_buf, tile_counts, (uint64_t*)keys.data_ptr<int64_t>(), capacity,
+                                             sorted.data_ptr<int32_t>(), sort_prefix, stream);
+                });
+        };
+        const HintKey key{(int)dev.index(), N, T, row0, row1};
+        int64_t guess = -1;
+        int32_t* host;
+        hipEvent_t ready;
+        {
+            std::lock_guard<std::mutex> lock(g_mutex);
+            auto it = g_capacity.find(key);
+            if (it != g_capacity.end()) guess = it->second;
+            std::tie(host, ready) = pinned_slot((int)dev.index());
+        }
+        hip_ok(hipMemcpyAsync(host, ranges_buf + T, (2 + plan_ints) * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        hip_ok(hipEventRecord(ready, (hipStream_t)stream));
+        const bool speculative = guess >= 0;
+        const bool whole = false;   // a band: rows outside it are zero-filled
+        const int64_t image_rows = sp.a2a_hook.is_none() ? sp.padded_height : 0;
+        bool rendered = false;
+        int64_t capacity = 0;
+        if (speculative) {
+            capacity = guess;
+            emit_sort(capacity);
+            if (g_early_render && sort_prefix && capacity > sort_prefix) {
+                fr.out = render_forward(packed, rgbr, ranges_buf, sorted, keys, fr.bg, W, H, row0, row1, whole, sort_prefix, stream,
+                                        image_rows);
+                rendered = true;
+            }
+        }
+        hip_ok(hipEventSynchronize(ready));
+        const int64_t S = host[0], V = host[1];
+        {
+            std::lock_guard<std::mutex> lock(g_mutex);
+            g_counters.frames++;
+            g_counters.speculative += speculative;
+            g_counters.s_min = g_counters.s_min < 0 ? S : std::min(g_counters.s_min, S);
+            g_counters.s_max = std::max(g_counters.s_max, S);
+            if (!speculative || S > capacity) g_counters.misses += speculative;
+            int64_t& hint = g_capacity[key];
+            hint = std::max(hint, S + S / 4 + 4096);
+        }
+        if (!speculative || S > capacity) {
+            emit_sort(S);
+            rendered = false;
+        }
+        Tensor sorted_g = sorted.narrow(0, 0, S), keys_g = keys.narrow(0, 0, S);
+        if (!rendered)
+            fr.out = render_forward(packed, rgbr, ranges_buf, sorted_g, keys_g, fr.bg, W, H, row0, row1, whole, sort_prefix, stream,
+                                    image_rows);
+        // the plan's host half: rows to send, V, v_lo, v_hi, send[G], recv[G]
+        const int32_t* rec = host + 2;
+        fr.v_lo = rec[2];
+        fr.v_hi = rec[3];
+        fr.send_splits.assign(rec + 4, rec + 4 + G);
+        fr.recv_splits.assign(rec + 4 + G, rec + 4 + 2 * G);
+        fr.V = V;
+        fr.S = S;
+        fr.ibuf = iar.buf;
+        fr.fbuf = far.buf;
+        fr.hbuf = hbuf;
+        fr.packed = far.block(6, 12 * (int64_t)N).view({N, 12});
+        fr.rgbr = far.block(5, 3 * (int64_t)N).view({N, 3}).narrow(0, 0, V);
+        fr.ranges = iar.block(5, T + 1);
+        fr.sorted_g = sorted_g;
+        fr.center = far.block(0, 3);
+        fr.rank_t = iar.block(2, N);
+        fr.opa_act = far.block(4, N).view({N, 1});
+        fr.halo_mask = hbuf.narrow(0, 0, N);
+        fr.halo_send = hbuf.narrow(0, N, N);
+        fr.halo_ws = hbuf.narrow(0, 2 * (int64_t)N, n_hw);
+        fr.bwd_mode = gs_get_backward_mode();
+        {
+            std::lock_guard<std::mutex> lock(g_mutex);
+            g_last_plan.v_lo = fr.v_lo;
+            g_last_plan.v_hi = fr.v_hi;
+            g_last_plan.V = V;
+            g_last_plan.S = S;
+            g_last_plan.send_splits = fr.send_splits;
+            g_last_plan.recv_splits = fr.recv_splits;
+        }
+        Tensor uv_t = far.block(1, 2 * (int64_t)N).view({N, 2}).narrow(0, 0, V);
+        Tensor mask_t = iar.block(6, (N + 3) / 4).view(torch::kBool).narrow(0, 0, N);
+        ctx->saved_data["fr"] = guard;
+        ctx->set_materialize_grads(false);
+        ctx->mark_non_differentiable({mask_t});
+        return {uv_t, mask_t};
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        variable_list out(7);
+        FrameRec& fr = frame_of(ctx->saved_data["fr"].toTensor());
+        if (!fr.owned_rows.defined()) return out;
+        const auto dev = fr.xyz.device();
+        const int n_sh = fr.n_sh;
+        Tensor owned = fr.owned_rows;
+        fr.owned_rows = Tensor();
+        // a loss term put directly on uv arrives on top of what node 2 handed over (the owned rows' uv columns,
+        // or a stride-0 placeholder): add the rest for the owned rows
+        const Tensor& g_uv = g[0];
+        Tensor rendered = fr.rendered_uv_grad;
+        fr.rendered_uv_grad = Tensor();
+        if (g_uv.defined() && fr.v_hi > fr.v_lo && g_uv.stride(0) != 0 &&
+            !(rendered.defined() && g_uv.unsafeGetTensorImpl() == rendered.unsafeGetTensorImpl())) {
+            Tensor extra = g_uv.narrow(0, fr.v_lo, fr.v_hi - fr.v_lo);
+            if (rendered.defined() && rendered.stride(0) != 0) extra = extra - rendered.narrow(0, fr.v_lo, fr.v_hi - fr.v_lo);
+            owned = owned.clone();
+            owned.narrow(1, 4, 2).add_(extra);
+        }
+        const int64_t n = fr.i1 - fr.i0, extra_w = 3 * (int64_t)(n_sh - 1);
+        Arena ga(torch::kFloat32, dev, {3 * n, 4 * n, 3 * n, n, 3 * n, extra_w * n});
+        if (n > 0) {
+            void* stream = cur_stream();
+            const int64_t i0 = fr.i0;
+            timed("gs_preprocess_backward", stream, [&] {
+                return gs_preprocess_backward(fr.xyz.data_ptr<float>() + 3 * i0, fr.quaternion.data_ptr<float>() + 4 * i0,
+                                              fr.scale.data_ptr<float>() + 3 * i0, n_sh, fr.camera_T_world.data_ptr(),
+                                              fr.K.data_ptr(), fr.center.data_ptr(), fr.rank_t.data_ptr<int32_t>() + i0,
+                                              fr.opa_act.data_ptr(), owned.data_ptr(), (int)fr.v_lo, (int)n, ga.ptr<float>(0),
+                                              ga.ptr<float>(1), ga.ptr<float>(2), ga.ptr<float>(3), ga.ptr<float>(4),
+                                              n_sh > 1 ? ga.ptr<float>(5) : nullptr, stream);
+            });
+        }
+        out[0] = ga.block(0, 3 * n).view({n, 3});
+        out[1] = ga.block(1, 4 * n).view({n, 4});
+        out[2] = ga.block(2, 3 * n).view({n, 3});
+        out[3] = ga.block(3, n).view({n, 1});
+        out[4] = ga.block(4, 3 * n).view({n, 3});
+        if (n_sh > 1) out[5] = ga.block(5, extra_w * n).view({n, 3, (int64_t)n_sh - 1});
+        return out;
+    }
+};
+
+struct OwnerRender : public torch::autograd::Function<OwnerRender> {
+    static Tensor forward(AutogradContext* ctx, Tensor uv, Tensor guard) {
+        FrameRec& fr = frame_of(guard);
+        const ShardSpec& sp = fr.spec;
+        ctx->saved_data["fr"] = guard;
+        ctx->set_materialize_grads(false);
+        Tensor image = fr.out.image;
+        if (sp.a2a_hook.is_none()) {
+            // in-place all-gather of the equal bands: every rank's band sits at its own rows of the padded buffer
+            const int64_t chunk = sp.band_pixel_rows * fr.W * 3;
+            Tensor flat = image.view({-1}).narrow(0, 0, sp.G * chunk);
+            Tensor mine = flat.narrow(0, sp.rank * chunk, chunk).clone();
+            void* stream = cur_stream();
+            timed_region("rccl_all_gather_image", stream, [&] { sp.pg->_allgather_base(flat, mine)->wait(); });
+        }
+        return image.narrow(0, 0, fr.H);
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        variable_list out(2);
+        if (!g[0].defined()) return out;
+        FrameRec& fr = frame_of(ctx->saved_data["fr"].toTensor());
+        const ShardSpec& sp = fr.spec;
+        const int W = fr.W, H = fr.H;
+        const int64_t V = fr.V;
+        Tensor grad_image = g[0].contiguous();
+        Tensor slab = torch::zeros({std::max<int64_t>(V, 1), SLAB_WIDTH}, fr.packed.options());
+        void* stream = cur_stream();
+        const bool segmented = fr.out.seg.numel() > 0;
+        timed("gs_render_tiles_backward_slab", stream, [&] {
+            return gs_render_tiles_backward_slab(fr.packed.data_ptr(), fr.rgbr.data_ptr(), fr.ranges.data_ptr<int32_t>(),
+                                                 fr.sorted_g.data_ptr<int32_t>(), fr.bg.data_ptr(), fr.out.nsp.data_ptr<int32_t>(),
+                                                 fr.out.fw.data_ptr(), grad_image.data_ptr(), W, H, fr.row0, fr.row1,
+                                                 slab.data_ptr(), nullptr, nullptr, segmented ? fr.out.seg.data_ptr() : nullptr,
+                                                 fr.bwd_mode, stream);
+        });
+        // rows of the send list -> owners; rows of the owned range <- the ranks whose band they reach
+        int64_t n_send = 0, n_recv = 0;
+        for (int64_t c : fr.send_splits) n_send += c;
+        for (int64_t c : fr.recv_splits) n_recv += c;
+        Tensor send = slab.index_select(0, fr.halo_send.narrow(0, 0, n_send));
+        Tensor recv = torch::empty({n_recv, SLAB_WIDTH}, slab.options());
+        if (!sp.a2a_hook.is_none()) {
+            py::gil_scoped_acquire gil;
+            sp.a2a_hook(recv, send, fr.recv_splits, fr.send_splits);
+        } else {
+            timed_region("rccl_all_to_all_grad_rows", stream,
+                         [&] { sp.pg->alltoall_base(recv, send, fr.recv_splits, fr.send_splits)->wait(); });
+        }
+        const int64_t n_own = fr.v_hi - fr.v_lo;
+        Tensor owned = torch::empty({std::max<int64_t>(n_own, 1), SLAB_WIDTH}, slab.options()).narrow(0, 0, n_own);
+        if (n_own > 0) {
+            std::vector<int32_t> offs(sp.G);
+            int32_t off = 0;
+            for (int s2 = 0; s2 < sp.G; s2++) {
+                offs[s2] = off;
+                off += (int32_t)fr.recv_splits[s2];
+            }
+            timed("gs_halo_gather_sum", stream, [&] {
+                return gs_halo_gather_sum((const uint32_t*)fr.halo_mask.data_ptr<int32_t>(), fr.halo_ws.data_ptr<int32_t>(), fr.N,
+                                          sp.G, sp.rank, (int)fr.v_lo, (int)fr.v_hi, recv.data_ptr(), offs.data(),
+                                          owned.data_ptr(), stream);
+            });
+        }
+        fr.owned_rows = owned;
+        // uv.grad (trainer.py:360,379): the complete rows of the owned Gaussians, zeros elsewhere -- materialised
+        // only when somebody retains it; a stride-0 zero routes the backward otherwise
+        bool retained = false;
+        if (auto impl = fr.uv_weak.lock()) retained = Tensor(std::move(impl)).retains_grad();
+        Tensor g_uv;
+        if (retained) {
+            g_uv = torch::zeros({V, 2}, slab.options());
+            if (n_own > 0) g_uv.narrow(0, fr.v_lo, n_own).copy_(owned.narrow(1, 4, 2));
+        } else {
+            g_uv = torch::zeros({1}, slab.options()).expand({V, 2});
+        }
+        fr.rendered_uv_grad = g_uv;
+        out[0] = g_uv;
+        return out;
+    }
+};
+
+std::tuple<Tensor, Tensor, Tensor> sharded_rasterize(
+    Tensor o_xyz, Tensor o_quaternion, Tensor o_scale, Tensor o_opacity, Tensor o_rgb, c10::optional<Tensor> o_sh, Tensor xyz,
+    Tensor quaternion, Tensor scale, Tensor opacity, Tensor rgb, c10::optional<Tensor> sh, Tensor camera_T_world, Tensor K,
+    int64_t width, int64_t height, double near_thresh, double far_thresh, double cull_mask_padding, double mh_dist,
+    Tensor background_rgb, int64_t world_size, int64_t rank, std::vector<int64_t> bounds, std::vector<int64_t> owner_blocks,
+    py::object process_group, py::object all_to_all_hook) {
+    const auto dev = xyz.device();
+    const int64_t N = xyz.size(0);
+    TORCH_CHECK(xyz.is_cuda(), "xyz is not a CUDA tensor");
+    require_f32_cuda(xyz, "xyz", dev, {N, 3});
+    require_f32_cuda(quaternion, "quaternion", dev, {N, 4});
+    require_f32_cuda(scale, "scale", dev, {N, 3});
+    require_f32_cuda(opacity, "opacity", dev, {N, 1});
+    require_f32_cuda(rgb, "rgb", dev, {N, 3});
+    require_f32_cuda(camera_T_world, "camera_T_world", dev, {4, 4});
+    require_f32_cuda(K, "K", dev, {3, 3});
+    require_f32_cuda(background_rgb, "background_rgb", dev, {3});
+    const bool has_sh = sh.has_value() && sh->defined();
+    if (has_sh) {
+        TORCH_CHECK(sh->is_cuda() && sh->device() == dev && sh->scalar_type() == torch::kFloat32, "sh is not a float CUDA tensor");
+        TORCH_CHECK(sh->dim() == 3 && sh->size(0) == N && sh->size(1) == 3 &&
+                        (sh->size(2) == 3 || sh->size(2) == 8 || sh->size(2) == 15),
+                    "sh has the wrong shape ", sh->sizes());
+    }
+    const int G = (int)world_size, me = (int)rank;
+    TORCH_CHECK(G >= 1 && G <= GS_MAX_RANKS && me >= 0 && me < G, "bad world size / rank");
+    TORCH_CHECK((int)bounds.size() == G + 1 && (int)owner_blocks.size() == G + 1, "bounds / owner_blocks need world_size + 1 entries");
+    TORCH_CHECK(width > 0 && height > 0, "image must be non-empty");
+    const int64_t nty = (height + 15) / 16;
+    auto fr = std::make_shared<FrameRec>();
+    ShardSpec& sp = fr->spec;
+    sp.G = G;
+    sp.rank = me;
+    for (int64_t b : bounds) sp.bounds.push_back((int32_t)b);
+    for (int64_t b : owner_blocks) sp.owner_blocks.push_back((int32_t)b);
+    sp.a2a_hook = all_to_all_hook;
+    if (all_to_all_hook.is_none()) {
+        TORCH_CHECK(!process_group.is_none(), "sharded_rasterize needs a process group (or the test hook)");
+        sp.pg = process_group.cast<c10::intrusive_ptr<c10d::ProcessGroup>>();
+        TORCH_CHECK(sp.pg->getSize() == G && sp.pg->getRank() == me, "process group does not match world_size / rank");
+    }
+    sp.band_pixel_rows = 16 * ((nty + G - 1) / G);
+    sp.padded_height = sp.band_pixel_rows * G;
+    fr->row0 = sp.bounds[me];
+    fr->row1 = sp.bounds[me + 1];
+    TORCH_CHECK(0 <= fr->row0 && fr->row0 <= fr->row1 && fr->row1 <= nty, "bad tile row range");
+    fr->xyz = xyz.contiguous();
+    fr->quaternion = quaternion.contiguous();
+    fr->scale = scale.contiguous();
+    fr->opacity = opacity.contiguous();
+    fr->rgb = rgb.contiguous();
+    if (has_sh) fr->sh = sh->contiguous();
+    fr->camera_T_world = camera_T_world.contiguous();
+    fr->K = K.contiguous();
+    fr->bg = background_rgb.contiguous();
+    fr->N = (int)N;
+    fr->n_sh = has_sh ? (int)sh->size(2) + 1 : 1;
+    fr->W = (int)width;
+    fr->H = (int)height;
+    fr->near_thresh = near_thresh;
+    fr->far_thresh = far_thresh;
+    fr->padding = cull_mask_padding;
+    fr->mh_dist = mh_dist;
+    fr->i0 = (int)std::min<int64_t>(N, 256 * owner_blocks[me]);
+    fr->i1 = (int)std::min<int64_t>(N, 256 * owner_blocks[me + 1]);
+    TORCH_CHECK(o_xyz.size(0) == fr->i1 - fr->i0, "the owned slices do not match owner_blocks");
+    c10::DeviceGuard dguard(dev);
+    Tensor guard = make_guard(fr);
+    auto o = OwnerPreprocess::apply(o_xyz, o_quaternion, o_scale, o_opacity, o_rgb, o_sh, guard);
+    fr->uv_weak = c10::weak_intrusive_ptr<c10::TensorImpl, c10::UndefinedTensorImpl>(o[0].getIntrusivePtr());
+    Tensor image = OwnerRender::apply(o[0], guard);
+    return std::make_tuple(image, o[1], o[0]);
+}
+
+py::dict last_plan() {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    py::dict d;
+    d["v_lo"] = g_last_plan.v_lo;
+    d["v_hi"] = g_last_plan.v_hi;
+    d["V"] = g_last_plan.V;
+    d["S"] = g_last_plan.S;
+    d["send_splits"] = g_last_plan.send_splits;
+    d["recv_splits"] = g_last_plan.recv_splits;
+    return d;
+}
+
 py::dict counters() {
     std::vector<Tensor> log;
     Counters c;
@@ -530,6 +949,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("scale"), py::arg("opacity"), py::arg("rgb"), py::arg("sh"), py::arg("camera_T_world"), py::arg("K"),
           py::arg("width"), py::arg("height"), py::arg("near_thresh"), py::arg("far_thresh"), py::arg("cull_mask_padding"),
           py::arg("mh_dist"), py::arg("background_rgb"), py::arg("row0") = 0, py::arg("row1") = -1);
+    m.def("sharded_rasterize", &sharded_rasterize,
+          "one rank of the tile-row sharded frame, owner-sliced gradients, equal bands: -> (image, culling_mask, uv)");
+    m.def("last_plan", &last_plan);
     m.def("counters", &counters);
     m.def("reset_counters", &reset_counters);
     m.def("set_modes", &set_modes, py::arg("sort_prefix"), py::arg("early_render"));

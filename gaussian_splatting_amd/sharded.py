@@ -34,6 +34,9 @@ import torch.distributed as dist
 from .splat_py.structs import Gaussians
 
 DEFER_HOST_READ = True    # owner fused path: enqueue the render before waiting for the frame's counts
+# owner mode, fused path, equal bands: the frame's orchestration in C++ (csrc/frame_hip.cpp: sharded_rasterize --
+# the same two autograd nodes, the same C-ABI calls, the collectives through c10d); False keeps it in Python
+NATIVE = True
 OWNER_BLOCK = 256   # owner slices are whole blocks of the per-Gaussian kernels (csrc/halo.hip)
 SLAB_WIDTH = 9      # rgb 3 | opacity 1 | uv 2 | conic 3
 
@@ -641,6 +644,23 @@ class ShardedRasterizer:
             if owned is None:
                 raise ValueError("grad_mode 'owner' needs owned= (the parameter slices of this rank)")
             o = (owned.xyz, owned.quaternion, owned.scale, owned.opacity, owned.rgb, owned.sh)
+            nat = fused.native() if (use_fused and NATIVE and self.band_policy == "equal") else None
+            if nat is not None:
+                g = gaussians
+                nat.set_modes(bool(fused.SORT_PREFIX), bool(fused.EARLY_RENDER))
+                nat.set_segments(0 if fused.SEGMENTS == "auto" else (1 if fused.SEGMENTS else -1))
+                group = None
+                if self.all_to_all is None:
+                    group = self.group if self.group is not None else dist.group.WORLD
+                image, culling_mask, uv = nat.sharded_rasterize(
+                    *o, g.xyz, g.quaternion, g.scale, g.opacity, g.rgb, g.sh, camera_T_world, camera.K, int(camera.width),
+                    int(camera.height), near_thresh, far_thresh, cull_mask_padding, mh_dist, background_rgb,
+                    self.world_size, self.rank, list(self.bounds), owner_blocks(g.xyz.shape[0], self.world_size), group,
+                    self.all_to_all)
+                p = nat.last_plan()
+                self.last_plan = SimpleNamespace(send_splits=p["send_splits"], recv_splits=p["recv_splits"],
+                                                 v_lo=p["v_lo"], v_hi=p["v_hi"])
+                return self._checked(image), culling_mask, uv
             if use_fused:
                 fr = SimpleNamespace(owned_rows=None, uv_ref=None, rendered_uv_grad=None, tile_rows=None)
                 uv, culling_mask = _OwnerPreprocess.apply(

@@ -19,7 +19,10 @@ ap.add_argument("--workload", default="D")
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--grad-mode", default="replicated", choices=["replicated", "owner"],
                 help="owner: the sparse-exchange path with the all_to_all replaced by a local fill (compute only)")
+ap.add_argument("--native", type=int, default=1, help="0: the Python orchestration of the sharded frame")
 a = ap.parse_args()
+from gaussian_splatting_amd import sharded as _sh
+_sh.NATIVE = bool(a.native)
 N, W, H, deg = WORKLOADS[a.workload]
 g, cam, T = make_scene(N, W, H, deg, seed=0, device="cuda")
 params = [p for p in (g.xyz, g.rgb, g.opacity, g.scale, g.quaternion, g.sh) if p is not None]

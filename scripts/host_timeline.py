@@ -15,8 +15,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--defer", type=int, default=0)
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--native", type=int, default=1, help="0: the Python orchestration of the sharded frame")
 a = ap.parse_args()
 sharded.DEFER_HOST_READ = bool(a.defer)
+sharded.NATIVE = bool(a.native)
 N, W, H, deg = WORKLOADS["D"]
 g, cam, T = make_scene(N, W, H, deg, seed=0, device="cuda")
 gi = make_grad_image(W, H, seed=1, device="cuda")
@@ -64,7 +66,7 @@ t_all = time.perf_counter()
 for _ in range(a.steps):
     step()
 torch.cuda.synchronize()
-print(f"defer={a.defer} world={a.world}: {(time.perf_counter() - t_all) / a.steps * 1e3:.3f} ms/step")
+print(f"native={a.native} defer={a.defer} world={a.world}: {(time.perf_counter() - t_all) / a.steps * 1e3:.3f} ms/step")
 marks.clear()
 torch.cuda.synchronize()
 t0 = time.perf_counter()

@@ -78,7 +78,21 @@ def test_halo_plan_matches_reference_and_oracle(G):
                                                       (3, 3, 20000, 640, 472, 2.0, "cost-ffb"),
                                                       # a loss term directly on the returned uv, next to the image loss
                                                       (2, 3, 20000, 640, 472, 2.0, "equal-uvloss")])
-def test_owner_mode_with_simulated_ranks(G, deg, N, W, H, near, policy):
+@pytest.mark.parametrize("native", [True, False])
+def test_owner_mode_with_simulated_ranks(G, deg, N, W, H, near, policy, native):
+    """native: the frame's orchestration in C++ (csrc/frame_hip.cpp sharded_rasterize; equal bands) or in Python"""
+    from gaussian_splatting_amd import sharded
+    if native and not policy.startswith("equal"):
+        pytest.skip("the native orchestration covers the equal-band policy")
+    prev = sharded.NATIVE
+    sharded.NATIVE = native
+    try:
+        _owner_mode_with_simulated_ranks(G, deg, N, W, H, near, policy)
+    finally:
+        sharded.NATIVE = prev
+
+
+def _owner_mode_with_simulated_ranks(G, deg, N, W, H, near, policy):
     ffb = policy == "cost-ffb"
     uvloss = policy == "equal-uvloss"
     policy = "cost" if ffb else ("equal" if uvloss else policy)
