@@ -273,14 +273,16 @@ __device__ inline void slice_of(int sl, int V, int& g0, int& g1) {
     g1 = min(V, g0 + chunk);
 }
 
+// (t0, Tb): the tiles of the rows [row0, row1) -- the histogram covers only those (a multi-GPU rank's band is an
+// eighth of the grid: 2.4 MB of histogram matrix instead of 17.8 at workload D)
 __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_count(const float* __restrict__ uvs,
                                                           const float* __restrict__ conic, int V,
                                                           int ntx, int nty, float mh, int row0,
                                                           int row1, int* __restrict__ hist,
                                                           Items items) {
     extern __shared__ int s_hist[];
-    const int T = ntx * nty;
-    for (int t = threadIdx.x; t < T; t += PRIV_BLOCK) s_hist[t] = 0;
+    const int t0 = row0 * ntx, Tb = (row1 - row0) * ntx;
+    for (int t = threadIdx.x; t < Tb; t += PRIV_BLOCK) s_hist[t] = 0;
     __syncthreads();
     int g0, g1;
     const int sl = slice_index(blockIdx.x);
@@ -290,11 +292,11 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_count(const float* __restric
         const bool active = i < g1;
         TileWalk tw;
         if (active) tw = tile_walk_setup(uvs, conic, item_at(items, i), ntx, nty, mh, row0, row1);
-        wave_for_each_tile(active, tw, ntx, 0, [&](int tile, uint64_t) { atomicAdd(&s_hist[tile], 1); });
+        wave_for_each_tile(active, tw, ntx, 0, [&](int tile, uint64_t) { atomicAdd(&s_hist[tile - t0], 1); });
     }
     __syncthreads();
-    int* row = hist + (size_t)sl * T;
-    for (int t = threadIdx.x; t < T; t += PRIV_BLOCK) row[t] = s_hist[t];
+    int* row = hist + (size_t)sl * Tb;
+    for (int t = threadIdx.x; t < Tb; t += PRIV_BLOCK) row[t] = s_hist[t];
 }
 
 // hist[b][t] <- sum_{b' < b} hist[b'][t];  counts[t] <- column total.
@@ -365,10 +367,10 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_emit(
     const int* __restrict__ ranges, const int* __restrict__ hist, uint64_t* __restrict__ keys,
     Items items, int64_t cap) {
     extern __shared__ int s_cursor[];
-    const int T = ntx * nty;
+    const int t0 = row0 * ntx, Tb = (row1 - row0) * ntx;   // the histogram matrix covers the rows [row0, row1)
     const int sl = slice_index(blockIdx.x);
-    const int* row = hist + (size_t)sl * T;
-    for (int t = threadIdx.x; t < T; t += PRIV_BLOCK) s_cursor[t] = ranges[t] + row[t];
+    const int* row = hist + (size_t)sl * Tb;
+    for (int t = threadIdx.x; t < Tb; t += PRIV_BLOCK) s_cursor[t] = ranges[t0 + t] + row[t];
     __syncthreads();
     int g0, g1;
     slice_of(sl, item_count(items, V), g0, g1);
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_emit(
         // (storing a hit's key only after the NEXT hit's cursor atomic has been issued, so that the LDS round
         // trip overlaps the following separating-axis test, changes nothing: 0.293 vs 0.291 ms)
         wave_for_each_tile(active, tw, ntx, key, [&](int tile, uint64_t k) {
-            const int pos = atomicAdd(&s_cursor[tile], 1);
+            const int pos = atomicAdd(&s_cursor[tile - t0], 1);
 #if defined(GS_EMIT_NOSTORE)      // experiment builds (timing only): the walk + LDS cursors without the key stores
             if (pos < 0) keys[pos] = k;
 #elif defined(GS_EMIT_CELL)       // ... and with the stores going to (4x4-tile cell, workgroup) runs instead of tile segments
@@ -972,13 +974,18 @@ int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visi
                "bad tile row range");
     hipStream_t s = (hipStream_t)stream;
     const int T = n_tiles_x * n_tiles_y;
+    const int t0 = tile_row0 * n_tiles_x, Tb = (tile_row1 - tile_row0) * n_tiles_x;   // the rows' tiles
     int32_t* counts = workspace;
-    if (use_private(T, V)) {
+    if (Tb > 0 && use_private(Tb, V)) {
         int32_t* hist = workspace + T;
-        k_bin_count<<<PRIV_NB, PRIV_BLOCK, sizeof(int) * (size_t)T, s>>>(
+        if (Tb < T && hipMemsetAsync(counts, 0, sizeof(int) * (size_t)T, s) != hipSuccess) {   // tiles of other rows: empty
+            gs::set_error("tile_count: memset failed");
+            return GS_EHIP;
+        }
+        k_bin_count<<<PRIV_NB, PRIV_BLOCK, sizeof(int) * (size_t)Tb, s>>>(
             (const float*)uvs, (const float*)conic, V, n_tiles_x, n_tiles_y, mh_dist, tile_row0,
             tile_row1, hist, items);
-        k_bin_colscan<<<div_up(T, CS_TILES), CS_TILES * CS_SEGS, 0, s>>>(hist, T, counts);
+        k_bin_colscan<<<div_up(Tb, CS_TILES), CS_TILES * CS_SEGS, 0, s>>>(hist, Tb, counts + t0);
     } else {
         if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)T, s) != hipSuccess) {
             gs::set_error("tile_count: memset failed");
@@ -1009,10 +1016,11 @@ int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void*
                "sort_prefix must be 0 or GS_SORT_PREFIX (%d)", GS_SORT_PREFIX);
     hipStream_t s = (hipStream_t)stream;
     const int T = n_tiles_x * n_tiles_y;
+    const int Tb = (tile_row1 - tile_row0) * n_tiles_x;
     if (S <= 0 || V <= 0) return GS_OK;
-    if (use_private(T, V)) {
+    if (Tb > 0 && use_private(Tb, V)) {
         const int32_t* hist = workspace + T;
-        k_bin_emit<<<PRIV_NB, PRIV_BLOCK, sizeof(int) * (size_t)T, s>>>(
+        k_bin_emit<<<PRIV_NB, PRIV_BLOCK, sizeof(int) * (size_t)Tb, s>>>(
             (const float*)uvs, (const float*)xyz_camera_frame, (const float*)conic, V, n_tiles_x,
             n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, hist, keys, items, S);
     } else {

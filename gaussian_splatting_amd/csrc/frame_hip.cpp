@@ -61,6 +61,7 @@ bool g_sort_prefix = true, g_early_render = true;
 // depth segments of the backward (include/gsplat_hip.h: gs_render_segment_workspace_bytes): 0 = auto (frames /
 // bands of fewer than 1500 tiles whose lists average >= 192 entries: a multi-GPU rank's band), 1 = always, -1 = never
 int g_segments = 0;
+bool g_band_compact = true;   // multi-GPU: band-compact per-Gaussian stage (OwnerPreprocess)
 bool want_segments(int64_t n_instances, int64_t n_tiles) {
     if (g_segments == 0) return n_tiles > 0 && n_tiles < 1500 && n_instances >= 192 * n_tiles;
     return g_segments > 0 && n_tiles > 0;
@@ -483,7 +484,8 @@ struct FrameRec {
     Tensor ibuf, fbuf, hbuf;   // arenas (kept alive: everything below points into them)
     Tensor packed, rgbr, ranges, sorted_g, center, rank_t, opa_act, halo_mask, halo_send, halo_ws;
     RenderOut out;
-    int64_t V = 0, S = 0, v_lo = 0, v_hi = 0;
+    int64_t V = 0, L = 0, S = 0, v_lo = 0, v_hi = 0;
+    bool compact = false;
     std::vector<int64_t> send_splits, recv_splits;
     Tensor owned_rows, rendered_uv_grad;
     // the uv output (weak: the record must not keep its own graph alive), to see whether its gradient is retained
@@ -523,37 +525,69 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
         const int row0 = fr.row0, row1 = fr.row1;
         const int sort_prefix = g_sort_prefix ? GS_SORT_PREFIX : 0;
         const int plan_ints = 4 + 2 * G;
+        // band-compact per-Gaussian stage (csrc/preprocess.hip): the full evaluation only for the Gaussians that can
+        // reach the band, arrays compacted to those rows (row index l); everything downstream then works on rows l
+        const bool compact = g_band_compact && G > 1;
+        fr.compact = compact;
         void* stream = cur_stream();
 
         const int64_t n_ws = (int64_t)gs_preprocess_workspace_ints(N), n_tc = (int64_t)gs_tile_workspace_ints(T);
         Arena iar(torch::kInt32, dev, {n_ws, 1, N, N, n_tc, T + 2 + plan_ints, (N + 3) / 4});
-        Arena far(torch::kFloat32, dev, {3, 2 * (int64_t)N, 3 * (int64_t)N, 3 * (int64_t)N, N, 3 * (int64_t)N, 12 * (int64_t)N});
+        // float blocks: centre | uv (by visible index) | xyz_cam | conic | opacity_act (by visible index) | colour |
+        // packed | uv of the compact rows (compact mode; xyz_cam, conic, packed are then by compact row as well)
+        Arena far(torch::kFloat32, dev, {4, 2 * (int64_t)N, 3 * (int64_t)N, 3 * (int64_t)N, N, compact ? 0 : 3 * (int64_t)N,
+                                         12 * (int64_t)N, compact ? 2 * (int64_t)N : 0});
         int32_t *ws = iar.ptr<int32_t>(0), *count = iar.ptr<int32_t>(1), *rank = iar.ptr<int32_t>(2),
                 *vis_idx = iar.ptr<int32_t>(3), *tile_counts = iar.ptr<int32_t>(4), *ranges_buf = iar.ptr<int32_t>(5);
         uint8_t* mask = (uint8_t*)iar.ptr<int32_t>(6);
         float *center = far.ptr<float>(0), *uv = far.ptr<float>(1), *xyz_cam = far.ptr<float>(2), *conic = far.ptr<float>(3),
-              *opa = far.ptr<float>(4), *rgbr = far.ptr<float>(5), *packed = far.ptr<float>(6);
-        timed("gs_preprocess_forward", stream, [&] {
-            return gs_preprocess_forward(fr.xyz.data_ptr(), fr.quaternion.data_ptr(), fr.scale.data_ptr(), fr.opacity.data_ptr(),
-                                         fr.rgb.data_ptr(), has_sh ? fr.sh.data_ptr() : nullptr, n_sh,
-                                         fr.camera_T_world.data_ptr(), fr.K.data_ptr(), N, W, H, (float)fr.near_thresh,
-                                         (float)fr.far_thresh, (float)fr.padding, (float)fr.mh_dist, row0, row1, ws, center,
-                                         count, mask, rank, vis_idx, uv, xyz_cam, conic, opa, rgbr, packed, stream);
-        });
-        // the exchange plan; its record rides on the frame's one host read, its send list is the binning's subset
+              *opa = far.ptr<float>(4), *rgbr = far.ptr<float>(5), *packed = far.ptr<float>(6), *uv_l = far.ptr<float>(7);
         const int64_t n_hw = (int64_t)gs_halo_workspace_ints(N, G);
         Tensor hbuf = torch::empty({2 * (int64_t)N + n_hw}, torch::TensorOptions().dtype(torch::kInt32).device(dev));
         int32_t* h = hbuf.data_ptr<int32_t>();
         int32_t* record = ranges_buf + T + 2;
-        timed("gs_halo_plan", stream, [&] {
-            return gs_halo_plan(uv, conic, N, count, ws, ntx, nty, (float)fr.mh_dist, sp.bounds.data(), sp.owner_blocks.data(), G,
-                                me, (uint32_t*)h, h + 2 * (int64_t)N, h + N, record, stream);
-        });
-        const int32_t* subset = G > 1 ? h + N : nullptr;
-        const int32_t* subset_n = G > 1 ? record : nullptr;
+        // what the binning walks: the first *items_n rows of (bin_uv, bin_conic, bin_xyz) or an index list into them
+        const float *bin_uv = uv, *bin_conic = conic, *bin_xyz = xyz_cam;
+        const int32_t *items_n = count, *subset = nullptr, *subset_n = nullptr;
+        if (compact) {
+            timed("gs_band_project", stream, [&] {
+                return gs_band_project(fr.xyz.data_ptr(), fr.scale.data_ptr(), fr.opacity.data_ptr(), fr.camera_T_world.data_ptr(),
+                                       fr.K.data_ptr(), N, W, H, (float)fr.near_thresh, (float)fr.far_thresh, (float)fr.padding,
+                                       (float)fr.mh_dist, sp.bounds.data(), G, ws, center, count, mask, rank, vis_idx, uv, opa,
+                                       (uint32_t*)h, h + 2 * (int64_t)N, stream);
+            });
+            timed("gs_halo_plan", stream, [&] {
+                return gs_halo_plan_masked((const uint32_t*)h, N, count, ws, sp.owner_blocks.data(), G, me, h + 2 * (int64_t)N,
+                                           h + N, record, stream);
+            });
+            timed("gs_preprocess_forward", stream, [&] {
+                return gs_preprocess_forward_list(fr.xyz.data_ptr(), fr.quaternion.data_ptr(), fr.scale.data_ptr(),
+                                                  fr.rgb.data_ptr(), has_sh ? fr.sh.data_ptr() : nullptr, n_sh,
+                                                  fr.camera_T_world.data_ptr(), fr.K.data_ptr(), center, h + N, record, N, vis_idx,
+                                                  uv, opa, uv_l, xyz_cam, conic, packed, stream);
+            });
+            bin_uv = uv_l;
+            items_n = record;   // record[0] = rows of the send list = rows of the compact arrays
+            rgbr = packed;      // (the one-coefficient render reads the colour from the record)
+        } else {
+            timed("gs_preprocess_forward", stream, [&] {
+                return gs_preprocess_forward(fr.xyz.data_ptr(), fr.quaternion.data_ptr(), fr.scale.data_ptr(), fr.opacity.data_ptr(),
+                                             fr.rgb.data_ptr(), has_sh ? fr.sh.data_ptr() : nullptr, n_sh,
+                                             fr.camera_T_world.data_ptr(), fr.K.data_ptr(), N, W, H, (float)fr.near_thresh,
+                                             (float)fr.far_thresh, (float)fr.padding, (float)fr.mh_dist, row0, row1, ws, center,
+                                             count, mask, rank, vis_idx, uv, xyz_cam, conic, opa, rgbr, packed, stream);
+            });
+            // the exchange plan; its record rides on the frame's one host read, its send list is the binning's subset
+            timed("gs_halo_plan", stream, [&] {
+                return gs_halo_plan(uv, conic, N, count, ws, ntx, nty, (float)fr.mh_dist, sp.bounds.data(),
+                                    sp.owner_blocks.data(), G, me, (uint32_t*)h, h + 2 * (int64_t)N, h + N, record, stream);
+            });
+            subset = G > 1 ? h + N : nullptr;
+            subset_n = G > 1 ? record : nullptr;
+        }
         timed("gs_tile_count", stream, [&] {
-            return gs_tile_count(uv, conic, N, count, subset, subset_n, ntx, nty, (float)fr.mh_dist, row0, row1, tile_counts,
-                                 ranges_buf, stream);
+            return gs_tile_count(bin_uv, bin_conic, N, items_n, subset, subset_n, ntx, nty, (float)fr.mh_dist, row0, row1,
+                                 tile_counts, ranges_buf, stream);
         });
         auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(dev);
         Tensor sorted, keys;
@@ -562,9 +596,10 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
             keys = torch::empty({capacity}, i32.dtype(torch::kInt64));
             if (capacity > 0)
                 timed("gs_tile_emit_sort", stream, [&] {
-                    return gs_tile_emit_sort(uv, xyz_cam, conic, N, count, subset, subset_n, ntx, nty, (float)fr.mh_dist, row0,
-                                             row1, ranges_buf, tile_counts, (uint64_t*)keys.data_ptr<int64_t>(), capacity,
-                                             sorted.data_ptr<int32_t>(), sort_prefix, stream);
+                    return gs_tile_emit_sort(bin_uv, bin_xyz, bin_conic, N, items_n, subset, subset_n, ntx, nty,
+                                             (float)fr.mh_dist, row0, row1, ranges_buf, tile_counts,
+                                             (uint64_t*)keys.data_ptr<int64_t>(), capacity, sorted.data_ptr<int32_t>(),
+                                             sort_prefix, stream);
                 });
         };
         const HintKey key{(int)dev.index(), N, T, row0, row1};
@@ -594,7 +629,9 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
             }
         }
         hip_ok(hipEventSynchronize(ready));
-        const int64_t S = host[0], V = host[1];
+        // the plan's host half: rows to send, V, v_lo, v_hi, send[G], recv[G]
+        const int32_t* rec = host + 2;
+        const int64_t S = host[0], V = rec[1], L = compact ? rec[0] : rec[1];
         {
             std::lock_guard<std::mutex> lock(g_mutex);
             g_counters.frames++;
@@ -613,19 +650,18 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
         if (!rendered)
             fr.out = render_forward(packed, rgbr, ranges_buf, sorted_g, keys_g, fr.bg, W, H, row0, row1, whole, sort_prefix, stream,
                                     image_rows);
-        // the plan's host half: rows to send, V, v_lo, v_hi, send[G], recv[G]
-        const int32_t* rec = host + 2;
         fr.v_lo = rec[2];
         fr.v_hi = rec[3];
         fr.send_splits.assign(rec + 4, rec + 4 + G);
         fr.recv_splits.assign(rec + 4 + G, rec + 4 + 2 * G);
         fr.V = V;
+        fr.L = L;   // rows of the per-splat arrays the render works on (and of its gradient slab)
         fr.S = S;
         fr.ibuf = iar.buf;
         fr.fbuf = far.buf;
         fr.hbuf = hbuf;
         fr.packed = far.block(6, 12 * (int64_t)N).view({N, 12});
-        fr.rgbr = far.block(5, 3 * (int64_t)N).view({N, 3}).narrow(0, 0, V);
+        fr.rgbr = compact ? fr.packed : far.block(5, 3 * (int64_t)N).view({N, 3}).narrow(0, 0, V);
         fr.ranges = iar.block(5, T + 1);
         fr.sorted_g = sorted_g;
         fr.center = far.block(0, 3);
@@ -722,7 +758,7 @@ struct OwnerRender : public torch::autograd::Function<OwnerRender> {
         const int W = fr.W, H = fr.H;
         const int64_t V = fr.V;
         Tensor grad_image = g[0].contiguous();
-        Tensor slab = torch::zeros({std::max<int64_t>(V, 1), SLAB_WIDTH}, fr.packed.options());
+        Tensor slab = torch::zeros({std::max<int64_t>(fr.L, 1), SLAB_WIDTH}, fr.packed.options());
         void* stream = cur_stream();
         const bool segmented = fr.out.seg.numel() > 0;
         timed("gs_render_tiles_backward_slab", stream, [&] {
@@ -736,7 +772,8 @@ struct OwnerRender : public torch::autograd::Function<OwnerRender> {
         int64_t n_send = 0, n_recv = 0;
         for (int64_t c : fr.send_splits) n_send += c;
         for (int64_t c : fr.recv_splits) n_recv += c;
-        Tensor send = slab.index_select(0, fr.halo_send.narrow(0, 0, n_send));
+        // (band-compact rows ARE the send list, in its order)
+        Tensor send = fr.compact ? slab.narrow(0, 0, n_send) : slab.index_select(0, fr.halo_send.narrow(0, 0, n_send));
         Tensor recv = torch::empty({n_recv, SLAB_WIDTH}, slab.options());
         if (!sp.a2a_hook.is_none()) {
             py::gil_scoped_acquire gil;
@@ -935,6 +972,7 @@ py::dict collect_timing() {
 }
 
 void set_segments(int mode) { g_segments = mode; }
+void set_band_compact(bool on) { g_band_compact = on; }
 
 void set_modes(bool sort_prefix, bool early_render) {
     g_sort_prefix = sort_prefix;
@@ -956,6 +994,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("reset_counters", &reset_counters);
     m.def("set_modes", &set_modes, py::arg("sort_prefix"), py::arg("early_render"));
     m.def("set_segments", &set_segments, py::arg("mode"));
+    m.def("set_band_compact", &set_band_compact, py::arg("on"));
     m.def("last_tile_flags", &last_tile_flags, py::arg("clear") = false);
     m.def("enable_timing", &enable_timing, py::arg("on"), py::arg("only") = std::string());
     m.def("reserve_events", &reserve_events);

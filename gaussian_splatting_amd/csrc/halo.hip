@@ -264,6 +264,26 @@ int gs_halo_plan(const void* uvs, const void* conic, int N, const int32_t* visib
     return check_launch("halo_plan");
 }
 
+int gs_halo_plan_masked(const uint32_t* mask, int N, const int32_t* visible_count,
+                        const int32_t* preprocess_workspace, const int32_t* owner_blocks, int G, int rank,
+                        int32_t* workspace, int32_t* send_index, int32_t* plan, void* stream) {
+    GS_REQUIRE(G >= 1 && G <= GS_MAX_RANKS, "halo_plan: 1 <= G <= %d", GS_MAX_RANKS);
+    GS_REQUIRE(rank >= 0 && rank < G, "halo_plan: bad rank");
+    GS_REQUIRE(N > 0, "halo_plan: N must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = div_up(N, HB);
+    int32_t* blk_counts = workspace;   // filled by gs_band_project
+    int32_t* offsets = workspace + (size_t)G * nblk;
+    int32_t* vb = offsets + (size_t)G * nblk;
+    int32_t* Pb = vb + (G + 1);
+    const int32_t* pre_offsets = preprocess_workspace + nblk;
+    k_halo_scan<<<G, 1024, 0, s>>>(blk_counts, nblk, offsets);
+    k_halo_bounds<<<1, GS_WAVE*(GS_MAX_RANKS + 1), 0, s>>>(
+        mask, offsets, nblk, visible_count, pre_offsets, rank_ints(owner_blocks, G + 1), G, rank, vb, Pb, plan);
+    k_halo_send_index<<<nblk, HB, 0, s>>>(mask, offsets, nblk, visible_count, rank, send_index);
+    return check_launch("halo_plan_masked");
+}
+
 int gs_halo_gather_sum(const uint32_t* mask, const int32_t* workspace, int N, int G, int rank,
                        int v_lo, int v_hi, const void* recv, const int32_t* recv_offsets,
                        void* out, void* stream) {

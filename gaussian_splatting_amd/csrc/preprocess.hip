@@ -282,6 +282,178 @@ __global__ __launch_bounds__(PP_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))
     dst[2] = make_float4(pk[8], pk[9], pk[10], pk[11]);
 }
 
+
+// ---- multi-GPU: band-compact per-Gaussian stage ------------------------------------------------------------
+// A rank renders 1/G of the tile rows but gs_preprocess_forward evaluates and writes ~100 B for every visible
+// Gaussian of the frame (only the SH colour is band-limited): 0.126 of a rank's 0.53 ms at 8 ranks (workload D).
+// Here the full evaluation runs only for the Gaussians that can reach the rank's band, into arrays compacted to
+// exactly those rows:
+//   k_band_project     every Gaussian: transform, projection, frustum cull, ordered compaction (visible index v as in
+//                      k_preprocess) -> culling mask, rank, vis_idx, uv[v], sigmoid(opacity)[v], and mask[v]: bit s =
+//                      the Gaussian CAN reach the band of rank s.  The test needs no covariance: the candidate window of
+//                      tile_culling.cu:138-156 has radius_tiles = ceil(mh sqrt(l1) / 16) + 1 with l1 = lambda_max(Sigma_2D)
+//                      + 0.25 and Sigma_2D = (J W) Sigma (J W)^T <= s_max^2 |W|^2 J J^T, so l1 <= s_max^2 |W|^2
+//                      lambda_max(J J^T) + 0.25 (s_max = the largest scale, |W| = the rotation block's norm, 1 for a
+//                      rigid pose): a superset of the exact window, the same on every rank.  A row that is exchanged
+//                      for nothing is a row of zeros.
+//   (gs_halo_plan_masked: the exchange plan from these masks; its send list -- the visible Gaussians with this
+//   rank's bit, ascending -- is the list of rows of the compact arrays)
+//   k_preprocess_list  row l of the list: Sigma, J, conic, SH colour, packed record of Gaussian vis_idx[send[l]],
+//                      written at row l.  Same device functions and operation order as k_preprocess: the same bits.
+// Binning, sort and render then work on the compact arrays (row index l, monotone in v: depth ties keep their
+// order, the tile lists are the single-GPU lists with v relabelled), and the band's render-gradient slab [L, 9]
+// IS the send buffer of the gradient exchange.
+struct BandRows {
+    int v[GS_MAX_RANKS + 1];
+};
+
+__device__ inline float rotation_norm2_bound(const float* __restrict__ M) {
+    // lambda_max(W^T W) <= its largest absolute row sum (1 + rounding for a rotation)
+    float best = 0;
+    for (int i = 0; i < 3; i++) {
+        float row = 0;
+        for (int j = 0; j < 3; j++) {
+            const float d = M[0 + i] * M[0 + j] + M[4 + i] * M[4 + j] + M[8 + i] * M[8 + j];
+            row += __builtin_fabsf(d);
+        }
+        best = fmaxf(best, row);
+    }
+    return best;
+}
+
+template <int PASS>   // 0: count per block; 1: write
+__global__ __launch_bounds__(PP_BLOCK) void k_band_project(
+    const float* __restrict__ xyz, const float* __restrict__ scale, const float* __restrict__ opacity,
+    const float* __restrict__ M, const float* __restrict__ K, int N, Frustum fr, float mh, int nty, BandRows rows, int G,
+    const int* __restrict__ block_offsets, uint8_t* __restrict__ culled, int* __restrict__ rank,
+    int* __restrict__ vis_idx, float* __restrict__ uv_out, float* __restrict__ opa_out, uint32_t* __restrict__ mask,
+    int* __restrict__ bit_counts /*[G][nblk] by visible-index block*/, int nblk) {
+    __shared__ int s_cnt[PP_BLOCK / GS_WAVE];
+    const int g = blockIdx.x * PP_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool vis = false;
+    float c[3] = {0, 0, 1}, uv[2] = {0, 0};
+    if (g < N) {
+        to_camera(M, xyz[g * 3 + 0], xyz[g * 3 + 1], xyz[g * 3 + 2], c);
+        vis = !is_culled(c, K, fr, uv);
+    }
+    const unsigned long long bal = __ballot(vis);
+    if (lane == 0) s_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int v = block_offsets[blockIdx.x] + __popcll(bal & ((1ull << lane) - 1));
+    for (int w = 0; w < wave; w++) v += s_cnt[w];
+    if (g < N) {
+        culled[g] = vis ? 0 : 1;
+        rank[g] = vis ? v : -1;
+    }
+    if (!(g < N && vis)) return;
+    vis_idx[v] = g;
+    uv_out[v * 2 + 0] = uv[0];
+    uv_out[v * 2 + 1] = uv[1];
+    opa_out[v] = sigmoid_det(opacity[g]);
+    // upper bound of the candidate window's radius in tiles
+    const float s_max = fmaxf(fmaxf(det_expf(scale[g * 3 + 0]), det_expf(scale[g * 3 + 1])), det_expf(scale[g * 3 + 2]));
+    const float iz = 1.0f / c[2];
+    const float jx = K[0] * iz, jy = K[4] * iz, tx = K[0] * c[0] * iz * iz, ty = K[4] * c[1] * iz * iz;
+    const float A = jx * jx + tx * tx, C = jy * jy + ty * ty, B = tx * ty;
+    const float lam = 0.5f * (A + C) + __builtin_sqrtf(0.25f * (A - C) * (A - C) + B * B);
+    const float l1 = s_max * s_max * rotation_norm2_bound(M) * lam * 1.001f + 0.25f;
+    const float rt = __builtin_ceilf(mh * __builtin_sqrtf(l1) * 1.001f / 16.0f) + 1.0f;
+    uint32_t m = 0;
+    if (rt < 1.0e6f) {
+        const int r = (int)rt;
+        const int py = f2i(__builtin_floorf(uv[1] / 16.0f));
+        const int sy = max(0, py - r), ey = min(nty, py + r);
+        for (int s2 = 0; s2 < G; s2++)
+            if (sy < rows.v[s2 + 1] && ey > rows.v[s2] && sy < ey) m |= 1u << s2;
+    } else {
+        m = (1u << G) - 1;   // unbounded or not a number: every band (a superset is always safe)
+    }
+    mask[v] = m;
+}
+
+// per-256-block counts of every mask bit, by VISIBLE index (the layout gs_halo_plan's scan expects)
+__global__ __launch_bounds__(PP_BLOCK) void k_band_bit_counts(const uint32_t* __restrict__ mask,
+                                                              const int* __restrict__ visible_count, int G,
+                                                              int* __restrict__ blk_counts, int nblk) {
+    __shared__ int s_cnt[GS_MAX_RANKS][PP_BLOCK / GS_WAVE];
+    const int v = blockIdx.x * PP_BLOCK + threadIdx.x;
+    const uint32_t m = v < *visible_count ? mask[v] : 0;
+    for (int s2 = 0; s2 < G; s2++) {
+        const int n = __popcll(__ballot((m >> s2) & 1u));
+        if ((threadIdx.x & 63) == 0) s_cnt[s2][threadIdx.x >> 6] = n;
+    }
+    __syncthreads();
+    if (threadIdx.x < G)
+        blk_counts[threadIdx.x * nblk + blockIdx.x] =
+            s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
+}
+
+template <int N_SH>
+__global__ __launch_bounds__(PP_BLOCK) void k_preprocess_list(
+    const float* __restrict__ xyz, const float* __restrict__ quat, const float* __restrict__ scale,
+    const float* __restrict__ rgb, const float* __restrict__ sh, const float* __restrict__ M,
+    const float* __restrict__ K, const float* __restrict__ center, const int* __restrict__ list,
+    const int* __restrict__ list_count, const int* __restrict__ vis_idx, const float* __restrict__ uv_v,
+    const float* __restrict__ opa_v, float* __restrict__ uv_l, float* __restrict__ xyz_cam_l,
+    float* __restrict__ conic_l, float* __restrict__ packed_l) {
+    constexpr int SHW = 3 * (N_SH - 1);
+    const int l = blockIdx.x * PP_BLOCK + threadIdx.x;
+    if (l >= *list_count) return;
+    const int v = list[l];
+    const int g = vis_idx[v];
+    const float p[3] = {xyz[g * 3 + 0], xyz[g * 3 + 1], xyz[g * 3 + 2]};
+    float c[3];
+    to_camera(M, p[0], p[1], p[2], c);
+    const float uv[2] = {uv_v[v * 2 + 0], uv_v[v * 2 + 1]};   // == K c / z + c0 of k_band_project (same expression)
+    uv_l[l * 2 + 0] = uv[0];
+    uv_l[l * 2 + 1] = uv[1];
+    xyz_cam_l[l * 3 + 0] = c[0];
+    xyz_cam_l[l * 3 + 1] = c[1];
+    xyz_cam_l[l * 3 + 2] = c[2];
+    const float q4[4] = {quat[g * 4 + 0], quat[g * 4 + 1], quat[g * 4 + 2], quat[g * 4 + 3]};
+    const float s3[3] = {scale[g * 3 + 0], scale[g * 3 + 1], scale[g * 3 + 2]};
+    float S9[9], W[9], J6[6], c3[3];
+    sigma_world_of(q4, s3, S9);
+    load_rotation(M, W);
+    J6[0] = K[0] / c[2];                       // projection.cu:169-174
+    J6[1] = 0;
+    J6[2] = -K[0] * c[0] / (c[2] * c[2]);
+    J6[3] = 0;
+    J6[4] = K[4] / c[2];
+    J6[5] = -K[4] * c[1] / (c[2] * c[2]);
+    conic_of(J6, W, S9, c3);
+    conic_l[l * 3 + 0] = c3[0];
+    conic_l[l * 3 + 1] = c3[1];
+    conic_l[l * 3 + 2] = c3[2];
+    float col[3];
+    if constexpr (N_SH == 1) {
+        col[0] = rgb[g * 3 + 0]; col[1] = rgb[g * 3 + 1]; col[2] = rgb[g * 3 + 2];
+    } else {
+        float Y[N_SH];
+        float d[3] = {p[0] - center[0], p[1] - center[1], p[2] - center[2]};
+        const float r = 1.0f / __builtin_sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        d[0] *= r; d[1] *= r; d[2] *= r;
+        sh_basis<float, N_SH>(d, Y);
+        const float* shg = sh + (size_t)g * SHW;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            float t = 0;
+            t += Y[0] * rgb[g * 3 + ch];
+#pragma unroll
+            for (int s2 = 1; s2 < N_SH; s2++) t += Y[s2] * shg[(N_SH - 1) * ch + (s2 - 1)];
+            t *= GS_R_SH_0;
+            col[ch] = t;
+        }
+    }
+    float pk[GS_PACKED_WIDTH];
+    pack_record<float>(uv[0], uv[1], c3, opa_v[v], col, pk);
+    float4* dst = reinterpret_cast<float4*>(packed_l + (size_t)l * GS_PACKED_WIDTH);
+    dst[0] = make_float4(pk[0], pk[1], pk[2], pk[3]);
+    dst[1] = make_float4(pk[4], pk[5], pk[6], pk[7]);
+    dst[2] = make_float4(pk[8], pk[9], pk[10], pk[11]);
+}
+
 struct PreGrad {
     float* xyz;         // [N,3]
     float* quaternion;  // [N,4]
@@ -480,6 +652,49 @@ int gs_preprocess_forward(const void* xyz, const void* quaternion, const void* s
                               (const float*)camera_center, N, fr, block_offsets, o, band)));
     }
     return check_launch("preprocess_forward");
+}
+
+
+int gs_band_project(const void* xyz, const void* scale, const void* opacity, const void* camera_T_world, const void* K,
+                    int N, int W, int H, float near_thresh, float far_thresh, float cull_mask_padding, float mh_dist,
+                    const int32_t* band_rows, int G, int32_t* workspace, void* camera_center, int32_t* visible_count,
+                    uint8_t* culling_mask, int32_t* rank, int32_t* vis_idx, void* uv, void* opacity_act, uint32_t* mask,
+                    int32_t* halo_workspace, void* stream) {
+    GS_REQUIRE(G >= 1 && G <= GS_MAX_RANKS, "band_project: 1 <= G <= %d", GS_MAX_RANKS);
+    hipStream_t s = (hipStream_t)stream;
+    const Frustum fr = make_frustum(W, H, near_thresh, far_thresh, cull_mask_padding);
+    const int nb = div_up(N > 0 ? N : 1, PP_BLOCK);
+    int* block_counts = workspace;
+    int* block_offsets = workspace + nb;
+    k_cull_count<<<nb, PP_BLOCK, 0, s>>>((const float*)xyz, (const float*)camera_T_world, (const float*)K, N, fr,
+                                         block_counts, (float*)camera_center);
+    k_scan_counts<<<1, 1024, 0, s>>>(block_counts, nb, block_offsets, visible_count);
+    BandRows rows;
+    for (int i = 0; i <= GS_MAX_RANKS; i++) rows.v[i] = i <= G ? band_rows[i] : 0;
+    const int nty = (H + GS_TILE - 1) / GS_TILE;
+    k_band_project<1><<<nb, PP_BLOCK, 0, s>>>((const float*)xyz, (const float*)scale, (const float*)opacity,
+                                              (const float*)camera_T_world, (const float*)K, N, fr, mh_dist, nty, rows, G,
+                                              block_offsets, culling_mask, rank, vis_idx, (float*)uv, (float*)opacity_act,
+                                              mask, nullptr, nb);
+    // per-block bit counts by visible index: the first block of gs_halo_workspace_ints' layout
+    k_band_bit_counts<<<nb, PP_BLOCK, 0, s>>>(mask, visible_count, G, halo_workspace, nb);
+    return check_launch("band_project");
+}
+
+int gs_preprocess_forward_list(const void* xyz, const void* quaternion, const void* scale, const void* rgb, const void* sh,
+                               int n_sh, const void* camera_T_world, const void* K, const void* camera_center,
+                               const int32_t* list, const int32_t* list_count, int capacity, const int32_t* vis_idx,
+                               const void* uv, const void* opacity_act, void* uv_l, void* xyz_camera_frame_l, void* conic_l,
+                               void* packed_l, void* stream) {
+    GS_REQUIRE(n_sh == 1 || sh != nullptr, "sh must be given when n_sh > 1");
+    if (capacity <= 0) return GS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_SH(n_sh, (k_preprocess_list<N_SH><<<div_up(capacity, PP_BLOCK), PP_BLOCK, 0, s>>>(
+                          (const float*)xyz, (const float*)quaternion, (const float*)scale, (const float*)rgb,
+                          (const float*)sh, (const float*)camera_T_world, (const float*)K, (const float*)camera_center, list,
+                          list_count, vis_idx, (const float*)uv, (const float*)opacity_act, (float*)uv_l,
+                          (float*)xyz_camera_frame_l, (float*)conic_l, (float*)packed_l)));
+    return check_launch("preprocess_forward_list");
 }
 
 int gs_preprocess_backward(const void* xyz, const void* quaternion, const void* scale, int n_sh,

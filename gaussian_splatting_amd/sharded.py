@@ -37,6 +37,9 @@ DEFER_HOST_READ = True    # owner fused path: enqueue the render before waiting 
 # owner mode, fused path, equal bands: the frame's orchestration in C++ (csrc/frame_hip.cpp: sharded_rasterize --
 # the same two autograd nodes, the same C-ABI calls, the collectives through c10d); False keeps it in Python
 NATIVE = True
+# native path: evaluate the per-Gaussian stage in full only for the Gaussians that can reach the rank's band, into
+# arrays compacted to those rows (csrc/preprocess.hip "band-compact"); False: every visible Gaussian, as on one GPU
+BAND_COMPACT = True
 OWNER_BLOCK = 256   # owner slices are whole blocks of the per-Gaussian kernels (csrc/halo.hip)
 SLAB_WIDTH = 9      # rgb 3 | opacity 1 | uv 2 | conic 3
 
@@ -649,6 +652,7 @@ class ShardedRasterizer:
                 g = gaussians
                 nat.set_modes(bool(fused.SORT_PREFIX), bool(fused.EARLY_RENDER))
                 nat.set_segments(0 if fused.SEGMENTS == "auto" else (1 if fused.SEGMENTS else -1))
+                nat.set_band_compact(bool(BAND_COMPACT))
                 group = None
                 if self.all_to_all is None:
                     group = self.group if self.group is not None else dist.group.WORLD

@@ -326,6 +326,34 @@ int gs_halo_gather_sum(const uint32_t* mask, const int32_t* workspace, int N, in
                        int v_lo, int v_hi, const void* recv, const int32_t* recv_offsets,
                        void* out, void* stream);
 
+/* ---- multi-GPU: band-compact per-Gaussian stage (ABI 5; no reference counterpart) -------------------------
+ * A rank evaluates the per-Gaussian stage in full only for the Gaussians that can reach its band, into arrays
+ * compacted to those rows.
+ * gs_band_project: for every Gaussian the transform, projection and frustum cull of gs_preprocess_forward (same
+ *   culling_mask, rank, vis_idx, uv[V,2], opacity_act[V], visible_count, camera_center, workspace), plus mask[V]:
+ *   bit s = the Gaussian can reach the tile rows [band_rows[s], band_rows[s+1]) -- its candidate window
+ *   (tile_culling.cu:138-156) bounded from the largest scale, a superset of the exact window that needs no
+ *   covariance and is the same on every rank.  halo_workspace: int32[gs_halo_workspace_ints(N, G)].
+ * gs_halo_plan_masked: gs_halo_plan's send list, split sizes and gather layout from those masks.
+ * gs_preprocess_forward_list: rows l < *list_count of `list` (visible indices, ascending: the send list): Sigma, J,
+ *   conic, SH colour and the packed record of Gaussian vis_idx[list[l]], written at row l of uv_l[.,2],
+ *   xyz_camera_frame_l[.,3], conic_l[.,3], packed_l[.,12] (capacity rows allocated).  Bit-identical to the rows
+ *   gs_preprocess_forward writes.  Binning, sort and render take the compact arrays (visible_count = list_count);
+ *   the render-gradient slab [rows, 9] of the band is then the send buffer of the gradient exchange. */
+int gs_band_project(const void* xyz, const void* scale, const void* opacity, const void* camera_T_world, const void* K,
+                    int N, int W, int H, float near_thresh, float far_thresh, float cull_mask_padding, float mh_dist,
+                    const int32_t* band_rows, int G, int32_t* workspace, void* camera_center, int32_t* visible_count,
+                    uint8_t* culling_mask, int32_t* rank, int32_t* vis_idx, void* uv, void* opacity_act, uint32_t* mask,
+                    int32_t* halo_workspace, void* stream);
+int gs_halo_plan_masked(const uint32_t* mask, int N, const int32_t* visible_count,
+                        const int32_t* preprocess_workspace, const int32_t* owner_blocks, int G, int rank,
+                        int32_t* workspace, int32_t* send_index, int32_t* plan, void* stream);
+int gs_preprocess_forward_list(const void* xyz, const void* quaternion, const void* scale, const void* rgb, const void* sh,
+                               int n_sh, const void* camera_T_world, const void* K, const void* camera_center,
+                               const int32_t* list, const int32_t* list_count, int capacity, const int32_t* vis_idx,
+                               const void* uv, const void* opacity_act, void* uv_l, void* xyz_camera_frame_l, void* conic_l,
+                               void* packed_l, void* stream);
+
 /* ---- training-loop operations behind the rasterizer ------------------------------
  * gs_adam_step: torch.optim.Adam.step() as the reference uses it (splat_py/optimizer_manager.py:15-42
  * builds the optimizer with one group per parameter tensor and a learning rate each; trainer.py:376

@@ -20,9 +20,11 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--grad-mode", default="replicated", choices=["replicated", "owner"],
                 help="owner: the sparse-exchange path with the all_to_all replaced by a local fill (compute only)")
 ap.add_argument("--native", type=int, default=1, help="0: the Python orchestration of the sharded frame")
+ap.add_argument("--compact", type=int, default=1, help="0: replicated per-Gaussian stage (native path)")
 a = ap.parse_args()
 from gaussian_splatting_amd import sharded as _sh
 _sh.NATIVE = bool(a.native)
+_sh.BAND_COMPACT = bool(a.compact)
 N, W, H, deg = WORKLOADS[a.workload]
 g, cam, T = make_scene(N, W, H, deg, seed=0, device="cuda")
 params = [p for p in (g.xyz, g.rgb, g.opacity, g.scale, g.quaternion, g.sh) if p is not None]
@@ -70,5 +72,5 @@ for _ in range(a.steps):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / a.steps * 1e3
 t = _hip.collect_timing()
-print(f"world {a.world} rank {a.rank} rows {rows}: {ms:.3f} ms/step",
+print(f"world {a.world} rank {a.rank} rows {rows} native {a.native} compact {a.compact}: {ms:.3f} ms/step",
       {k: round(sum(v) / len(v), 4) for k, v in sorted(t.items())}, moved)

@@ -16,9 +16,11 @@ ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--defer", type=int, default=0)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--native", type=int, default=1, help="0: the Python orchestration of the sharded frame")
+ap.add_argument("--compact", type=int, default=1, help="0: replicated per-Gaussian stage (native path)")
 a = ap.parse_args()
 sharded.DEFER_HOST_READ = bool(a.defer)
 sharded.NATIVE = bool(a.native)
+sharded.BAND_COMPACT = bool(a.compact)
 N, W, H, deg = WORKLOADS["D"]
 g, cam, T = make_scene(N, W, H, deg, seed=0, device="cuda")
 gi = make_grad_image(W, H, seed=1, device="cuda")
@@ -66,7 +68,7 @@ t_all = time.perf_counter()
 for _ in range(a.steps):
     step()
 torch.cuda.synchronize()
-print(f"native={a.native} defer={a.defer} world={a.world}: {(time.perf_counter() - t_all) / a.steps * 1e3:.3f} ms/step")
+print(f"native={a.native} compact={a.compact} defer={a.defer} world={a.world}: {(time.perf_counter() - t_all) / a.steps * 1e3:.3f} ms/step")
 marks.clear()
 torch.cuda.synchronize()
 t0 = time.perf_counter()

@@ -78,18 +78,19 @@ def test_halo_plan_matches_reference_and_oracle(G):
                                                       (3, 3, 20000, 640, 472, 2.0, "cost-ffb"),
                                                       # a loss term directly on the returned uv, next to the image loss
                                                       (2, 3, 20000, 640, 472, 2.0, "equal-uvloss")])
-@pytest.mark.parametrize("native", [True, False])
+@pytest.mark.parametrize("native", ["native+compact", "native", "python"])
 def test_owner_mode_with_simulated_ranks(G, deg, N, W, H, near, policy, native):
-    """native: the frame's orchestration in C++ (csrc/frame_hip.cpp sharded_rasterize; equal bands) or in Python"""
+    """native: the frame's orchestration in C++ (csrc/frame_hip.cpp sharded_rasterize; equal bands) -- with the
+    band-compact per-Gaussian stage or with the replicated one -- or in Python"""
     from gaussian_splatting_amd import sharded
-    if native and not policy.startswith("equal"):
+    if native != "python" and not policy.startswith("equal"):
         pytest.skip("the native orchestration covers the equal-band policy")
-    prev = sharded.NATIVE
-    sharded.NATIVE = native
+    prev = sharded.NATIVE, sharded.BAND_COMPACT
+    sharded.NATIVE, sharded.BAND_COMPACT = native != "python", native == "native+compact"
     try:
         _owner_mode_with_simulated_ranks(G, deg, N, W, H, near, policy)
     finally:
-        sharded.NATIVE = prev
+        sharded.NATIVE, sharded.BAND_COMPACT = prev
 
 
 def _owner_mode_with_simulated_ranks(G, deg, N, W, H, near, policy):
