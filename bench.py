@@ -300,6 +300,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # first contact with RCCL: every rank proves that the collective layer sees the whole job before anything
+        # is timed -- an all-reduce of ones must give the world size, an all-gather of the ranks 0..world-1 in order
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)
+        seen = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(seen, torch.tensor([rank], dtype=torch.int64, device=dev))
+        ok = int(probe.item()) == world and seen.tolist() == list(range(world)) and dist.get_world_size() == world
+        print(f"[bench] rank {rank}/{world} on {torch.cuda.get_device_name(dev)} (local {local_rank}): RCCL world size "
+              f"{dist.get_world_size()}, all-reduce of ones = {int(probe.item())}, ranks seen {seen.tolist()}",
+              file=sys.stderr, flush=True)
+        if not ok:
+            raise SystemExit(f"rank {rank}: RCCL does not see a world of {world} ranks -- refusing to time anything")
 
     from gaussian_splatting_amd import _hip
     from gaussian_splatting_amd.synthetic import DEFAULTS, WORKLOADS, make_grad_image, make_scene
@@ -489,7 +501,8 @@ def main():
     # runs and corrected for gfx950: scripts/pmc_passes.sh, scripts/make_traffic_json.py) -- a committed
     # profile of this workload, NOT measured by this run: tagged with its source
     traffic, traffic_source = {}, None
-    for rel in (f"profiles/r02/hbm_traffic_{args.workload}.json", f"profiles/r01_hbm_traffic_{args.workload}.json"):
+    for rel in (f"profiles/r03/hbm_traffic_{args.workload}.json", f"profiles/r02/hbm_traffic_{args.workload}.json",
+                f"profiles/r01_hbm_traffic_{args.workload}.json"):
         tpath = os.path.join(ROOT, rel)
         if world == 1 and path == "fused" and os.path.exists(tpath):
             traffic = {k: v["hbm_bytes"] for k, v in json.load(open(tpath))["entries"].items()}
@@ -527,6 +540,11 @@ def main():
     if world == 1 and not args.force_sharded and path == "fused":
         for name in [w for w in args.also.split(",") if w and w != args.workload]:
             other[name] = _time_workload(name, fused_mod, dev, steps=max(5, args.steps), warmup=max(3, args.warmup))
+        if args.also:
+            try:
+                other["secondary_paths_B"] = _time_secondary(dev)
+            except Exception as e:   # noqa: BLE001 -- secondary numbers must not cost the headline line
+                other["secondary_paths_B"] = {"error": str(e)[:200]}
 
     train_ops = None
     if args.train_ops and rank == 0 and world == 1:
@@ -630,15 +648,17 @@ def valu_roofline(entry, launch_ms, workload):
     """VALU issue view of the dominant kernel: wave-instructions from the committed PMC pass (source tagged)
     over the launch time measured by THIS run, against the plain-fp32 issue peak of the chip
     (256 CUs x 4 SIMDs x one wave-instruction per 2 cycles at 2.4 GHz; profiles/r02/ubench_valu_rate.txt)."""
-    src = os.path.join(ROOT, "profiles", "r02", f"valu_insts_{workload}.json")
-    if not os.path.exists(src):
+    rnd = next((r for r in ("r03", "r02") if os.path.exists(os.path.join(ROOT, "profiles", r, f"valu_insts_{workload}.json"))),
+               None)
+    if rnd is None:
         return None
+    src = os.path.join(ROOT, "profiles", rnd, f"valu_insts_{workload}.json")
     insts = json.load(open(src)).get(ENTRY_ALIAS.get(entry, entry))
     if not insts:
         return None
     peak = 1024 * 2.4e9 / 2
     rate = insts / (launch_ms * 1e-3)
-    return {"wave_instructions_per_launch": int(insts), "source": f"profiles/r02/valu_insts_{workload}.json",
+    return {"wave_instructions_per_launch": int(insts), "source": f"profiles/{rnd}/valu_insts_{workload}.json",
             "achieved_per_s": round(rate, 1), "peak_per_s": peak, "frac": round(rate / peak, 4),
             "note": "half- and quarter-rate instructions (DPP, v_cndmask, v_ldexp, fp64, v_rcp) count as one"}
 
@@ -1011,6 +1031,48 @@ def _time_workload(name, fused_mod, dev, steps, warmup, spinup=20):
     return {"workload": f"{name}: {N} Gaussians, {W}x{H}, SH degree {deg}, seed 0", "N": N, "V": V, "S": S, "P": P,
             "ms_per_step": round(ms, 4), "value": round(P / (ms * 1e-3) / 1e6, 3), "unit": "Mpixels/s", "steps": steps,
             "warmup": warmup, "spinup": spinup, "roofline": roofline}
+
+
+def _time_secondary(dev, steps=10):
+    """SURVEY.md 8(f2)/(f3), workload B through the reference-shaped API (never part of the headline value): the
+    depth renderer (splat_py.depth.render_depth, forward only) and the per-pixel-SH colour mode
+    (rasterize(use_sh_precompute=False): N_SH = 16 render kernels, forward + backward).  Wall ms per call between
+    device synchronisations, whole host pipeline of that API included."""
+    from gaussian_splatting_amd.splat_py.depth import render_depth
+    from gaussian_splatting_amd.splat_py.rasterize import rasterize
+    from gaussian_splatting_amd.synthetic import DEFAULTS, WORKLOADS, make_grad_image, make_scene
+    N, W, H, deg = WORKLOADS["B"]
+    g, cam, T = make_scene(N, W, H, deg, seed=0, device=dev)
+    gi = make_grad_image(W, H, seed=1, device=dev)
+    bg = torch.zeros(3, device=dev)
+    params = [p for p in (g.xyz, g.rgb, g.opacity, g.scale, g.quaternion, g.sh) if p is not None]
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    out = {"workload": f"B: {N} Gaussians, {W}x{H}, SH degree {deg}, seed 0", "steps": steps}
+    out["depth_forward_ms"] = round(timed(lambda: render_depth(g, 0.5, T, cam, DEFAULTS["near_thresh"],
+                                                              DEFAULTS["cull_mask_padding"], DEFAULTS["mh_dist"])), 4)
+    for p in params:
+        p.requires_grad_(True)
+
+    def per_pixel_sh():
+        for p in params:
+            p.grad = None
+        image, _, _ = rasterize(g, T, cam, use_sh_precompute=False, background_rgb=bg, **DEFAULTS)
+        image.backward(gi)
+
+    out["per_pixel_sh_forward_backward_ms"] = round(timed(per_pixel_sh), 4)
+    del g, params
+    torch.cuda.empty_cache()
+    return out
 
 
 def _count_instances(g, T, cam, defaults, dev):

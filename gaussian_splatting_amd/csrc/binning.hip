@@ -306,11 +306,12 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_count(const float* __restric
 #ifndef GS_CS_TILES
 #define GS_CS_TILES 64   // 68 workgroups at workload D; 32 or 16 tiles per workgroup (more, narrower ones) are no faster
 #endif
-constexpr int CS_TILES = GS_CS_TILES;
-constexpr int CS_SEGS = 1024 / CS_TILES;
-constexpr int CS_ROWS = PRIV_NB / CS_SEGS;
-__global__ __launch_bounds__(CS_TILES * CS_SEGS) void k_bin_colscan(int* __restrict__ hist, int T,
-                                                                   int* __restrict__ counts) {
+// CS_TILES tiles x (1024 / CS_TILES) row segments per workgroup.  The narrow form (16 tiles) is for a multi-GPU
+// rank's band: ~570 tiles are 9 workgroups of 64 tiles -- 12 us of a 0.5 ms frame -- but 36 of 16
+template <int CS_TILES>
+__global__ __launch_bounds__(1024) void k_bin_colscan(int* __restrict__ hist, int T, int* __restrict__ counts) {
+    constexpr int CS_SEGS = 1024 / CS_TILES;
+    constexpr int CS_ROWS = PRIV_NB / CS_SEGS;
     __shared__ int s_seg[CS_SEGS][CS_TILES];
     const int lt = threadIdx.x & (CS_TILES - 1);
     const int seg = threadIdx.x / CS_TILES;
@@ -985,7 +986,8 @@ int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visi
         k_bin_count<<<PRIV_NB, PRIV_BLOCK, sizeof(int) * (size_t)Tb, s>>>(
             (const float*)uvs, (const float*)conic, V, n_tiles_x, n_tiles_y, mh_dist, tile_row0,
             tile_row1, hist, items);
-        k_bin_colscan<<<div_up(Tb, CS_TILES), CS_TILES * CS_SEGS, 0, s>>>(hist, Tb, counts + t0);
+        if (Tb >= 2048) k_bin_colscan<GS_CS_TILES><<<div_up(Tb, GS_CS_TILES), 1024, 0, s>>>(hist, Tb, counts + t0);
+        else k_bin_colscan<16><<<div_up(Tb, 16), 1024, 0, s>>>(hist, Tb, counts + t0);
     } else {
         if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)T, s) != hipSuccess) {
             gs::set_error("tile_count: memset failed");

@@ -18,11 +18,11 @@ for name in ("pass3.txt", "pass4.txt"):
             vals.setdefault(k, {})[m.group(2)] = float(m.group(3))
 ENTRY = {
     "gs_render_tiles_backward_slab": ["gs::k_render_bwd<float, 1>", "gs::k_tile_order"],
-    "gs_render_tiles_prefix": ["gs::k_render_fwd<float, 1>", "gs::k_render_fwd_flagged", "gs::k_tile_sort_flagged<8192>",
-                               "gs::k_tile_sort_flagged<4096>"],
+    "gs_render_tiles_prefix": ["gs::k_render_fwd<float, 1>", "gs::k_render_fwd_flagged", "gs::k_render_fwd_flagged<false>",
+                               "gs::k_tile_sort_flagged<8192>", "gs::k_tile_sort_flagged<4096>"],
     "gs_preprocess_forward": ["gs::k_preprocess<16, false>", "gs::k_cull_count", "gs::k_scan_counts"],
     "gs_preprocess_backward": ["gs::k_preprocess_bwd<16>"],
-    "gs_tile_count": ["gs::k_bin_count", "gs::k_bin_colscan", "gs::k_scan_tiles"],
+    "gs_tile_count": ["gs::k_bin_count", "gs::k_bin_colscan", "gs::k_bin_colscan<64>", "gs::k_scan_tiles"],
     "gs_tile_emit_sort": ["gs::k_bin_emit", "gs::k_tile_sort<true>", "gs::k_tile_sort_big<true>"],
 }
 res = {"workload": workload, "source": pmc_dir, "note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024",

@@ -7,7 +7,7 @@ OUT=$R/${2:-gpurun_out/pmc_$WL}
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline"
+CMD="python $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --also="
 i=0
 for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \

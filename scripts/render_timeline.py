@@ -76,9 +76,13 @@ def main():
     ap.add_argument("--workload", default="D")
     ap.add_argument("--out", default="")
     ap.add_argument("--dump", default="", help="npy file for the raw records")
+    ap.add_argument("--rows", type=int, nargs=2, default=None, help="tile rows [R0, R1): a multi-GPU rank's band")
+    ap.add_argument("--segments", default="auto", choices=["auto", "on", "off"], help="depth-segmented backward")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     fused.NATIVE = False   # the native frame module is linked against the product library
+    fused.SEGMENTS = {"auto": "auto", "on": True, "off": False}[args.segments]
+    rows = tuple(args.rows) if args.rows else None
     lib = _hip.lib()
     N, W, H, deg = WORKLOADS[args.workload]
     g, cam, T = make_scene(N, W, H, deg, seed=0, device=dev)
@@ -90,7 +94,7 @@ def main():
     buf = (ctypes.c_ulonglong * (2 * CAP * 10))()
 
     def frame():
-        img, _, _ = fused.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, **DEFAULTS)
+        img, _, _ = fused.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, tile_rows=rows, **DEFAULTS)
         img.backward(gi)
 
     for _ in range(3):
@@ -100,7 +104,8 @@ def main():
     _hip.check(lib.gs_debug_render_timeline(buf, CAP))
     rec = np.ctypeslib.as_array(buf).reshape(2, CAP, 10).copy()
     fwd, bwd = (r[r[:, 1] != 0] for r in rec)
-    out = {"workload": args.workload, "forward": analyse(fwd), "backward": analyse(bwd)}
+    out = {"workload": args.workload, "tile_rows": list(rows) if rows else None, "segments": args.segments,
+           "forward": analyse(fwd), "backward": analyse(bwd)}
     text = json.dumps(out, indent=1)
     print(text)
     if args.out:
