@@ -610,10 +610,20 @@ def main():
             line["train_ops"] = train_ops
         if train_loop is not None:
             line["train_loop"] = train_loop
-        print(json.dumps(line))
+    else:
+        line = None
     if sharded:
         dist.barrier()   # rank 0 does untimed extra work (instance count, JSON) before teardown
         dist.destroy_process_group()
+    if line is not None:
+        # RCCL writes its version banner to the C stdout buffer, which is flushed at exit (or at the teardown
+        # above): flush it now, so that the JSON line is the LAST thing on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 def check_sharded_frame(mode, step, info, g, cam, T, grad_image, bg, fused_mod, defaults, world, rank, dev):
