@@ -472,8 +472,13 @@ struct ShardSpec {
     py::object a2a_hook;                                // tests: stands in for all_to_all_single, no image gather
     int64_t band_pixel_rows = 0, padded_height = 0;
     ~ShardSpec() {   // the record may die on an autograd thread: Python references are dropped under the GIL
-        py::gil_scoped_acquire gil;
-        a2a_hook = py::object();
+        if (!a2a_hook.ptr()) return;
+        if (Py_IsInitialized()) {
+            py::gil_scoped_acquire gil;
+            a2a_hook = py::object();
+        } else {
+            a2a_hook.release();   // interpreter already gone: nothing to release the reference into
+        }
     }
 };
 struct FrameRec {

@@ -256,3 +256,47 @@ def test_owner_mode_single_rank_rccl():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("workload,G", [("D", 8), ("B", 4)])
+def test_band_project_masks_are_a_superset_of_the_exact_windows(workload, G):
+    """gs_band_project decides which bands a Gaussian CAN reach from its largest scale (no covariance); the exchange
+    and the band-compact evaluation are only correct if that is a superset of the exact candidate windows
+    (gs_halo_plan's masks, checked against the oracle above) -- at full size, every visible Gaussian.  Its other
+    outputs are the fused stage's: culling mask, rank, visible index, uv, sigmoid(opacity)."""
+    import ctypes
+    from gaussian_splatting_amd import _hip
+    from gaussian_splatting_amd.synthetic import DEFAULTS, WORKLOADS
+    N, W, H, deg = WORKLOADS[workload]
+    g, cam, T = make_scene(N, W, H, deg, seed=0, device=DEV)
+    d = DEFAULTS
+    nty = (H + 15) // 16
+    rows = _band_rows(nty, G)
+    me = G // 2
+    f = fused.preprocess_forward(g.xyz, g.quaternion, g.scale, g.opacity, g.rgb, g.sh, T, cam.K, W, H, d["near_thresh"],
+                                 d["far_thresh"], d["cull_mask_padding"], d["mh_dist"], (rows[me], rows[me + 1]), 0,
+                                 plan=lambda fr: enqueue_hip_plan(fr, G, me), plan_ints=plan_record_ints(G))
+    V = f.V
+    exact = f.halo_mask[:V].clone()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    i32 = dict(dtype=torch.int32, device=DEV)
+    ws = torch.empty(_hip.lib().gs_preprocess_workspace_ints(N), **i32)
+    hws = torch.empty(_hip.lib().gs_halo_workspace_ints(N, G), **i32)
+    center = torch.empty(4, device=DEV)
+    count = torch.empty(1, **i32)
+    culled = torch.empty(N, dtype=torch.uint8, device=DEV)
+    rank, vis_idx, mask = torch.empty(N, **i32), torch.empty(N, **i32), torch.zeros(N, **i32)
+    uv, opa = torch.empty(N, 2, device=DEV), torch.empty(N, device=DEV)
+    band_rows = (ctypes.c_int32 * (G + 1))(*rows)
+    cf = lambda x: ctypes.c_float(float(x))
+    _hip.call("gs_band_project", p(g.xyz), p(g.scale), p(g.opacity), p(T), p(cam.K), N, W, H, cf(d["near_thresh"]),
+              cf(d["far_thresh"]), cf(d["cull_mask_padding"]), cf(d["mh_dist"]), band_rows, G, p(ws), p(center), p(count),
+              p(culled), p(rank), p(vis_idx), p(uv), p(opa), p(mask), p(hws), _hip.current_stream())
+    assert int(count) == V
+    assert torch.equal(culled.bool(), f.culling_mask) and torch.equal(rank, f.rank) and torch.equal(vis_idx[:V], f.vis_idx[:V])
+    assert torch.equal(uv[:V], f.uv[:V]) and torch.equal(opa[:V], f.opacity_act[:V, 0])
+    bound = mask[:V]
+    assert bool(((exact & ~bound) == 0).all()), "a band the exact window reaches is missing from the bound"
+    n_exact = int(((exact >> me) & 1).sum())
+    n_bound = int(((bound >> me) & 1).sum())
+    assert n_exact <= n_bound <= 1.35 * n_exact + 64, (n_exact, n_bound)   # tight enough to be worth it
