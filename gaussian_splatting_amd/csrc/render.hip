@@ -467,8 +467,15 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int* __restrict__ cos
 // "Contributor" means: in the BACKWARD's arithmetic -- its alpha differs from the forward's in the last ulp
 // and the two can disagree at the 1/255 threshold; the forward evaluates the backward's form where they could
 // (see its visit), so the state it leaves describes exactly the walk the unsegmented kernel would do.
-constexpr int SEG_LEN = 128;   // entries per segment (a multiple of the 64-entry mask words)
-constexpr int SEG_MAX = 8;     // segments per tile; the last one is open-ended
+#ifndef GS_SEG_LEN
+#define GS_SEG_LEN 128
+#endif
+#ifndef GS_SEG_MAX
+#define GS_SEG_MAX 8
+#endif
+constexpr int SEG_LEN = GS_SEG_LEN;   // entries per segment (a multiple of the 64-entry mask words)
+constexpr int SEG_MAX = GS_SEG_MAX;   // segments per tile; the last one is open-ended
+static_assert(SEG_LEN % 64 == 0 && SEG_MAX >= 2, "segment geometry");
 struct SegState {              // views into the caller's workspace (gs_render_segment_workspace_bytes)
     int* kend;                 // [H W]
     float* oma_last;           // [H W]
