@@ -352,8 +352,12 @@ def main():
         stats = {}
         if sharded:
             from gaussian_splatting_amd.sharded import ShardedRasterizer, owned_slice
+            # "owner_python": the same frame and kernels with the Python orchestration of the exchange (tried only if
+            # the native C++ orchestration fails on this job's RCCL world)
+            native = None if grad_mode != "owner_python" else False
+            grad_mode = "owner" if grad_mode == "owner_python" else grad_mode
             rast = ShardedRasterizer(cam.height, world, rank, fused=(path == "fused"), grad_mode=grad_mode,
-                                     band_policy=args.bands)
+                                     band_policy=args.bands, native=native)
             if grad_mode == "owner":
                 # the replicated tensors carry the values, the owned slices receive the gradients
                 set_requires_grad(g, False)
@@ -452,11 +456,17 @@ def main():
         order = [args.grad_mode] + [m for m in ("owner", "replicated") if m != args.grad_mode]
         if args.single_mode:
             order = order[:1]
+        fallback = {"owner": "owner_python"}   # tried only when the mode before it failed
         ok_all = True
-        for mode in order:
+        queue, tried = list(order), []
+        while queue:
+            mode = queue.pop(0)
+            tried.append(mode)
             ok = torch.ones(1, device=dev)
             err = ""
             try:
+                if os.environ.get("GS_BENCH_INJECT_FAILURE") == mode:   # exercises the fallback order in tests
+                    raise RuntimeError(f"injected failure of mode {mode}")
                 step, info = make_mode(mode)
                 if sharded_check is None:
                     sharded_check = check_sharded_frame(mode, step, info, g, cam, poses[0], grad_image, bg, fused_mod,
@@ -474,7 +484,9 @@ def main():
                 modes.pop(mode, None)
                 modes[mode + "_error"] = err or "failed on another rank"
                 ok_all = False
-        head_mode = next((m for m in order if m in modes), None)
+                if mode in fallback:   # every rank takes this branch: `ok` was reduced over the job
+                    queue.insert(0, fallback[mode])
+        head_mode = next((m for m in tried if m in modes), None)
         if head_mode is None:
             raise SystemExit("no gradient mode of the sharded frame ran")
         run = modes[head_mode]
@@ -640,7 +652,7 @@ def check_sharded_frame(mode, step, info, g, cam, T, grad_image, bg, fused_mod, 
     ref_img.backward(grad_image)
     same = torch.tensor([1.0 if torch.equal(image, ref_img.detach()) else 0.0], device=dev)
     worst = torch.zeros(1, device=dev, dtype=torch.float64)
-    i0, i1 = (info["rast"].owned_range(g.xyz.shape[0]) if mode == "owner" else (0, g.xyz.shape[0]))
+    i0, i1 = (info["rast"].owned_range(g.xyz.shape[0]) if mode.startswith("owner") else (0, g.xyz.shape[0]))
     for k, v in got.items():
         ref = getattr(ref_g, k).grad[i0:i1].double()
         scale = getattr(ref_g, k).grad.abs().max().double().clamp(min=1e-300)

@@ -998,17 +998,28 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     constexpr int C = 3 * N_SH;
     constexpr int NV = C + 6;   // rgb coeffs, opacity, u, v, conic x3
     constexpr int REF_CH = ref_chunk<T>(N_SH);
-    // SLOTS: the fp32 one-coefficient kernel of the fused renderer.  Every wave owns a slot of nine sums
-    // per staged splat and writes it once (plain store after a full-wave reduction), the flush adds the
-    // slots of the waves that wrote -- no LDS atomics, no zero fill.  The other instantiations
-    // (per-pixel SH, fp64: tests and gradcheck) keep one shared accumulator row per splat.
-    constexpr bool SLOTS = fast && N_SH == 1;
+    // SLOTS: the fp32 kernels.  Every wave owns a slot of nine sums per staged splat and writes it once
+    // (plain store after a full-wave reduction), the flush adds the slots of the waves that wrote -- no LDS
+    // atomics, no zero fill.  The fp64 instantiations (gradcheck) keep one shared accumulator row per splat.
+    // SHMM: fp32 with per-pixel SH (render_backward.cu:422-488).  The gradient of coefficient (ch, s) of a
+    // splat is sum over pixels of Y_s(p) gi_ch(p) * aw(p): a contraction over the wave's 64 pixels whose left
+    // factor does not depend on the splat -- a GEMM [16 x 64] x [64 x 16 splats] per channel, done with
+    // v_mfma_f32_16x16x4_f32 (exact fp32) on batches of 16 contributing splats instead of 3 * N_SH cross-lane
+    // reductions per visit.  The slots then carry only the six geometric sums.
+    constexpr bool SLOTS = fast;
+    constexpr bool SHMM = fast && N_SH > 1;
+    constexpr int SV = 9;   // width of a slot: colour 3 (unused with SHMM) | w, w du, w dv | conic terms 3
     constexpr int RCHUNK = SLOTS ? GS_BWD_CHUNK : Chunk<T, N_SH>::value;
     constexpr int NWORD = RCHUNK / 64 > 0 ? RCHUNK / 64 : 1;
+    constexpr int MB = 16;        // splats per MFMA batch (the N of 16x16x4)
+    constexpr int BROW = 64 + 4;  // floats per row of the batch's aw matrix [slot][pixel] (16-byte aligned rows)
     __shared__ alignas(16) T s_geom[RCHUNK * GS_PACKED_WIDTH];
     __shared__ alignas(16) T s_col[N_SH > 1 ? RCHUNK * CW : 4];
     __shared__ int s_idx[RCHUNK];
-    __shared__ T s_acc[SLOTS ? 4 * RCHUNK * NV : RCHUNK * NV];   // SLOTS: [wave][splat][9]
+    __shared__ T s_acc[SLOTS ? 4 * RCHUNK * SV : RCHUNK * NV];   // SLOTS: [wave][splat][9]
+    __shared__ alignas(16) float s_B[SHMM ? 4 * MB * BROW : 4];  // SHMM: [wave][slot][pixel] aw of the open batch
+    __shared__ int s_bidx[SHMM ? 4 * MB : 1];                     // SHMM: [wave][slot] staged index of the splat
+    __shared__ float s_sh[SHMM ? RCHUNK * C : 1];                 // SHMM: [splat][ch][s] sums of the chunk
     __shared__ int s_max[4];
     __shared__ unsigned long long s_mask[4][NWORD];
     __shared__ unsigned long long s_hit[SLOTS ? 4 : 1][NWORD];   // SLOTS: slots written by each wave
@@ -1076,6 +1087,65 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     bool bg_init = false;
     const T bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
+    // SHMM: the A operands of the batch GEMM, constant over the walk.  The contraction index of MFMA step t,
+    // sub-index q (= lane >> 4) is pixel 16 q + t of the wave -- any bijection serves a sum -- so that lane
+    // 16 q + j finds its sixteen B values, aw of batch slot j at pixels 16 q .. 16 q + 15, contiguous:
+    //   a_op[ch][t] = Y_{lane & 15}(pixel 16 q + t) * grad_image_ch(pixel 16 q + t)      (rows s >= N_SH: 0)
+    float a_op[SHMM ? 3 : 1][SHMM ? 16 : 1];
+    int nb = 0;   // SHMM: filled slots of the wave's open batch (wave-uniform)
+    if constexpr (SHMM) {
+        float* tmp = s_B + wave * MB * BROW;   // [pixel][17]: 64 * 17 == MB * BROW floats of this wave
+        static_assert(64 * 17 <= MB * BROW, "transposition scratch");
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+#pragma unroll
+            for (int s2 = 0; s2 < 16; s2++) tmp[lane * 17 + s2] = s2 < N_SH ? float(Y[s2 < N_SH ? s2 : 0] * gi[ch]) : 0.0f;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int t = 0; t < 16; t++) a_op[ch][t] = tmp[(16 * (lane >> 4) + t) * 17 + (lane & 15)];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // SHMM: C[s][j] += sum_k A[s][k] B[k][j] for the nb splats of the open batch, added to the chunk's sums
+    auto mma_flush = [&](int n_filled) {
+        if constexpr (SHMM) {
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int j = lane & 15, q = lane >> 4;
+            const Vec4<float>* brow = reinterpret_cast<const Vec4<float>*>(s_B + (wave * MB + j) * BROW + 16 * q);
+            float b[16];
+#pragma unroll
+            for (int m4 = 0; m4 < 4; m4++) {
+                const Vec4<float> v4 = brow[m4];
+                b[4 * m4 + 0] = v4.x; b[4 * m4 + 1] = v4.y; b[4 * m4 + 2] = v4.z; b[4 * m4 + 3] = v4.w;
+            }
+            f32x4 acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                    acc[ch] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op[ch][t], b[t], acc[ch], 0, 0, 0);
+            }
+            // D: column j = lane & 15 (the batch slot), rows s = 4 q + r
+            if (j < n_filled) {
+                float* dst = s_sh + s_bidx[wave * MB + j] * C;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (4 * q + r < N_SH) lds_add(dst + N_SH * ch + 4 * q + r, acc[ch][r]);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+
     GS_STAT_DECL;
     GS_STAT(0, 1);          // waves
     GS_STAT(7, n_tile);
@@ -1126,6 +1196,8 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
         stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, s_idx, src_opacity, src_conic);
         if constexpr (!SLOTS)
             for (int k = tid; k < cnt * NV; k += RB) s_acc[k] = 0;
+        if constexpr (SHMM)
+            for (int k = tid; k < cnt * C; k += RB) s_sh[k] = 0;
         GS_PHASE(0);
         // (no barrier in between: thread t tests the record thread t staged)
         build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
@@ -1202,7 +1274,12 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                             if ((exact ? k : k % REF_CH) < nsp - 1) weight = weight * r1ma;   // Q1 (chunk-local index) unless exact
                             aw = alpha * weight;
                             // grad_alpha (render_backward.cu:196-203); the record's colour is Y0 * coefficient
-                            const T c0 = g2.y, c1 = g2.z, c2 = g2.w;
+                            T c0 = g2.y, c1 = g2.z, c2 = g2.w;
+                            if constexpr (SHMM) {   // colour at this pixel's view direction
+                                T col[3];
+                                splat_colour<T, N_SH>(s_geom, s_col, i, Y, col);
+                                c0 = col[0]; c1 = col[1]; c2 = col[2];
+                            }
                             const T ga = (c0 * weight - color_accum[0] * r1ma) * gi[0] +
                                          (c1 * weight - color_accum[1] * r1ma) * gi[1] +
                                          (c2 * weight - color_accum[2] * r1ma) * gi[2];
@@ -1227,8 +1304,17 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                 val[0] = awy * gi[0]; val[1] = awy * gi[1]; val[2] = awy * gi[2];
                 val[3] = w; val[4] = w * du; val[5] = w * dv;
                 val[6] = q0; val[7] = q1; val[8] = q2;
-                reduce9_to_slot(val, lane, slot_off, &s_acc[(wave * RCHUNK + i) * NV]);
+                reduce9_to_slot(val, lane, slot_off, &s_acc[(wave * RCHUNK + i) * SV]);
                 hit |= 1ull << bit;
+                if constexpr (SHMM) {
+                    // column nb of the batch's B: this splat's aw at the wave's 64 pixels (0 where it does not contribute)
+                    s_B[(wave * MB + nb) * BROW + lane] = aw;
+                    if (lane == 0) s_bidx[wave * MB + nb] = i;
+                    if (++nb == MB) {
+                        mma_flush(MB);
+                        nb = 0;
+                    }
+                }
                 continue;
             }
             T val[NV];
@@ -1320,6 +1406,12 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
           if constexpr (SLOTS)
               if (lane == 0) s_hit[wave][word] = hit;
         }
+        if constexpr (SHMM) {
+            if (nb > 0) {
+                mma_flush(nb);
+                nb = 0;
+            }
+        }
         GS_PHASE(2);
         __syncthreads();
         GS_PHASE(3);
@@ -1329,15 +1421,15 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
             // (deterministic per tile), apply the per-splat factors, and park the row in wave 0's slot of the
             // same splat (each thread only ever touches its own splat's slots: no barrier needed before).
             if (tid < cnt) {
-                T a[NV];
+                T a[SV];
 #pragma unroll
-                for (int j = 0; j < NV; j++) a[j] = 0;
+                for (int j = 0; j < SV; j++) a[j] = 0;
 #pragma unroll
                 for (int w4 = 0; w4 < 4; w4++) {
                     if ((s_hit[w4][tid >> 6] >> (tid & 63)) & 1ull) {
-                        const T* sl = s_acc + (w4 * RCHUNK + tid) * NV;
+                        const T* sl = s_acc + (w4 * RCHUNK + tid) * SV;
 #pragma unroll
-                        for (int j = 0; j < NV; j++) a[j] += sl[j];
+                        for (int j = 0; j < SV; j++) a[j] += sl[j];
                     }
                 }
                 // sums of (w, w du, w dv) and of the per-pixel conic terms -> gradients (see the loop)
@@ -1350,32 +1442,39 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                 a[6] *= k;
                 a[7] *= k;
                 a[8] *= k;
-                T* row = s_acc + tid * NV;
+                T* row = s_acc + tid * SV;
 #pragma unroll
-                for (int j = 0; j < NV; j++) row[j] = a[j];
+                for (int j = 0; j < SV; j++) row[j] = a[j];
             }
             __syncthreads();
             // Phase 2, nine lanes = one row: a wave's atomic instruction then covers seven whole 36-byte
             // rows with consecutive addresses, which the L2 handles per cache line -- 6x the rate of one
             // thread per row with nine instructions (scripts/ubench/atomic_rows.hip: 0.094 vs 0.557 ms for
             // the 1.25 M rows of a frame; the per-row form had become 0.17 ms of this kernel).
-            const int sub = lane / NV, col = lane - sub * NV;   // lane 63: idle
+            const int sub = lane / SV, col = lane - sub * SV;   // lane 63: idle
             for (int r0 = wave * 7; r0 < cnt; r0 += 28) {
                 const int r = r0 + sub;
-                const bool in = lane < 63 && r < cnt;
-                const T v = in ? s_acc[r * NV + col] : T(0);
+                const bool in = lane < 63 && r < cnt && !(SHMM && col < 3);   // SHMM: the colour columns are s_sh's
+                const T v = in ? s_acc[r * SV + col] : T(0);
                 const unsigned long long nz = ballot(v != T(0));
-                const bool any = in && ((nz >> (sub * NV)) & 0x1ffull) != 0;   // rows of zeros stay untouched
+                const bool any = in && ((nz >> (sub * SV)) & 0x1ffull) != 0;   // rows of zeros stay untouched
                 GS_STAT(11, __popcll(ballot(any && col == 0)));   // flushed rows
                 if (any) {
                     const int g = s_idx[r];
                     T* dst;
-                    if (slab) dst = g_rgb + (size_t)g * NV + col;   // [V, 9]: rgb 3 | opacity 1 | uv 2 | conic 3
+                    if (slab) dst = g_rgb + (size_t)g * SV + col;   // [V, 9]: rgb 3 | opacity 1 | uv 2 | conic 3
                     else if (col < 3) dst = g_rgb + (size_t)g * 3 + col;
                     else if (col == 3) dst = g_opa + g;
                     else if (col < 6) dst = g_uv + (size_t)g * 2 + (col - 4);
                     else dst = g_conic + (size_t)g * 3 + (col - 6);
                     global_add(dst, v);
+                }
+            }
+            if constexpr (SHMM) {
+                // the colour-coefficient rows of the chunk: consecutive lanes, consecutive addresses of a row
+                for (int k = tid; k < cnt * C; k += RB) {
+                    const float v = s_sh[k];
+                    if (v != 0.0f) global_add(g_rgb + (size_t)s_idx[k / C] * C + (k % C), v);
                 }
             }
         } else if (tid < cnt) {

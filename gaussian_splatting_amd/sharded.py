@@ -502,7 +502,7 @@ class ShardedRasterizer:
     TILE_COST = 64   # per-tile constant of the row cost (a tile with an empty list still costs a workgroup)
 
     def __init__(self, image_height, world_size=None, rank=None, group=None, fused=True, grad_mode="replicated",
-                 all_to_all=None, band_policy="equal", check_grad_image=False):
+                 all_to_all=None, band_policy="equal", check_grad_image=False, native=None):
         if grad_mode not in ("replicated", "owner"):
             raise ValueError("grad_mode must be 'replicated' or 'owner'")
         if band_policy not in ("equal", "cost"):
@@ -514,6 +514,7 @@ class ShardedRasterizer:
         self.grad_mode = grad_mode
         self.band_policy = band_policy
         self.check_grad_image = check_grad_image
+        self.native = native   # None: the module default NATIVE; False: this rasterizer keeps the Python orchestration
         self.all_to_all = all_to_all   # test hook: stands in for dist.all_to_all_single (and skips the image gather)
         self.n_tile_rows = (image_height + 15) // 16
         self.bounds = _band_rows(self.n_tile_rows, self.world_size)
@@ -647,7 +648,8 @@ class ShardedRasterizer:
             if owned is None:
                 raise ValueError("grad_mode 'owner' needs owned= (the parameter slices of this rank)")
             o = (owned.xyz, owned.quaternion, owned.scale, owned.opacity, owned.rgb, owned.sh)
-            nat = fused.native() if (use_fused and NATIVE and self.band_policy == "equal") else None
+            use_native = NATIVE if self.native is None else self.native
+            nat = fused.native() if (use_fused and use_native and self.band_policy == "equal") else None
             if nat is not None:
                 g = gaussians
                 nat.set_modes(bool(fused.SORT_PREFIX), bool(fused.EARLY_RENDER))
