@@ -205,12 +205,17 @@ __device__ inline void stage_chunk(const T* __restrict__ packed, const T* __rest
             dst[1] = src[1];
             dst[2] = src[2];
         }
-        if constexpr (N_SH > 1) {
-            const T* c = rgb + (size_t)g * 3 * N_SH;
-#pragma unroll
-            for (int k = 0; k < 3 * N_SH; k++) s_col[tid * CW + k] = c[k];
-        }
         if (s_idx) s_idx[tid] = g;
+    }
+    if constexpr (N_SH > 1) {
+        // the [3, N_SH] coefficient rows, by the whole workgroup: consecutive threads read consecutive words of
+        // a row (one thread per row with 3 N_SH dependent-latency loads was 0.2 ms of the 0.4 ms skeleton of the
+        // N_SH = 16 backward at workload B)
+        constexpr int C = 3 * N_SH;
+        for (int k = tid; k < count * C; k += RB) {
+            const int r = k / C, c = k - r * C;
+            s_col[r * CW + c] = rgb[(size_t)sorted[first + r] * C + c];
+        }
     }
 }
 
@@ -1018,8 +1023,8 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     __shared__ int s_idx[RCHUNK];
     __shared__ T s_acc[SLOTS ? 4 * RCHUNK * SV : RCHUNK * NV];   // SLOTS: [wave][splat][9]
     __shared__ alignas(16) float s_B[SHMM ? 4 * MB * BROW : 4];  // SHMM: [wave][slot][pixel] aw of the open batch
-    __shared__ int s_bidx[SHMM ? 4 * MB : 1];                     // SHMM: [wave][slot] staged index of the splat
-    __shared__ float s_sh[SHMM ? RCHUNK * C : 1];                 // SHMM: [splat][ch][s] sums of the chunk
+    __shared__ int s_bidx[SHMM ? 4 * MB : 1];                     // SHMM: [wave][slot] Gaussian index of the splat
+    __shared__ alignas(16) float s_gi[SHMM ? 4 * 3 * 64 : 4];    // SHMM: [wave][ch][pixel] grad_image
     __shared__ int s_max[4];
     __shared__ unsigned long long s_mask[4][NWORD];
     __shared__ unsigned long long s_hit[SLOTS ? 4 : 1][NWORD];   // SLOTS: slots written by each wave
@@ -1087,29 +1092,32 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     bool bg_init = false;
     const T bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
-    // SHMM: the A operands of the batch GEMM, constant over the walk.  The contraction index of MFMA step t,
-    // sub-index q (= lane >> 4) is pixel 16 q + t of the wave -- any bijection serves a sum -- so that lane
-    // 16 q + j finds its sixteen B values, aw of batch slot j at pixels 16 q .. 16 q + 15, contiguous:
-    //   a_op[ch][t] = Y_{lane & 15}(pixel 16 q + t) * grad_image_ch(pixel 16 q + t)      (rows s >= N_SH: 0)
-    float a_op[SHMM ? 3 : 1][SHMM ? 16 : 1];
+    // SHMM: the batch GEMM, per channel  D[s][j] = sum_k A[s][k] B[k][j]  with
+    //   A[s][k] = Y_s(pixel k)                  (constant over the walk: registers y_op)
+    //   B[k][j] = aw of batch slot j at pixel k * grad_image_ch(pixel k)
+    // The contraction index of MFMA step t, sub-index q (= lane >> 4) is pixel 16 q + t of the wave -- any bijection
+    // serves a sum -- so that lane 16 q + j finds its sixteen B values (slot j, pixels 16 q .. 16 q + 15) and its
+    // sixteen grad_image values contiguous in LDS:   y_op[t] = Y_{lane & 15}(pixel 16 q + t)   (rows s >= N_SH: 0)
+    float y_op[SHMM ? 16 : 1];
     int nb = 0;   // SHMM: filled slots of the wave's open batch (wave-uniform)
     if constexpr (SHMM) {
         float* tmp = s_B + wave * MB * BROW;   // [pixel][17]: 64 * 17 == MB * BROW floats of this wave
-        static_assert(64 * 17 <= MB * BROW, "transposition scratch");
+        static_assert(64 * 17 <= MB * BROW && MB * 48 <= MB * BROW, "scratch uses of the wave's B rows");
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
+        for (int s2 = 0; s2 < 16; s2++) tmp[lane * 17 + s2] = s2 < N_SH ? float(Y[s2 < N_SH ? s2 : 0]) : 0.0f;
 #pragma unroll
-            for (int s2 = 0; s2 < 16; s2++) tmp[lane * 17 + s2] = s2 < N_SH ? float(Y[s2 < N_SH ? s2 : 0] * gi[ch]) : 0.0f;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int ch = 0; ch < 3; ch++) s_gi[(wave * 3 + ch) * 64 + lane] = float(gi[ch]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-            for (int t = 0; t < 16; t++) a_op[ch][t] = tmp[(16 * (lane >> 4) + t) * 17 + (lane & 15)];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
+        for (int t = 0; t < 16; t++) y_op[t] = tmp[(16 * (lane >> 4) + t) * 17 + (lane & 15)];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
-    // SHMM: C[s][j] += sum_k A[s][k] B[k][j] for the nb splats of the open batch, added to the chunk's sums
+    // SHMM: the GEMM of the open batch; its results are the wave's complete sums for (tile patch, splat): they go
+    // straight to the global gradient rows (an LDS accumulator shared by the four waves needs 768 LDS float
+    // atomics per batch, which cost more than the MFMAs: 0.15 of 0.69 ms at workload B)
     auto mma_flush = [&](int n_filled) {
         if constexpr (SHMM) {
             typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1117,29 +1125,52 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const int j = lane & 15, q = lane >> 4;
-            const Vec4<float>* brow = reinterpret_cast<const Vec4<float>*>(s_B + (wave * MB + j) * BROW + 16 * q);
+            float* mine = s_B + wave * MB * BROW;
+            const Vec4<float>* brow = reinterpret_cast<const Vec4<float>*>(mine + j * BROW + 16 * q);
             float b[16];
 #pragma unroll
             for (int m4 = 0; m4 < 4; m4++) {
                 const Vec4<float> v4 = brow[m4];
                 b[4 * m4 + 0] = v4.x; b[4 * m4 + 1] = v4.y; b[4 * m4 + 2] = v4.z; b[4 * m4 + 3] = v4.w;
             }
-            f32x4 acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            f32x4 acc[3];
 #pragma unroll
-            for (int t = 0; t < 16; t++) {
+            for (int ch = 0; ch < 3; ch++) {
+                const Vec4<float>* grow = reinterpret_cast<const Vec4<float>*>(s_gi + (wave * 3 + ch) * 64 + 16 * q);
+                float g[16];
 #pragma unroll
-                for (int ch = 0; ch < 3; ch++)
-                    acc[ch] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op[ch][t], b[t], acc[ch], 0, 0, 0);
-            }
-            // D: column j = lane & 15 (the batch slot), rows s = 4 q + r
-            if (j < n_filled) {
-                float* dst = s_sh + s_bidx[wave * MB + j] * C;
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        if (4 * q + r < N_SH) lds_add(dst + N_SH * ch + 4 * q + r, acc[ch][r]);
+                for (int m4 = 0; m4 < 4; m4++) {
+                    const Vec4<float> v4 = grow[m4];
+                    g[4 * m4 + 0] = v4.x; g[4 * m4 + 1] = v4.y; g[4 * m4 + 2] = v4.z; g[4 * m4 + 3] = v4.w;
                 }
+                f32x4 even = {0, 0, 0, 0}, odd = {0, 0, 0, 0};   // two chains: the dependent-issue latency is 40 cycles
+#pragma unroll
+                for (int t = 0; t < 16; t += 2) {
+                    even = __builtin_amdgcn_mfma_f32_16x16x4f32(y_op[t], b[t] * g[t], even, 0, 0, 0);
+                    odd = __builtin_amdgcn_mfma_f32_16x16x4f32(y_op[t + 1], b[t + 1] * g[t + 1], odd, 0, 0, 0);
+                }
+                acc[ch] = even + odd;
+            }
+            // D: column j = lane & 15 (the batch slot), rows s = 4 q + r  ->  the wave's scratch as [slot][ch][16]
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // every lane has read its B values
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                Vec4<float> v4;
+                v4.x = acc[ch][0]; v4.y = acc[ch][1]; v4.z = acc[ch][2]; v4.w = acc[ch][3];
+                *reinterpret_cast<Vec4<float>*>(mine + j * 48 + ch * 16 + 4 * q) = v4;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // consecutive lanes, consecutive words of a gradient row
+            for (int k = lane; k < n_filled * 48; k += 64) {
+                const int row = k / 48, c = k - row * 48;
+                const int ch = c >> 4, s2 = c & 15;
+#ifdef GS_SHMM_NOFLUSH   // timing experiment
+                if (mine[k] != 12345.678f) continue;
+#endif
+                if (s2 < N_SH) global_add(g_rgb + (size_t)s_bidx[wave * MB + row] * C + ch * N_SH + s2, mine[k]);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1196,8 +1227,6 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
         stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, s_idx, src_opacity, src_conic);
         if constexpr (!SLOTS)
             for (int k = tid; k < cnt * NV; k += RB) s_acc[k] = 0;
-        if constexpr (SHMM)
-            for (int k = tid; k < cnt * C; k += RB) s_sh[k] = 0;
         GS_PHASE(0);
         // (no barrier in between: thread t tests the record thread t staged)
         build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
@@ -1275,11 +1304,13 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                             aw = alpha * weight;
                             // grad_alpha (render_backward.cu:196-203); the record's colour is Y0 * coefficient
                             T c0 = g2.y, c1 = g2.z, c2 = g2.w;
+#ifndef GS_SHMM_NOCOL   // timing experiment
                             if constexpr (SHMM) {   // colour at this pixel's view direction
                                 T col[3];
                                 splat_colour<T, N_SH>(s_geom, s_col, i, Y, col);
                                 c0 = col[0]; c1 = col[1]; c2 = col[2];
                             }
+#endif
                             const T ga = (c0 * weight - color_accum[0] * r1ma) * gi[0] +
                                          (c1 * weight - color_accum[1] * r1ma) * gi[1] +
                                          (c2 * weight - color_accum[2] * r1ma) * gi[2];
@@ -1309,7 +1340,10 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                 if constexpr (SHMM) {
                     // column nb of the batch's B: this splat's aw at the wave's 64 pixels (0 where it does not contribute)
                     s_B[(wave * MB + nb) * BROW + lane] = aw;
-                    if (lane == 0) s_bidx[wave * MB + nb] = i;
+                    if (lane == 0) s_bidx[wave * MB + nb] = s_idx[i];
+#ifdef GS_SHMM_NOMMA   // timing experiment
+                    if (nb == MB - 1) nb = 0;
+#endif
                     if (++nb == MB) {
                         mma_flush(MB);
                         nb = 0;
@@ -1454,7 +1488,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
             const int sub = lane / SV, col = lane - sub * SV;   // lane 63: idle
             for (int r0 = wave * 7; r0 < cnt; r0 += 28) {
                 const int r = r0 + sub;
-                const bool in = lane < 63 && r < cnt && !(SHMM && col < 3);   // SHMM: the colour columns are s_sh's
+                const bool in = lane < 63 && r < cnt && !(SHMM && col < 3);   // SHMM: the colour sums went out with the batches
                 const T v = in ? s_acc[r * SV + col] : T(0);
                 const unsigned long long nz = ballot(v != T(0));
                 const bool any = in && ((nz >> (sub * SV)) & 0x1ffull) != 0;   // rows of zeros stay untouched
@@ -1468,13 +1502,6 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                     else if (col < 6) dst = g_uv + (size_t)g * 2 + (col - 4);
                     else dst = g_conic + (size_t)g * 3 + (col - 6);
                     global_add(dst, v);
-                }
-            }
-            if constexpr (SHMM) {
-                // the colour-coefficient rows of the chunk: consecutive lanes, consecutive addresses of a row
-                for (int k = tid; k < cnt * C; k += RB) {
-                    const float v = s_sh[k];
-                    if (v != 0.0f) global_add(g_rgb + (size_t)s_idx[k / C] * C + (k % C), v);
                 }
             }
         } else if (tid < cnt) {
@@ -1509,7 +1536,10 @@ __global__ __launch_bounds__(RB) void k_render_depth(const float* __restrict__ p
                                                      const int* __restrict__ sorted, int W, int H,
                                                      int ntx, int nt, float alpha_threshold,
                                                      float* __restrict__ depth) {
-    constexpr int RCHUNK = 256;
+#ifndef GS_DEPTH_CHUNK
+#define GS_DEPTH_CHUNK 256
+#endif
+    constexpr int RCHUNK = GS_DEPTH_CHUNK;
     __shared__ alignas(16) float s_geom[RCHUNK * GS_PACKED_WIDTH];
     __shared__ int s_idx[RCHUNK];
     const int tile = tile_of_block(blockIdx.x, nt);
