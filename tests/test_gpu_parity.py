@@ -313,6 +313,31 @@ def test_render_per_pixel_sh_variants(hip_backend, n_sh):
         assert scaled_err(got[k], ref[k]) < GRAD_TOL, f"{k}: {scaled_err(got[k], ref[k])}"
 
 
+def test_render_per_pixel_sh_dense_lists(hip_backend):
+    """The fp32 per-pixel-SH backward forms the colour-coefficient gradients in batches of 16 contributing splats
+    per wave (a matrix-core contraction over the wave's 64 pixels): a scene with several chunks of 64 per tile and
+    several full batches per wave and chunk, partial tiles on the right and bottom edges, every element checked."""
+    orc = oracle()
+    W, H = 200, 136   # 13 x 9 tiles, the last column / row partial
+    d = cpu_stage_inputs(12000, W, H, 3, 91)
+    sorted_g, ranges = orc.get_sorted_gaussian_list(1024, d["uv"], d["xyz_c"], d["conic"], 13, 9, 3.0)
+    assert int((ranges[1:] - ranges[:-1]).max()) > 256
+    rays = compute_rays_in_world_frame(d["cam"], d["T"])
+    coeffs = d["sh_coeffs"].contiguous()
+    bg = torch.full((3,), 0.1)
+    gi = make_grad_image(W, H, seed=92)
+    ref = render_case(orc, "cpu", d, coeffs, rays, bg, sorted_g, ranges, torch.float32, gi)
+    got = render_case(hip_backend, DEV, d, coeffs, rays, bg, sorted_g, ranges, torch.float32, gi)
+    assert torch.equal(got["nsp"], ref["nsp"]) and torch.equal(got["image"], ref["image"])
+    for k in ("g_rgb", "g_opacity", "g_uv", "g_conic"):
+        assert scaled_err(got[k], ref[k]) < 1e-5, f"{k}: {scaled_err(got[k], ref[k])}"
+        assert rel_err(got[k], ref[k]) < GRAD_TOL, f"{k} elementwise: {rel_err(got[k], ref[k])}"
+    # rows of Gaussians no pixel used stay exactly zero (nothing is added for an all-zero batch column)
+    unused = torch.ones(coeffs.shape[0], dtype=torch.bool)
+    unused[sorted_g.long()] = False
+    assert not got["g_rgb"].cpu()[unused].any()
+
+
 @pytest.mark.parametrize("n_sh", [1, 16])
 def test_render_fp64_parity(hip_backend, n_sh):
     orc = oracle()
