@@ -1058,8 +1058,8 @@ def _time_workload(name, fused_mod, dev, steps, warmup, spinup=20):
 def _time_secondary(dev, steps=10):
     """SURVEY.md 8(f2)/(f3), workload B through the reference-shaped API (never part of the headline value): the
     depth renderer (splat_py.depth.render_depth, forward only) and the per-pixel-SH colour mode
-    (rasterize(use_sh_precompute=False): N_SH = 16 render kernels, forward + backward).  Wall ms per call between
-    device synchronisations, whole host pipeline of that API included."""
+    (rasterize(use_sh_precompute=False): N_SH = 16 render kernels, forward + backward) -- and that colour mode through
+    fused.rasterize.  Wall ms per call between device synchronisations, whole host pipeline of that API included."""
     from gaussian_splatting_amd.splat_py.depth import render_depth
     from gaussian_splatting_amd.splat_py.rasterize import rasterize
     from gaussian_splatting_amd.synthetic import DEFAULTS, WORKLOADS, make_grad_image, make_scene
@@ -1092,6 +1092,17 @@ def _time_secondary(dev, steps=10):
         image.backward(gi)
 
     out["per_pixel_sh_forward_backward_ms"] = round(timed(per_pixel_sh), 4)
+
+    from gaussian_splatting_amd import fused as fused_mod
+
+    def per_pixel_sh_fused():
+        for p in params:
+            p.grad = None
+        image, _, _ = fused_mod.rasterize(g, T, cam, use_sh_precompute=False, background_rgb=bg, **DEFAULTS)
+        image.backward(gi)
+
+    # the same colour mode on the fused frame's stages (same render kernels, without the six-node host glue)
+    out["per_pixel_sh_fused_forward_backward_ms"] = round(timed(per_pixel_sh_fused), 4)
     del g, params
     torch.cuda.empty_cache()
     return out

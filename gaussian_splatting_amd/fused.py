@@ -26,6 +26,7 @@ import torch
 from . import _hip
 from .splat_py import rasterize as _reference_shaped
 from .splat_py.structs import TILE_EDGE_LENGTH_PX
+from .splat_py.utils import compute_rays_in_world_frame
 
 
 def _p(t):
@@ -146,12 +147,12 @@ def counters():
 class _Arena:
     """one allocation cut into 1-D blocks of the given element counts, each starting 16-byte aligned"""
 
-    def __init__(self, dtype, device, sizes):
+    def __init__(self, dtype, device, sizes, zero=False):
         self.offsets, off = [], 0
         for n in sizes:
             self.offsets.append((off, n))
             off += (n + 3) & ~3
-        self.buf = torch.empty(off, dtype=dtype, device=device)
+        self.buf = (torch.zeros if zero else torch.empty)(off, dtype=dtype, device=device)
 
     def blocks(self):
         return [self.buf[o:o + n] for o, n in self.offsets]
@@ -479,6 +480,83 @@ class _Render(torch.autograd.Function):
         return (slab[:, SLAB_UV], slab[:, SLAB_CONIC], slab[:, SLAB_OPACITY], slab[:, SLAB_RGB]) + (None,) * 11
 
 
+class _GatherRows(torch.autograd.Function):
+    """rows `index` (unique, int64) of a dense parameter tensor; the gradient is an index_copy into zeros
+    (torch's own indexing backward sorts the indices to accumulate duplicates: there are none)"""
+
+    @staticmethod
+    def forward(ctx, dense, index):
+        ctx.save_for_backward(index)
+        ctx.shape = dense.shape
+        return dense.index_select(0, index)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (index,) = ctx.saved_tensors
+        return torch.zeros(ctx.shape, dtype=grad.dtype, device=grad.device).index_copy_(0, index, grad), None
+
+
+class _RenderSH(torch.autograd.Function):
+    """Per-pixel SH colour (rasterize.py:100-110 with use_sh_precompute=False; render.cu:283-333,
+    render_backward.cu:422-488): the N_SH in {4, 9, 16} render kernels on the fused frame's packed records and
+    tile lists.  coeffs: [V, 3, N_SH] colour coefficients of the visible Gaussians, rays: [H, W, 3]."""
+
+    @staticmethod
+    def forward(ctx, uv, conic, opacity, coeffs, packed, ranges, sorted_g, rays, background_rgb, height, width,
+                tile_rows):
+        dev = packed.device
+        nty = (height + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
+        row0, row1 = tile_rows if tile_rows is not None else (0, nty)
+        alloc = torch.empty if tile_rows is None else torch.zeros
+        P = height * width
+        buf = alloc(5 * P, dtype=torch.float32, device=dev)
+        image, fw = buf[:3 * P].view(height, width, 3), buf[3 * P:4 * P].view(height, width)
+        nsp = buf[4 * P:].view(torch.int32).view(height, width)
+        _hip.call("gs_render_tiles_packed", _p(packed), _p(coeffs), _p(rays), _p(ranges), _p(sorted_g),
+                  _p(background_rgb), width, height, int(coeffs.shape[2]), row0, row1, _p(nsp), _p(fw), _p(image),
+                  _hip.GS_F32, None, _stream())
+        ctx.save_for_backward(packed, coeffs, ranges, sorted_g, rays, background_rgb, nsp, fw)
+        ctx.set_materialize_grads(False)
+        ctx.dims = (height, width, row0, row1, uv.shape[0])
+        ctx.backward_mode = _hip.get_backward_mode()   # the frame's mode is the default at its forward
+        return image
+
+    @staticmethod
+    def backward(ctx, grad_image):
+        packed, coeffs, ranges, sorted_g, rays, background_rgb, nsp, fw = ctx.saved_tensors
+        height, width, row0, row1, V = ctx.dims
+        if grad_image is None:
+            return (None,) * 12
+        n_sh = int(coeffs.shape[2])
+        (gc, go, gu, gk) = _Arena(torch.float32, packed.device, (3 * n_sh * V, V, 2 * V, 3 * V), zero=True).blocks()
+        g_rgb, g_opa, g_uv, g_conic = gc.view(V, 3, n_sh), go.view(V, 1), gu.view(V, 2), gk.view(V, 3)
+        _hip.call("gs_render_tiles_backward_packed", _p(packed), _p(coeffs), _p(rays), _p(ranges), _p(sorted_g),
+                  _p(background_rgb), _p(nsp), _p(fw), _p(grad_image.contiguous()), width, height, n_sh, row0, row1,
+                  _p(g_rgb), _p(g_opa), _p(g_uv), _p(g_conic), _hip.GS_F32, int(ctx.backward_mode), _stream())
+        return (g_uv, g_conic, g_opa, g_rgb) + (None,) * 8
+
+
+def _rasterize_per_pixel_sh(g, camera_T_world, camera, near_thresh, far_thresh, cull_mask_padding, mh_dist,
+                            background_rgb, tile_rows):
+    """use_sh_precompute=False on the fused frame: its per-Gaussian stage, binning and full per-tile sort, the
+    colour coefficients of the visible Gaussians gathered once, and the per-pixel-SH render kernels.  Same
+    (image, culling_mask, uv) contract and the same kernels as the reference-shaped path of this colour mode
+    (which spends ~4 ms per frame of workload B in its host glue); against it the frame differs as the
+    precompute mode's does: by the fused per-Gaussian stage's explicit fp32 world->camera transform."""
+    out = _Preprocess.apply(
+        g.xyz.contiguous(), g.quaternion.contiguous(), g.scale.contiguous(), g.opacity.contiguous(),
+        g.rgb.contiguous(), None, camera_T_world.contiguous(), camera.K.contiguous(), int(camera.width),
+        int(camera.height), near_thresh, far_thresh, cull_mask_padding, mh_dist, tile_rows, 0, None)
+    uv, conic, opacity, _rgb_unused, packed, _xyz_cam, culling_mask, ranges, sorted_g, vis_idx = out[:10]
+    index = vis_idx.long()
+    # coefficient 0 is the rgb parameter (rasterize.py:103: cat of rgb and sh)
+    coeffs = torch.cat((_GatherRows.apply(g.rgb, index).unsqueeze(2), _GatherRows.apply(g.sh, index)), dim=2)
+    rays = compute_rays_in_world_frame(camera, camera_T_world)
+    image = _RenderSH.apply(uv, conic, opacity, coeffs.contiguous(), packed, ranges, sorted_g, rays,
+                            background_rgb.contiguous(), int(camera.height), int(camera.width), tile_rows)
+    return image, culling_mask, uv
+
+
 def _require(cond, msg):
     if not cond:
         raise RuntimeError(msg)
@@ -510,7 +588,7 @@ def supported(gaussians, camera_T_world, camera, use_sh_precompute):
     if not gaussians.xyz.is_cuda or gaussians.xyz.dtype != torch.float32:
         return False
     if gaussians.sh is not None and not use_sh_precompute:
-        return False   # per-pixel SH evaluation: reference-shaped path (N_SH in {4,9,16} render kernels)
+        return False   # per-pixel SH evaluation: not the two-node frame (rasterize() routes it, see there)
     return True
 
 
@@ -521,6 +599,14 @@ def rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_m
     called on the flat [9 V] render-gradient slab in the backward (grad_sync is the generic
     per-tensor form used by the reference-shaped path): the hooks gaussian_splatting_amd.sharded
     uses; all default to the single-GPU behaviour.  frame_hook(dict) receives the frame's tile ranges."""
+    hooks = return_aux or grad_sync or slab_sync or frame_hook
+    if (gaussians.sh is not None and not use_sh_precompute and not hooks and gaussians.xyz.is_cuda
+            and gaussians.xyz.dtype == torch.float32):
+        # per-pixel SH evaluation (N_SH in {4, 9, 16} render kernels) on the fused frame's stages: single-GPU frames;
+        # the multi-GPU hooks of this colour mode stay on the reference-shaped path
+        validate(gaussians, camera_T_world, camera, background_rgb)
+        return _rasterize_per_pixel_sh(gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_mask_padding,
+                                       mh_dist, background_rgb, tile_rows)
     if not supported(gaussians, camera_T_world, camera, use_sh_precompute):
         return _reference_shaped.rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh,
                                            cull_mask_padding, mh_dist, use_sh_precompute, background_rgb,

@@ -56,6 +56,16 @@ if "sh" in a.what:
 
     print("per-pixel SH forward+backward", timed(per_pixel_sh))
 
+    from gaussian_splatting_amd import fused
+
+    def per_pixel_sh_fused():
+        for p in params:
+            p.grad = None
+        image, _, _ = fused.rasterize(g, T, cam, use_sh_precompute=False, background_rgb=bg, **DEFAULTS)
+        image.backward(gi)
+
+    print("per-pixel SH forward+backward, fused frame", timed(per_pixel_sh_fused))
+
     def precomputed():
         for p in params:
             p.grad = None

@@ -130,6 +130,40 @@ def test_fused_matches_reference_shaped_path(hip_backend, N, W, H, deg, seed, bg
     assert max(errs.values()) < E2E_GRAD_TOL, errs
 
 
+@pytest.mark.parametrize("N,W,H,deg,seed,bgval", [(20000, 640, 472, 3, 1, 0.5), (6000, 328, 200, 1, 4, 0.0),
+                                                   (6000, 328, 200, 2, 5, 0.25)])
+def test_fused_per_pixel_sh_matches_reference_shaped_path(hip_backend, N, W, H, deg, seed, bgval):
+    """use_sh_precompute=False (rasterize.py:100-110; render.cu:283-333, render_backward.cu:422-488): the fused
+    frame's per-Gaussian stage / binning / sort with the N_SH = 4, 9, 16 render kernels against the six-node
+    path of the same colour mode -- same tolerances as the precompute mode's comparison above"""
+    bg = torch.full((3,), bgval, device=DEV)
+    gi = make_grad_image(W, H, seed=seed + 9, device=DEV)
+    outs = []
+    for fn in (rasterize_mirror, fused.rasterize):
+        g, cam, T = make_scene(N, W, H, deg, seed=seed, device=DEV)
+        for k in PARAMS:
+            if getattr(g, k) is not None:
+                getattr(g, k).requires_grad_(True)
+        img, mask, uv = fn(g, T, cam, 0.3, 500.0, 100, 3.0, False, bg)
+        uv.retain_grad()
+        img.backward(gi)
+        outs.append((img.detach(), mask, uv.detach(), uv.grad, {k: getattr(g, k).grad for k in PARAMS
+                                                                  if getattr(g, k) is not None}))
+    (i0, m0, u0, gu0, p0), (i1, m1, u1, gu1, p1) = outs
+    assert torch.equal(m0, m1)
+    assert (u0 - u1).abs().max() < 1e-3
+    diff = (i0 - i1).abs().amax(dim=2)
+    assert (diff > 1e-5).float().mean() < 2e-3 and diff.max() < 5e-3
+    errs = {k: scaled_err(p1[k], p0[k]) for k in p0}
+    errs["uv"] = scaled_err(gu1, gu0)
+    report(f"fused_per_pixel_sh_vs_reference_shaped[{N}-deg{deg}]", image_max_diff=diff.max().item(),
+           grad_scaled_err=max(errs.values()))
+    for k in p0:
+        assert p1[k].shape == p0[k].shape
+    assert p1["sh"].abs().max() > 0 and p1["rgb"].abs().max() > 0
+    assert max(errs.values()) < E2E_GRAD_TOL, errs
+
+
 @pytest.mark.parametrize("tag", ["deg0", "deg3_pre"])
 def test_fused_matches_reference_host_fixtures(tag):
     fx = load(f"ref_host_synth_{tag}.npz")
