@@ -1082,6 +1082,9 @@ def _time_secondary(dev, steps=10):
     out = {"workload": f"B: {N} Gaussians, {W}x{H}, SH degree {deg}, seed 0", "steps": steps}
     out["depth_forward_ms"] = round(timed(lambda: render_depth(g, 0.5, T, cam, DEFAULTS["near_thresh"],
                                                               DEFAULTS["cull_mask_padding"], DEFAULTS["mh_dist"])), 4)
+    from gaussian_splatting_amd import fused as fused_mod
+    out["depth_fused_forward_ms"] = round(timed(lambda: fused_mod.render_depth(
+        g, 0.5, T, cam, DEFAULTS["near_thresh"], DEFAULTS["cull_mask_padding"], DEFAULTS["mh_dist"])), 4)
     for p in params:
         p.requires_grad_(True)
 
@@ -1092,8 +1095,6 @@ def _time_secondary(dev, steps=10):
         image.backward(gi)
 
     out["per_pixel_sh_forward_backward_ms"] = round(timed(per_pixel_sh), 4)
-
-    from gaussian_splatting_amd import fused as fused_mod
 
     def per_pixel_sh_fused():
         for p in params:

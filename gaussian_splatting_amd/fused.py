@@ -557,6 +557,25 @@ def _rasterize_per_pixel_sh(g, camera_T_world, camera, near_thresh, far_thresh, 
     return image, culling_mask, uv
 
 
+def render_depth(gaussians, alpha_threshold, camera_T_world, camera, near_thresh, cull_mask_padding, mh_dist):
+    """splat_py.depth.render_depth (depth.py:17-88) on the fused frame's stages: [H, W, 1], the distance of the
+    first Gaussian at which a pixel's accumulated alpha passes alpha_threshold, -1 where it never does.  No
+    gradient.  The reference's depth path has no far threshold (depth.py:33-41): none is applied."""
+    g = gaussians
+    if not g.xyz.is_cuda or g.xyz.dtype != torch.float32:
+        from .splat_py.depth import render_depth as reference_shaped
+        return reference_shaped(g, alpha_threshold, camera_T_world, camera, near_thresh, cull_mask_padding, mh_dist)
+    with torch.no_grad():
+        W, H = int(camera.width), int(camera.height)
+        f = preprocess_forward(g.xyz.contiguous(), g.quaternion.contiguous(), g.scale.contiguous(),
+                               g.opacity.contiguous(), g.rgb.contiguous(), None, camera_T_world.contiguous(),
+                               camera.K.contiguous(), W, H, near_thresh, 3.0e38, cull_mask_padding, mh_dist, None, 0)
+        depth = torch.full((H, W, 1), -1.0, dtype=torch.float32, device=g.xyz.device)
+        _hip.call("gs_render_depth", _p(f.packed), _p(f.xyz_cam), _p(f.ranges), _p(f.sorted_g), W, H,
+                  _cf(alpha_threshold), _p(depth), _stream())
+        return depth
+
+
 def _require(cond, msg):
     if not cond:
         raise RuntimeError(msg)

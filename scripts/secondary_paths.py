@@ -44,6 +44,9 @@ def timed(fn):
 if "depth" in a.what:
     print("depth forward", timed(lambda: render_depth(g, 0.5, T, cam, DEFAULTS["near_thresh"],
                                                       DEFAULTS["cull_mask_padding"], DEFAULTS["mh_dist"])))
+    from gaussian_splatting_amd import fused as _fused
+    print("depth forward, fused frame", timed(lambda: _fused.render_depth(g, 0.5, T, cam, DEFAULTS["near_thresh"],
+                                                                          DEFAULTS["cull_mask_padding"], DEFAULTS["mh_dist"])))
 if "sh" in a.what:
     for p in params:
         p.requires_grad_(True)

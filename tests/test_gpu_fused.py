@@ -164,6 +164,28 @@ def test_fused_per_pixel_sh_matches_reference_shaped_path(hip_backend, N, W, H, 
     assert max(errs.values()) < E2E_GRAD_TOL, errs
 
 
+def test_fused_render_depth_matches_reference_shaped_path(hip_backend):
+    """depth.py:17-88 through the fused stages against the six-node mirror: the same depth wherever the two
+    per-Gaussian stages (ulp-level different world->camera transform) make the same threshold decisions"""
+    from gaussian_splatting_amd.splat_py.depth import render_depth as mirror_depth
+    N, W, H = 20000, 640, 472
+    g, cam, T = make_scene(N, W, H, 0, seed=3, device=DEV)
+    ref = mirror_depth(g, 0.5, T, cam, 0.3, 100, 3.0)
+    got = fused.render_depth(g, 0.5, T, cam, 0.3, 100, 3.0)
+    assert got.shape == ref.shape == (H, W, 1) and got.dtype == torch.float32
+    assert (ref > 0).float().mean() > 0.5   # the scene covers the image
+    differs = (got - ref).abs() > 1e-4 * ref.abs().clamp(min=1.0)
+    assert differs.float().mean() < 1e-4, differs.float().mean()
+    # a far Gaussian is not culled by a far threshold on this path (depth.py:33-41 has none)
+    g2, _, _ = make_scene(64, W, H, 0, seed=5, device=DEV)
+    g2.xyz[:, 2] += 1.0e4
+    g2.scale[:] = 6.0
+    g2.opacity[:] = 5.0
+    far_ref = mirror_depth(g2, 0.5, T, cam, 0.3, 100, 3.0)
+    far_got = fused.render_depth(g2, 0.5, T, cam, 0.3, 100, 3.0)
+    assert (far_ref > 0).any() and torch.equal(far_got > 0, far_ref > 0)
+
+
 @pytest.mark.parametrize("tag", ["deg0", "deg3_pre"])
 def test_fused_matches_reference_host_fixtures(tag):
     fx = load(f"ref_host_synth_{tag}.npz")
