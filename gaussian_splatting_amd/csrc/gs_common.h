@@ -170,6 +170,21 @@ __device__ inline void sh_to_rgb(const T* coeff, const T* Y, T* rgb) {
     }
 }
 
+// The same sum with fused multiply-adds: for gradient VALUES only (the render backward's recomputed colour, checked
+// at 1e-4); every forward quantity uses sh_to_rgb above, whose separate roundings the oracle reproduces.
+template <typename T, int N_SH>
+__device__ inline void sh_to_rgb_contracted(const T* coeff, const T* Y, T* rgb) {
+#pragma clang fp contract(fast)
+#pragma unroll
+    for (int c = 0; c < 3; c++) rgb[c] = Y[0] * coeff[N_SH * c];
+    if constexpr (N_SH >= 4) {
+#pragma unroll
+        for (int s = 1; s < N_SH; s++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) rgb[c] += Y[s] * coeff[N_SH * c + s];
+    }
+}
+
 // ---- prefix-sorted tile lists (binning.hip "prefix sort") --------------------------------------------
 // Largest tile list the LDS sort kernels take; longer ones are sorted in full in global memory.
 constexpr int SORT_MAX_LDS_KEYS = 8192;

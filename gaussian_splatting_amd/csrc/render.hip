@@ -1307,7 +1307,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
 #ifndef GS_SHMM_NOCOL   // timing experiment
                             if constexpr (SHMM) {   // colour at this pixel's view direction
                                 T col[3];
-                                splat_colour<T, N_SH>(s_geom, s_col, i, Y, col);
+                                sh_to_rgb_contracted<T, N_SH>(s_col + i * CW, Y, col);
                                 c0 = col[0]; c1 = col[1]; c2 = col[2];
                             }
 #endif
