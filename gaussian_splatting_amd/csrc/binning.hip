@@ -197,10 +197,11 @@ __global__ __launch_bounds__(BIN_BLOCK) void k_tile_count(const float* __restric
     wave_for_each_tile(active, tw, ntx, 0, [&](int tile, uint64_t) { atomicAdd(counts + tile, 1); });
 }
 
-// exclusive prefix of counts[T] -> ranges[T+1]; single workgroup of 1024 threads
+// exclusive prefix of counts[T] -> ranges[T+1]; single workgroup of 1024 threads.  Only counts[t0, t0 + Tb) are
+// read (a band's tiles: the others are empty and need not have been written)
 __global__ __launch_bounds__(1024) void k_scan_tiles(const int* __restrict__ counts, int T,
                                                      int* __restrict__ ranges,
-                                                     const int* __restrict__ v_dev) {
+                                                     const int* __restrict__ v_dev, int t0, int Tb) {
     __shared__ int s_wave[16];
     __shared__ int s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const int* __restrict__ cou
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int i = base + tid * 4 + k;
-            v[k] = i < T ? counts[i] : 0;
+            v[k] = (i >= t0 && i < t0 + Tb) ? counts[i] : 0;
             sum += v[k];
         }
         int incl = sum;   // inclusive wave scan
@@ -977,12 +978,9 @@ int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visi
     const int T = n_tiles_x * n_tiles_y;
     const int t0 = tile_row0 * n_tiles_x, Tb = (tile_row1 - tile_row0) * n_tiles_x;   // the rows' tiles
     int32_t* counts = workspace;
-    if (Tb > 0 && use_private(Tb, V)) {
+    const bool private_hist = Tb > 0 && use_private(Tb, V);
+    if (private_hist) {
         int32_t* hist = workspace + T;
-        if (Tb < T && hipMemsetAsync(counts, 0, sizeof(int) * (size_t)T, s) != hipSuccess) {   // tiles of other rows: empty
-            gs::set_error("tile_count: memset failed");
-            return GS_EHIP;
-        }
         k_bin_count<<<PRIV_NB, PRIV_BLOCK, sizeof(int) * (size_t)Tb, s>>>(
             (const float*)uvs, (const float*)conic, V, n_tiles_x, n_tiles_y, mh_dist, tile_row0,
             tile_row1, hist, items);
@@ -999,7 +997,8 @@ int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visi
                 tile_row0, tile_row1, counts, items);
         }
     }
-    k_scan_tiles<<<1, 1024, 0, s>>>(counts, T, tile_ranges, visible_count);
+    // (the histogram path writes the counts of the rows' tiles only; the atomic path zero-fills all of them)
+    k_scan_tiles<<<1, 1024, 0, s>>>(counts, T, tile_ranges, visible_count, private_hist ? t0 : 0, private_hist ? Tb : T);
     return check_launch("tile_count");
 }
 

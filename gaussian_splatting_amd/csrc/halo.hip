@@ -131,23 +131,39 @@ __device__ inline int prefix_at(const uint32_t* __restrict__ mask, const int* __
 // wave r handles boundary r.  pre_offsets: exclusive visible-count prefix per 256-block of the
 // Gaussian index (gs_preprocess_forward's workspace), so the visible index of the first Gaussian
 // of block k is pre_offsets[k].
-__global__ __launch_bounds__(GS_WAVE*(GS_MAX_RANKS + 1)) void k_halo_bounds(
+// (device function: runs as the one workgroup of k_halo_bounds, or as the extra last workgroup of
+// k_halo_send_index -- both only need the scan -- with n_waves waves taking the boundaries round-robin)
+__device__ inline void halo_bounds_block(
     const uint32_t* __restrict__ mask, const int* __restrict__ offsets, int nblk,
-    const int* __restrict__ visible_count, const int* __restrict__ pre_offsets, RankInts owner_blk,
+    const int* __restrict__ visible_count, const int* __restrict__ pre_offsets, const RankInts& owner_blk,
     int G, int me, int* __restrict__ vb /*[G+1]*/,
-    int* __restrict__ Pb /*[G][G+1]*/, int* __restrict__ plan /*[4+2G]*/) {
-    __shared__ int s_vb[GS_MAX_RANKS + 1];
-    __shared__ int s_P[GS_MAX_RANKS][GS_MAX_RANKS + 1];
-    const int r = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int* __restrict__ Pb /*[G][G+1]*/, int* __restrict__ plan /*[4+2G]*/, int n_waves,
+    int* s_vb /*[GS_MAX_RANKS + 1]*/, int (*s_P)[GS_MAX_RANKS + 1]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int V = *visible_count;
-    if (r <= G) {
+    for (int r = wave; r <= G; r += n_waves) {
         const int b = (r == G || owner_blk.v[r] >= nblk) ? V : min(V, pre_offsets[owner_blk.v[r]]);
         if (lane == 0) {
             s_vb[r] = b;
             vb[r] = b;
         }
+        // prefix_at(mask, offsets, nblk, s, b, lane) for every s from ONE round of loads: the boundary's block
+        // of mask words (the same for all s) and lane s's offset
+        const int blk = min(b / HB, nblk - 1);   // b == nblk * HB: the last block counted in full
+        uint32_t words[HB / GS_WAVE];
+#pragma unroll
+        for (int k = 0; k < HB / GS_WAVE; k++) {
+            const int i = blk * HB + k * GS_WAVE + lane;
+            words[k] = i < b ? mask[i] : 0u;
+        }
+        const int off = lane < G ? offsets[lane * nblk + blk] : 0;
         for (int s = 0; s < G; s++) {
-            const int p = prefix_at(mask, offsets, nblk, s, b, lane);
+            int n = 0;
+#pragma unroll
+            for (int k = 0; k < HB / GS_WAVE; k++) n += (words[k] >> s) & 1u;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) n += __shfl_xor(n, d);
+            const int p = __shfl(off, s) + n;
             if (lane == 0) {
                 s_P[s][r] = p;
                 Pb[s * (G + 1) + r] = p;
@@ -166,6 +182,43 @@ __global__ __launch_bounds__(GS_WAVE*(GS_MAX_RANKS + 1)) void k_halo_bounds(
         plan[4 + t] = s_P[me][t + 1] - s_P[me][t];       // rows I send to owner t
         plan[4 + G + t] = s_P[t][me + 1] - s_P[t][me];   // rows I receive from sender t
     }
+}
+
+__global__ __launch_bounds__(GS_WAVE*(GS_MAX_RANKS + 1)) void k_halo_bounds(
+    const uint32_t* __restrict__ mask, const int* __restrict__ offsets, int nblk,
+    const int* __restrict__ visible_count, const int* __restrict__ pre_offsets, RankInts owner_blk,
+    int G, int me, int* __restrict__ vb /*[G+1]*/,
+    int* __restrict__ Pb /*[G][G+1]*/, int* __restrict__ plan /*[4+2G]*/) {
+    __shared__ int s_vb[GS_MAX_RANKS + 1];
+    __shared__ int s_P[GS_MAX_RANKS][GS_MAX_RANKS + 1];
+    halo_bounds_block(mask, offsets, nblk, visible_count, pre_offsets, owner_blk, G, me, vb, Pb, plan,
+                      GS_MAX_RANKS + 1, s_vb, s_P);
+}
+
+// gs_halo_plan_masked's form: workgroups [0, nblk) build the send list, workgroup nblk the bounds and the plan
+__global__ __launch_bounds__(HB) void k_halo_send_index_bounds(
+    const uint32_t* __restrict__ mask, const int* __restrict__ offsets, int nblk,
+    const int* __restrict__ visible_count, const int* __restrict__ pre_offsets, RankInts owner_blk, int G, int me,
+    int* __restrict__ send_index, int* __restrict__ vb, int* __restrict__ Pb, int* __restrict__ plan) {
+    __shared__ int s_cnt[HB / GS_WAVE];
+    __shared__ int s_vb[GS_MAX_RANKS + 1];
+    __shared__ int s_P[GS_MAX_RANKS][GS_MAX_RANKS + 1];
+    if ((int)blockIdx.x == nblk) {
+        halo_bounds_block(mask, offsets, nblk, visible_count, pre_offsets, owner_blk, G, me, vb, Pb, plan,
+                          HB / GS_WAVE, s_vb, s_P);
+        return;
+    }
+    const int v = blockIdx.x * HB + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool bit = v < *visible_count && ((mask[v] >> me) & 1u);
+    const unsigned long long bal = __ballot(bit);
+    if (lane == 0) s_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    if (!bit) return;
+    int pos = offsets[me * nblk + blockIdx.x];
+    for (int w = 0; w < wave; w++) pos += s_cnt[w];
+    pos += __popcll(bal & ((1ull << lane) - 1));
+    send_index[pos] = v;
 }
 
 __global__ __launch_bounds__(HB) void k_halo_send_index(const uint32_t* __restrict__ mask,
@@ -278,9 +331,8 @@ int gs_halo_plan_masked(const uint32_t* mask, int N, const int32_t* visible_coun
     int32_t* Pb = vb + (G + 1);
     const int32_t* pre_offsets = preprocess_workspace + nblk;
     k_halo_scan<<<G, 1024, 0, s>>>(blk_counts, nblk, offsets);
-    k_halo_bounds<<<1, GS_WAVE*(GS_MAX_RANKS + 1), 0, s>>>(
-        mask, offsets, nblk, visible_count, pre_offsets, rank_ints(owner_blocks, G + 1), G, rank, vb, Pb, plan);
-    k_halo_send_index<<<nblk, HB, 0, s>>>(mask, offsets, nblk, visible_count, rank, send_index);
+    k_halo_send_index_bounds<<<nblk + 1, HB, 0, s>>>(mask, offsets, nblk, visible_count, pre_offsets,
+                                                     rank_ints(owner_blocks, G + 1), G, rank, send_index, vb, Pb, plan);
     return check_launch("halo_plan_masked");
 }
 
