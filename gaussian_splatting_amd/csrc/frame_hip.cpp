@@ -104,6 +104,16 @@ template <typename F> void timed(const char* name, void* stream, F&& call) {
     g_timing.spans[name].push_back({a, b});
 }
 
+// one float 0 per device (a stride-0 stand-in for gradients nobody reads: no fill kernel per frame)
+Tensor zero_scalar(const torch::Device& dev) {
+    static std::map<int, Tensor> zeros;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    auto it = zeros.find((int)dev.index());
+    if (it == zeros.end())
+        it = zeros.emplace((int)dev.index(), torch::zeros({1}, torch::TensorOptions().dtype(torch::kFloat32).device(dev))).first;
+    return it->second;
+}
+
 std::pair<int32_t*, hipEvent_t> pinned_slot(int dev) {
     PinnedRing& ring = g_pinned[dev];
     if (ring.bufs.empty()) {
@@ -620,7 +630,10 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
         hip_ok(hipMemcpyAsync(host, ranges_buf + T, (2 + plan_ints) * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
         hip_ok(hipEventRecord(ready, (hipStream_t)stream));
         const bool speculative = guess >= 0;
-        const bool whole = false;   // a band: rows outside it are zero-filled
+        // a band.  With the real exchange the other bands' rows are overwritten by the all-gather and nothing reads
+        // the other rows' splat counts / weights: no zero fill (5 us per frame); a stand-in exchange (tests, the
+        // one-GPU measurement of a rank's frame) returns the band image with zeros outside it
+        const bool whole = sp.a2a_hook.is_none();
         const int64_t image_rows = sp.a2a_hook.is_none() ? sp.padded_height : 0;
         bool rendered = false;
         int64_t capacity = 0;
@@ -812,7 +825,7 @@ struct OwnerRender : public torch::autograd::Function<OwnerRender> {
             g_uv = torch::zeros({V, 2}, slab.options());
             if (n_own > 0) g_uv.narrow(0, fr.v_lo, n_own).copy_(owned.narrow(1, 4, 2));
         } else {
-            g_uv = torch::zeros({1}, slab.options()).expand({V, 2});
+            g_uv = zero_scalar(slab.device()).expand({V, 2});
         }
         fr.rendered_uv_grad = g_uv;
         out[0] = g_uv;

@@ -141,29 +141,45 @@ __device__ inline void halo_bounds_block(
     int* s_vb /*[GS_MAX_RANKS + 1]*/, int (*s_P)[GS_MAX_RANKS + 1]) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int V = *visible_count;
-    for (int r = wave; r <= G; r += n_waves) {
-        const int b = (r == G || owner_blk.v[r] >= nblk) ? V : min(V, pre_offsets[owner_blk.v[r]]);
-        if (lane == 0) {
-            s_vb[r] = b;
-            vb[r] = b;
-        }
-        // prefix_at(mask, offsets, nblk, s, b, lane) for every s from ONE round of loads: the boundary's block
-        // of mask words (the same for all s) and lane s's offset
+    // Two rounds of loads for the whole workgroup: (1) every boundary's visible index, (2) per boundary the block of
+    // mask words it cuts (the same words for all s) and lane s's scanned offset -- a wave issues the loads of ALL
+    // its boundaries before it reduces any (dependent rounds of ~2 us each were what this workgroup's time was).
+    constexpr int MAXB = (GS_MAX_RANKS + 1 + 3) / 4;   // boundaries per wave with four waves
+    int bnd[MAXB], off[MAXB];
+    uint32_t words[MAXB][HB / GS_WAVE];
+#pragma unroll
+    for (int j = 0; j < MAXB; j++) {
+        const int r = wave + j * n_waves;
+        const int ob = owner_blk.v[min(r, G)];   // (r > G: no boundary, the value is not used)
+        bnd[j] = (r > G) ? 0 : ((r == G || ob >= nblk) ? V : min(V, pre_offsets[ob]));
+    }
+#pragma unroll
+    for (int j = 0; j < MAXB; j++) {
+        const int r = wave + j * n_waves;
+        const int b = bnd[j];
         const int blk = min(b / HB, nblk - 1);   // b == nblk * HB: the last block counted in full
-        uint32_t words[HB / GS_WAVE];
 #pragma unroll
         for (int k = 0; k < HB / GS_WAVE; k++) {
             const int i = blk * HB + k * GS_WAVE + lane;
-            words[k] = i < b ? mask[i] : 0u;
+            words[j][k] = (r <= G && i < b) ? mask[i] : 0u;
         }
-        const int off = lane < G ? offsets[lane * nblk + blk] : 0;
-        for (int s = 0; s < G; s++) {
+        off[j] = (r <= G && lane < G) ? offsets[lane * nblk + blk] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < MAXB; j++) {
+        const int r = wave + j * n_waves;
+        if (r > G) continue;   // wave-uniform
+        if (lane == 0) {
+            s_vb[r] = bnd[j];
+            vb[r] = bnd[j];
+        }
+        for (int s = 0; s < G; s++) {   // = prefix_at(mask, offsets, nblk, s, b, lane)
             int n = 0;
 #pragma unroll
-            for (int k = 0; k < HB / GS_WAVE; k++) n += (words[k] >> s) & 1u;
+            for (int k = 0; k < HB / GS_WAVE; k++) n += (words[j][k] >> s) & 1u;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) n += __shfl_xor(n, d);
-            const int p = __shfl(off, s) + n;
+            const int p = __shfl(off[j], s) + n;
             if (lane == 0) {
                 s_P[s][r] = p;
                 Pb[s * (G + 1) + r] = p;
