@@ -89,6 +89,22 @@ __device__ unsigned long long g_timeline[2 * GS_TIMELINE_CAP * GS_TIMELINE_W];
 #else
 #define GS_PHASE(k)
 #define GS_STAT(i, v) st_[i] += (unsigned long long)(v)
+// what two independent 8x4 half-waves in lockstep would walk: per chunk, the visits in which the upper
+// / the lower half of the patch has a lane inside the cutoff circle; the lockstep walk takes the larger of the two
+#define GS_HALF_DECL unsigned st_ha_ = 0, st_hb_ = 0
+#define GS_HALF_VISIT(bal)                                                                         \
+    {                                                                                              \
+        const unsigned long long b_ = (bal);                                                       \
+        st_ha_ += (b_ & 0xffffffffull) != 0;                                                       \
+        st_hb_ += (b_ >> 32) != 0;                                                                 \
+    }
+#define GS_HALF_CHUNK(i)                                                                           \
+    {                                                                                              \
+        st_[i] += st_ha_ > st_hb_ ? st_ha_ : st_hb_;                                               \
+        st_[(i) + 1] += st_ha_;                                                                    \
+        st_[(i) + 2] += st_hb_;                                                                    \
+        st_ha_ = st_hb_ = 0;                                                                       \
+    }
 #define GS_STAT_FLUSH(base)                                                                        \
     if ((threadIdx.x & 63) == 0) {                                                                 \
         for (int q_ = 0; q_ < 16; q_++)                                                            \
@@ -102,6 +118,11 @@ __device__ unsigned long long g_timeline[2 * GS_TIMELINE_CAP * GS_TIMELINE_W];
 #define GS_STAT_SET(name)
 #define GS_STAT_FLUSH(base)
 #define GS_PHASE(k)
+#endif
+#ifndef GS_HALF_DECL
+#define GS_HALF_DECL
+#define GS_HALF_VISIT(bal)
+#define GS_HALF_CHUNK(i)
 #endif
 
 #ifndef GS_BWD_GROUP
@@ -581,6 +602,7 @@ __device__ __forceinline__ void render_tile_fwd(
 
     bool all_done = false;
     GS_STAT_DECL;
+    GS_HALF_DECL;
     GS_STAT(0, 1);          // waves
     GS_STAT(7, n_tile);     // list entries of the wave's tile
     for (int base = 0; base < n_list; base += RCHUNK) {
@@ -656,6 +678,7 @@ __device__ __forceinline__ void render_tile_fwd(
                 GS_STAT(3, ballot(st_in) != 0);
                 GS_STAT(4, ballot(st_hit) != 0);
                 GS_STAT(5, __popcll(ballot(st_hit)));
+                GS_HALF_VISIT(ballot(st_in));
             };
             for (int word = 0; word < NW && word * 64 < cnt; word++) {
                 if constexpr (CK) {
@@ -747,6 +770,7 @@ __device__ __forceinline__ void render_tile_fwd(
             }
         }
         GS_PHASE(2);
+        GS_HALF_CHUNK(9);
         all_done = __syncthreads_and(done);
         GS_PHASE(3);
         if (all_done) break;
@@ -1178,6 +1202,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     };
 
     GS_STAT_DECL;
+    GS_HALF_DECL;
     GS_STAT(0, 1);          // waves
     GS_STAT(7, n_tile);
     GS_STAT(8, n_used);
@@ -1329,6 +1354,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                 GS_STAT(3, ballot(st_in) != 0);
                 GS_STAT(4, cmask != 0);
                 GS_STAT(5, __popcll(cmask));
+                GS_HALF_VISIT(ballot(st_in));
                 if (cmask == 0) continue;   // every reaching lane skipped the splat
                 T val[9];
                 const T awy = aw * Y[0];   // (the compiler re-formed Y0 * gi[ch] at every visit to save registers)
@@ -1447,6 +1473,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
             }
         }
         GS_PHASE(2);
+        GS_HALF_CHUNK(12);
         __syncthreads();
         GS_PHASE(3);
         // one global atomic per value per (splat, tile)

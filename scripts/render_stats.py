@@ -22,9 +22,11 @@ from gaussian_splatting_amd import _hip, fused  # noqa: E402
 from gaussian_splatting_amd.synthetic import DEFAULTS, WORKLOADS, make_grad_image, make_scene  # noqa: E402
 
 FWD = ["waves", "chunks", "visits", "visits_in_cutoff", "visits_hit", "pairs_hit", "live_lanes_at_visit",
-       "list_entries", "entries_staged"]
+       "list_entries", "entries_staged", "half_wave_lockstep_visits", "upper_half_visits_in_cutoff",
+       "lower_half_visits_in_cutoff"]
 BWD = ["waves", "chunks", "visits", "visits_in_cutoff", "visits_hit", "pairs_hit", "reaching_lanes_at_visit",
-       "list_entries", "entries_used", "visits_reached", "visits_few_path", "rows_flushed"]
+       "list_entries", "entries_used", "visits_reached", "visits_few_path", "rows_flushed",
+       "half_wave_lockstep_visits", "upper_half_visits_in_cutoff", "lower_half_visits_in_cutoff"]
 
 
 def main():
@@ -69,6 +71,12 @@ def main():
         "bwd_lane_utilisation_of_hit_visits": b["pairs_hit"] / max(64 * b["visits_hit"], 1),
         "bwd_few_path_fraction_of_hits": b["visits_few_path"] / max(b["visits_hit"], 1),
         "bwd_fraction_of_lists_used": b["entries_used"] / max(b["list_entries"], 1),
+        # two 8x4 half-waves in lockstep: steps per chunk = the larger of the halves' visit counts (cutoff test per
+        # lane: the lower bound of a rectangle test), against the visits the kernels walk today
+        "fwd_half_wave_lockstep_over_visits": f["half_wave_lockstep_visits"] / max(f["visits"], 1),
+        "fwd_visits_in_cutoff_over_visits": f["visits_in_cutoff"] / max(f["visits"], 1),
+        "bwd_half_wave_lockstep_over_visits_reached": b["half_wave_lockstep_visits"] / max(b["visits_reached"], 1),
+        "bwd_visits_in_cutoff_over_visits_reached": b["visits_in_cutoff"] / max(b["visits_reached"], 1),
     }
     text = json.dumps(out, indent=1)
     print(text)
