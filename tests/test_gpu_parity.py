@@ -338,6 +338,35 @@ def test_render_per_pixel_sh_dense_lists(hip_backend):
     assert not got["g_rgb"].cpu()[unused].any()
 
 
+@pytest.mark.parametrize("N,W,H,deg,seed,rows", [(4000, 75, 53, 3, 201, None), (9000, 96, 80, 3, 202, None),
+                                                 (2500, 333, 17, 2, 203, None), (7000, 160, 200, 1, 204, (3, 9)),
+                                                 (300, 64, 64, 3, 205, None), (12000, 48, 48, 3, 206, None)])
+def test_per_pixel_sh_backward_shapes(hip_backend, N, W, H, deg, seed, rows):
+    """render_backward.cu:422-488 through the fp32 kernel (slots + MFMA batches) against the oracle on shapes that
+    stress the batching: odd image sizes, a one-tile-row image, very long lists (48x48 with 12 k Gaussians: every wave
+    fills many batches per chunk, hundreds of chunks), nearly empty tiles, a tile-row band.
+    (The fp64 kernel on the device is no checker for it: the two precisions flip alpha >= 1/255 decisions against
+    each other, each worth colour / 255 in the image.)"""
+    orc = oracle()
+    d = cpu_stage_inputs(N, W, H, deg, seed)
+    ntx, nty = (W + 15) // 16, (H + 15) // 16
+    sorted_g, ranges = orc.get_sorted_gaussian_list(1024, d["uv"], d["xyz_c"], d["conic"], ntx, nty, 3.0)
+    rays = compute_rays_in_world_frame(d["cam"], d["T"])
+    coeffs = d["sh_coeffs"].contiguous()
+    bg = torch.full((3,), 0.3)
+    gi = make_grad_image(W, H, seed=seed + 1)
+    if rows is not None:
+        _needs_tile_rows_extension(hip_backend)
+    kw = {} if rows is None else dict(tile_rows=rows)
+    ref = render_case(orc, "cpu", d, coeffs, rays, bg, sorted_g, ranges, torch.float32, gi, **kw)
+    got = render_case(hip_backend, DEV, d, coeffs, rays, bg, sorted_g, ranges, torch.float32, gi, **kw)
+    assert torch.equal(got["nsp"], ref["nsp"]) and torch.equal(got["image"], ref["image"])
+    for k in ("g_rgb", "g_opacity", "g_uv", "g_conic"):
+        assert scaled_err(got[k], ref[k]) < 1e-5, f"{k}: {scaled_err(got[k], ref[k])}"
+        assert rel_err(got[k], ref[k]) < GRAD_TOL, f"{k} elementwise: {rel_err(got[k], ref[k])}"
+    assert got["g_rgb"].abs().max() > 0
+
+
 @pytest.mark.parametrize("n_sh", [1, 16])
 def test_render_fp64_parity(hip_backend, n_sh):
     orc = oracle()
