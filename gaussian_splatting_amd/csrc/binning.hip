@@ -130,21 +130,34 @@ __device__ inline int lane_bcast(int x, int src) { return __builtin_amdgcn_readl
 // lane looping alone over the thousands of tiles of a screen-filling Gaussian stalled its whole workgroup
 // (training scenes have such Gaussians: binning went from 0.2 to 3 ms on them).  The accepted set and
 // the payloads are unchanged; only the order of the emit calls differs (the per-tile sort fixes order).
+// LPG > 1 (a power of two): LPG consecutive lanes hold the SAME Gaussian (sub = its lane's index among them) and
+// share a small window's candidates round-robin -- for frames with few Gaussians, where one lane per Gaussian leaves
+// the chip a wave or two per SIMD, each a serial chain of tests and atomics (workload B: 90 k Gaussians).
 constexpr int COOP_MIN = 48;
-template <typename F>
-__device__ inline void wave_for_each_tile(bool active, const TileWalk& tw, int ntx, uint64_t payload, F emit) {
+template <int LPG = 1, typename F>
+__device__ inline void wave_for_each_tile(bool active, const TileWalk& tw, int ntx, uint64_t payload, F emit, int sub = 0) {
     const Window& w = tw.w;
     const int area = active ? (w.ex - w.sx) * (w.ey - w.sy) : 0;
     if (area > 0 && area <= COOP_MIN) {
-        for (int tx = w.sx; tx < w.ex; tx++) {
-            const float l = (float)tx * 16.0f, r = (float)(tx + 1) * 16.0f;
-            for (int ty = w.sy; ty < w.ey; ty++) {
-                const float t = (float)ty * 16.0f, b2 = (float)(ty + 1) * 16.0f;
-                if (sat_overlaps(tw.s, l, r, t, b2)) emit(ty * ntx + tx, payload);
+        if constexpr (LPG == 1) {
+            for (int tx = w.sx; tx < w.ex; tx++) {
+                const float l = (float)tx * 16.0f, r = (float)(tx + 1) * 16.0f;
+                for (int ty = w.sy; ty < w.ey; ty++) {
+                    const float t = (float)ty * 16.0f, b2 = (float)(ty + 1) * 16.0f;
+                    if (sat_overlaps(tw.s, l, r, t, b2)) emit(ty * ntx + tx, payload);
+                }
+            }
+        } else {
+            const int h = w.ey - w.sy;
+            for (int c = sub; c < area; c += LPG) {
+                const int cx = c / h;
+                const int tx = w.sx + cx, ty = w.sy + (c - cx * h);
+                if (sat_overlaps(tw.s, (float)tx * 16.0f, (float)(tx + 1) * 16.0f, (float)ty * 16.0f, (float)(ty + 1) * 16.0f))
+                    emit(ty * ntx + tx, payload);
             }
         }
     }
-    unsigned long long big = __builtin_amdgcn_ballot_w64(area > COOP_MIN);
+    unsigned long long big = __builtin_amdgcn_ballot_w64(area > COOP_MIN && sub == 0);
     const int lane = threadIdx.x & 63;
     while (big) {
         const int src = __builtin_ctzll(big);
@@ -185,23 +198,26 @@ __device__ inline int item_count(const Items& it, int V) {
 }
 __device__ inline int item_at(const Items& it, int i) { return it.subset ? it.subset[i] : i; }
 
+template <int LPG>
 __global__ __launch_bounds__(BIN_BLOCK) void k_tile_count(const float* __restrict__ uvs,
                                                           const float* __restrict__ conic, int V,
                                                           int ntx, int nty, float mh, int row0,
                                                           int row1, int* __restrict__ counts,
                                                           Items items) {
-    const int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
+    const int t = blockIdx.x * BIN_BLOCK + threadIdx.x;
+    const int i = t / LPG, sub = t % LPG;
     const bool active = i < item_count(items, V);
     TileWalk tw;
     if (active) tw = tile_walk_setup(uvs, conic, item_at(items, i), ntx, nty, mh, row0, row1);
-    wave_for_each_tile(active, tw, ntx, 0, [&](int tile, uint64_t) { atomicAdd(counts + tile, 1); });
+    wave_for_each_tile<LPG>(active, tw, ntx, 0, [&](int tile, uint64_t) { atomicAdd(counts + tile, 1); }, sub);
 }
 
 // exclusive prefix of counts[T] -> ranges[T+1]; single workgroup of 1024 threads.  Only counts[t0, t0 + Tb) are
 // read (a band's tiles: the others are empty and need not have been written)
-__global__ __launch_bounds__(1024) void k_scan_tiles(const int* __restrict__ counts, int T,
+// clear != 0: every count read is set to 0 (the atomic-counter path: the array is k_tile_emit's cursor next)
+__global__ __launch_bounds__(1024) void k_scan_tiles(int* __restrict__ counts, int T,
                                                      int* __restrict__ ranges,
-                                                     const int* __restrict__ v_dev, int t0, int Tb) {
+                                                     const int* __restrict__ v_dev, int t0, int Tb, int clear) {
     __shared__ int s_wave[16];
     __shared__ int s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -213,6 +229,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const int* __restrict__ cou
         for (int k = 0; k < 4; k++) {
             const int i = base + tid * 4 + k;
             v[k] = (i >= t0 && i < t0 + Tb) ? counts[i] : 0;
+            if (clear && i >= t0 && i < t0 + Tb) counts[i] = 0;
             sum += v[k];
         }
         int incl = sum;   // inclusive wave scan
@@ -343,12 +360,17 @@ __device__ inline uint32_t sortable_bits(float z) {   // monotone float -> uint 
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// cursor[T] must be zero on entry and is zero again on exit: the hit that takes a tile's last slot resets its cursor
+// (gs_tile_count leaves the zeros: k_scan_tiles clears each count it has read), so a repeated emit of the same
+// frame -- a capacity miss -- starts clean as well and no fill kernel runs per frame.
+template <int LPG>
 __global__ __launch_bounds__(BIN_BLOCK) void k_tile_emit(
     const float* __restrict__ uvs, const float* __restrict__ xyz_cam,
     const float* __restrict__ conic, int V, int ntx, int nty, float mh, int row0, int row1,
     const int* __restrict__ ranges, int* __restrict__ cursor, uint64_t* __restrict__ keys,
     Items items, int64_t cap) {
-    const int i = blockIdx.x * BIN_BLOCK + threadIdx.x;
+    const int t = blockIdx.x * BIN_BLOCK + threadIdx.x;
+    const int i = t / LPG, sub = t % LPG;
     const bool active = i < item_count(items, V);
     TileWalk tw;
     uint64_t key = 0;
@@ -357,10 +379,12 @@ __global__ __launch_bounds__(BIN_BLOCK) void k_tile_emit(
         key = ((uint64_t)sortable_bits(xyz_cam[g * 3 + 2]) << 32) | (uint32_t)g;
         tw = tile_walk_setup(uvs, conic, g, ntx, nty, mh, row0, row1);
     }
-    wave_for_each_tile(active, tw, ntx, key, [&](int tile, uint64_t k) {
-        const int pos = ranges[tile] + atomicAdd(cursor + tile, 1);
-        if (pos < cap) keys[pos] = k;
-    });
+    wave_for_each_tile<LPG>(active, tw, ntx, key, [&](int tile, uint64_t k) {
+        const int first = ranges[tile];
+        const int old = atomicAdd(cursor + tile, 1);
+        if (old + 1 == ranges[tile + 1] - first) cursor[tile] = 0;   // the tile's last hit: nobody else comes
+        if (first + old < cap) keys[first + old] = k;
+    }, sub);
 }
 
 __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_emit(
@@ -955,6 +979,12 @@ extern "C" {
 // LDS-histogram mode pays when there are many instances per tile; with few Gaussians the
 // NB x T histogram matrix costs more than the global atomics it saves.  The decision depends only
 // on (T, V) so that gs_tile_count and gs_tile_emit_sort agree.
+// The atomic-counter kernels give a Gaussian a group of lanes while the frame has few of them (see wave_for_each_tile)
+// (workload B, 90 k visible Gaussians, gs_tile_count / gs_tile_emit_sort entries with their scans and sort: one lane
+// per Gaussian 41 / 58 us, 4 lanes 32.3 / 46.2, 8 lanes 30.3 / 40.1, 16 lanes 28.1 / 34.6, 32 lanes 36.4 / 43.9;
+// every lane of a group repeats the Gaussian's setup, so the group shrinks as the frame grows)
+constexpr int SUBGROUP_SMALL = 16, SUBGROUP_SMALL_MAX_V = 1 << 17;
+constexpr int SUBGROUP_MID = 8, SUBGROUP_MID_MAX_V = 1 << 18;
 static bool use_private(int T, int V) {
     return T <= PRIV_MAX_TILES && (int64_t)V * 8 > (int64_t)PRIV_NB * T;
 }
@@ -992,13 +1022,23 @@ int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visi
             return GS_EHIP;
         }
         if (V > 0) {
-            k_tile_count<<<div_up(V, BIN_BLOCK), BIN_BLOCK, 0, s>>>(
-                (const float*)uvs, (const float*)conic, V, n_tiles_x, n_tiles_y, mh_dist,
-                tile_row0, tile_row1, counts, items);
+            if (V <= SUBGROUP_SMALL_MAX_V)
+                k_tile_count<SUBGROUP_SMALL><<<div_up(V * SUBGROUP_SMALL, BIN_BLOCK), BIN_BLOCK, 0, s>>>(
+                    (const float*)uvs, (const float*)conic, V, n_tiles_x, n_tiles_y, mh_dist,
+                    tile_row0, tile_row1, counts, items);
+            else if (V <= SUBGROUP_MID_MAX_V)
+                k_tile_count<SUBGROUP_MID><<<div_up(V * SUBGROUP_MID, BIN_BLOCK), BIN_BLOCK, 0, s>>>(
+                    (const float*)uvs, (const float*)conic, V, n_tiles_x, n_tiles_y, mh_dist,
+                    tile_row0, tile_row1, counts, items);
+            else
+                k_tile_count<1><<<div_up(V, BIN_BLOCK), BIN_BLOCK, 0, s>>>(
+                    (const float*)uvs, (const float*)conic, V, n_tiles_x, n_tiles_y, mh_dist,
+                    tile_row0, tile_row1, counts, items);
         }
     }
     // (the histogram path writes the counts of the rows' tiles only; the atomic path zero-fills all of them)
-    k_scan_tiles<<<1, 1024, 0, s>>>(counts, T, tile_ranges, visible_count, private_hist ? t0 : 0, private_hist ? Tb : T);
+    k_scan_tiles<<<1, 1024, 0, s>>>(counts, T, tile_ranges, visible_count, private_hist ? t0 : 0, private_hist ? Tb : T,
+                                    private_hist ? 0 : 1);
     return check_launch("tile_count");
 }
 
@@ -1025,14 +1065,19 @@ int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void*
             (const float*)uvs, (const float*)xyz_camera_frame, (const float*)conic, V, n_tiles_x,
             n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, hist, keys, items, S);
     } else {
-        int32_t* cursor = workspace;
-        if (hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)T, s) != hipSuccess) {
-            gs::set_error("tile_emit_sort: memset failed");
-            return GS_EHIP;
-        }
-        k_tile_emit<<<div_up(V, BIN_BLOCK), BIN_BLOCK, 0, s>>>(
-            (const float*)uvs, (const float*)xyz_camera_frame, (const float*)conic, V, n_tiles_x,
-            n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, cursor, keys, items, S);
+        int32_t* cursor = workspace;   // zero since gs_tile_count's scan, and again after every emit (k_tile_emit)
+        if (V <= SUBGROUP_SMALL_MAX_V)
+            k_tile_emit<SUBGROUP_SMALL><<<div_up(V * SUBGROUP_SMALL, BIN_BLOCK), BIN_BLOCK, 0, s>>>(
+                (const float*)uvs, (const float*)xyz_camera_frame, (const float*)conic, V, n_tiles_x,
+                n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, cursor, keys, items, S);
+        else if (V <= SUBGROUP_MID_MAX_V)
+            k_tile_emit<SUBGROUP_MID><<<div_up(V * SUBGROUP_MID, BIN_BLOCK), BIN_BLOCK, 0, s>>>(
+                (const float*)uvs, (const float*)xyz_camera_frame, (const float*)conic, V, n_tiles_x,
+                n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, cursor, keys, items, S);
+        else
+            k_tile_emit<1><<<div_up(V, BIN_BLOCK), BIN_BLOCK, 0, s>>>(
+                (const float*)uvs, (const float*)xyz_camera_frame, (const float*)conic, V, n_tiles_x,
+                n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, cursor, keys, items, S);
     }
     const int t0 = tile_row0 * n_tiles_x;
     const int nt = (tile_row1 - tile_row0) * n_tiles_x;

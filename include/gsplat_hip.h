@@ -107,7 +107,8 @@ int gs_precompute_rgb_from_sh_backward(const void* xyz, const void* matrix, cons
  *   reaches the rank's rows, gs_halo_plan's send_index).  The list must contain every row that has
  *   a tile in [tile_row0, tile_row1); the resulting lists are then the same as without it.
  * workspace: int32[gs_tile_workspace_ints(n_tiles)] scratch written by step 1 and read by step 2
- *   (per-workgroup tile histograms; keep it untouched between the two calls);
+ *   (per-workgroup tile histograms, or per-tile cursors that step 1 leaves zeroed and step 2 returns to zero;
+ *   keep it untouched between the two calls; step 2 may be repeated on it -- a larger capacity);
  * keys: uint64[S] scratch.  S may be an over-estimate (a capacity): instances beyond it are not
  * written and tiles reaching beyond it are left unsorted, so a caller may launch step 2 before it
  * has read the true count and repeat it with the exact S only if the count exceeded the capacity.
