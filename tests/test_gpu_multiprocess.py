@@ -75,7 +75,7 @@ def _worker(rank, world, port, mode, native, deg, out):
 
 
 @pytest.mark.parametrize("world,mode,native", [(2, "owner", True), (3, "owner", True), (4, "owner", True),
-                                               (2, "owner", False), (2, "replicated", None)])
+                                               (8, "owner", True), (2, "owner", False), (2, "replicated", None)])
 def test_sharded_frame_on_several_ranks_of_one_gpu(world, mode, native):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
