@@ -291,15 +291,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # GS_BENCH_BACKEND=gloo: a harness test -- several ranks share one GPU and exchange through gloo's CUDA-tensor
+    # collectives (RCCL refuses two ranks on a device), so that the N > 1 code of this script runs on a one-GPU
+    # box (tests/test_gpu_multiprocess.py).  The line it prints is labelled with the backend; its times mean nothing.
+    backend = os.environ.get("GS_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     sharded = world > 1 or args.force_sharded
     dist = None
     if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         # first contact with RCCL: every rank proves that the collective layer sees the whole job before anything
         # is timed -- an all-reduce of ones must give the world size, an all-gather of the ranks 0..world-1 in order
         probe = torch.ones(1, device=dev)

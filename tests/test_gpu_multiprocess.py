@@ -101,3 +101,31 @@ def test_sharded_frame_on_several_ranks_of_one_gpu(world, mode, native):
         # what the ranks send is what the ranks receive
         assert sum(r[3][0] for r in results) == sum(r[3][1] for r in results) > 0
         assert all(r[3][2] == bool(native) for r in results), "the orchestration asked for is not the one that ran"
+
+
+def test_bench_line_with_two_ranks_on_one_gpu():
+    """bench.py's N > 1 code (the command the driver launches for the scaling record) on a one-GPU box: two ranks
+    under torch.distributed.run, gloo instead of RCCL.  The times mean nothing; the line must be complete, carry
+    the in-run check of the sharded frame against the single-GPU frame, and be the last line on stdout."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GS_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "2", "--workload", "B", "--spinup-steps", "2"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 2 and line["scaling"] == "strong"
+    assert line["metric"] and line["value"] > 0 and line["config"]["parallelism"].startswith("tile-rows x2")
+    m = line["multi_gpu"]
+    assert m["world_size_seen_by_rccl"] == 2 and m["backend"] == "gloo"
+    assert m["headline_grad_mode"] == "owner", m["modes"]   # the native orchestration ran: no fallback was needed
+    assert m["sharded_check"]["image_equals_single_gpu_image_on_every_rank"] is True
+    assert m["sharded_check"]["grad_max_err_over_tensor_scale"] < 2e-5
+    assert len(m["ranks"]) == 2 and set(m["modes"]) >= {"owner", "replicated"}
+    assert "rank 0/2" in r.stderr and "rank 1/2" in r.stderr
