@@ -315,7 +315,8 @@ def main():
         seen = torch.empty(world, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(seen, torch.tensor([rank], dtype=torch.int64, device=dev))
         ok = int(probe.item()) == world and seen.tolist() == list(range(world)) and dist.get_world_size() == world
-        print(f"[bench] rank {rank}/{world} on {torch.cuda.get_device_name(dev)} (local {local_rank}): {"RCCL" if backend == "nccl" else backend} world size "
+        layer = "RCCL" if backend == "nccl" else backend
+        print(f"[bench] rank {rank}/{world} on {torch.cuda.get_device_name(dev)} (local {local_rank}): {layer} world size "
               f"{dist.get_world_size()}, all-reduce of ones = {int(probe.item())}, ranks seen {seen.tolist()}",
               file=sys.stderr, flush=True)
         if not ok:
