@@ -268,3 +268,21 @@ def test_committed_bench_lines_keep_the_contract(name):
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mpixels/s" and c["sample"]
         assert d["parity"]["image_max_abs_err"] == 0.0 and d["parity"]["grad_max_rel_err"] < 1e-4
         assert r["traffic"] is not None and r["traffic_source"].startswith("profiles/")
+
+
+def test_every_python_file_of_the_repo_compiles():
+    """bench.py, the entry module, the package and the scripts byte-compile under this interpreter (a syntax error
+    in a file the CPU suite never imports -- a script, a GPU-only branch -- would otherwise wait for the GPU box)"""
+    import os
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = []
+    for top in ("bench.py", "__graft_entry__.py", "gaussian_splatting_amd", "scripts", "tests", "oracle"):
+        path = os.path.join(root, top)
+        if os.path.isfile(path):
+            files.append(path)
+        for d, _, names in os.walk(path):
+            files += [os.path.join(d, n) for n in names if n.endswith(".py")]
+    assert len(files) > 40
+    for f in files:
+        py_compile.compile(f, doraise=True, cfile=os.devnull)
