@@ -270,7 +270,7 @@ def test_committed_bench_lines_keep_the_contract(name):
         assert r["traffic"] is not None and r["traffic_source"].startswith("profiles/")
 
 
-def test_every_python_file_of_the_repo_compiles():
+def test_every_python_file_of_the_repo_compiles(tmp_path):
     """bench.py, the entry module, the package and the scripts byte-compile under this interpreter (a syntax error
     in a file the CPU suite never imports -- a script, a GPU-only branch -- would otherwise wait for the GPU box)"""
     import os
@@ -285,4 +285,4 @@ def test_every_python_file_of_the_repo_compiles():
             files += [os.path.join(d, n) for n in names if n.endswith(".py")]
     assert len(files) > 40
     for f in files:
-        py_compile.compile(f, doraise=True, cfile=os.devnull)
+        py_compile.compile(f, doraise=True, cfile=str(tmp_path / "out.pyc"))
