@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, mode, native, deg, out):
+def _worker(rank, world, port, mode, native, deg, out, band_policy="equal"):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -38,7 +38,7 @@ def _worker(rank, world, port, mode, native, deg, out):
                           for k in ("xyz", "rgb", "opacity", "scale", "quaternion", "sh")])
         ref_img, ref_mask, ref_uv = fused.rasterize(ref_g, T, cam, use_sh_precompute=True, background_rgb=bg, **DEFAULTS)
         ref_img.backward(gi)
-        rast = sharded.ShardedRasterizer(H, grad_mode=mode, native=native)
+        rast = sharded.ShardedRasterizer(H, grad_mode=mode, native=native, band_policy=band_policy)
         assert rast.world_size == world and rast.rank == rank
         if mode == "owner":
             holder = sharded.owned_slice(g, world, rank)
@@ -50,7 +50,7 @@ def _worker(rank, world, port, mode, native, deg, out):
             holder, (i0, i1) = g, (0, g.xyz.shape[0])
         worst = 0.0
         same = True
-        for frame in range(2):   # the second frame takes the speculative-capacity path
+        for frame in range(3):   # later frames take the speculative-capacity path (and, cost policy, re-cut bands)
             for k in PARAMS:
                 if getattr(holder, k) is not None:
                     getattr(holder, k).grad = None
@@ -66,22 +66,26 @@ def _worker(rank, world, port, mode, native, deg, out):
                 worst = max(worst, float(err))
         plan = rast.last_plan
         native_used = type(plan).__name__ == "SimpleNamespace"   # the native branch records its plan as a namespace
-        out.put((rank, same, worst, None if plan is None else (sum(plan.send_splits), sum(plan.recv_splits), native_used)))
+        out.put((rank, same, worst, None if plan is None else (sum(plan.send_splits), sum(plan.recv_splits), native_used),
+                 tuple(rast.tile_rows)))
     except Exception as e:   # noqa: BLE001 -- reported to the parent, which fails the test
         import traceback
-        out.put((rank, False, float("inf"), "".join(traceback.format_exception(type(e), e, e.__traceback__))[-2000:]))
+        out.put((rank, False, float("inf"), "".join(traceback.format_exception(type(e), e, e.__traceback__))[-2000:], None))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode,native", [(2, "owner", True), (3, "owner", True), (4, "owner", True),
-                                               (8, "owner", True), (2, "owner", False), (2, "replicated", None)])
-def test_sharded_frame_on_several_ranks_of_one_gpu(world, mode, native):
+@pytest.mark.parametrize("world,mode,native,policy", [
+    (2, "owner", True, "equal"), (3, "owner", True, "equal"), (4, "owner", True, "equal"), (8, "owner", True, "equal"),
+    (2, "owner", False, "equal"), (2, "replicated", None, "equal"),
+    # cost-balanced bands: the per-row costs ride on the image gather and the next frame's bands follow them
+    (3, "owner", False, "cost"), (2, "replicated", None, "cost")])
+def test_sharded_frame_on_several_ranks_of_one_gpu(world, mode, native, policy):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, native, 3, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, native, 3, out, policy)) for r in range(world)]
     for p in procs:
         p.start()
     results = []
@@ -94,13 +98,16 @@ def test_sharded_frame_on_several_ranks_of_one_gpu(world, mode, native):
             if p.is_alive():
                 p.kill()
     results.sort()
-    for rank, same, worst, info in results:
+    for rank, same, worst, info, rows in results:
         assert same, f"rank {rank}: image or mask differs from the single-GPU frame ({info})"
         assert worst < 2e-5, f"rank {rank}: gradient error {worst} ({info})"
     if mode == "owner":
         # what the ranks send is what the ranks receive
         assert sum(r[3][0] for r in results) == sum(r[3][1] for r in results) > 0
         assert all(r[3][2] == bool(native) for r in results), "the orchestration asked for is not the one that ran"
+    # the ranks' bands tile the rows in rank order
+    rows = [r[4] for r in results]
+    assert rows[0][0] == 0 and rows[-1][1] == 19 and all(a[1] == b[0] for a, b in zip(rows, rows[1:])), rows
 
 
 def test_bench_line_with_two_ranks_on_one_gpu():
