@@ -383,10 +383,11 @@ def test_backward_mode_of_a_frame_is_the_mode_at_its_forward():
     gi = make_grad_image(W, H, seed=1, device=DEV)
     bg = torch.full((3,), 0.5, device=DEV)
 
+    g0, cam, T = make_scene(N, W, H, deg, seed=0, device=DEV)   # once: eight scene builds were 20 s of this test
+    g0.opacity.add_(-4.0)
+
     def run(mode_at_forward, mode_at_backward, aux):
-        g, cam, T = make_scene(N, W, H, deg, seed=0, device=DEV)
-        g.opacity.add_(-4.0)
-        g.opacity.requires_grad_(True)
+        g = type(g0)(g0.xyz, g0.rgb, g0.opacity.detach().clone().requires_grad_(True), g0.scale, g0.quaternion, g0.sh)
         try:
             _hip.set_backward_mode(mode_at_forward)
             out = fused.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, tile_rows=rows, return_aux=aux,
