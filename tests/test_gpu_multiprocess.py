@@ -110,7 +110,8 @@ def test_sharded_frame_on_several_ranks_of_one_gpu(world, mode, native, policy):
     assert rows[0][0] == 0 and rows[-1][1] == 19 and all(a[1] == b[0] for a, b in zip(rows, rows[1:])), rows
 
 
-def test_bench_line_with_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("inject", [None, "owner"])
+def test_bench_line_with_two_ranks_on_one_gpu(inject):
     """bench.py's N > 1 code (the command the driver launches for the scaling record) on a one-GPU box: two ranks
     under torch.distributed.run, gloo instead of RCCL.  The times mean nothing; the line must be complete, carry
     the in-run check of the sharded frame against the single-GPU frame, and be the last line on stdout."""
@@ -119,6 +120,8 @@ def test_bench_line_with_two_ranks_on_one_gpu():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GS_BENCH_BACKEND="gloo")
+    if inject:   # the native orchestration "fails" on every rank: the same frame with the Python orchestration is timed
+        env["GS_BENCH_INJECT_FAILURE"] = inject
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
@@ -131,8 +134,12 @@ def test_bench_line_with_two_ranks_on_one_gpu():
     assert line["metric"] and line["value"] > 0 and line["config"]["parallelism"].startswith("tile-rows x2")
     m = line["multi_gpu"]
     assert m["world_size_seen_by_rccl"] == 2 and m["backend"] == "gloo"
-    assert m["headline_grad_mode"] == "owner", m["modes"]   # the native orchestration ran: no fallback was needed
+    if inject:
+        assert m["headline_grad_mode"] == "owner_python" and "injected failure" in m["modes"]["owner_error"]
+        assert m["sharded_check"]["mode"] == "owner_python"
+    else:
+        assert m["headline_grad_mode"] == "owner", m["modes"]   # the native orchestration ran: no fallback was needed
     assert m["sharded_check"]["image_equals_single_gpu_image_on_every_rank"] is True
     assert m["sharded_check"]["grad_max_err_over_tensor_scale"] < 2e-5
-    assert len(m["ranks"]) == 2 and set(m["modes"]) >= {"owner", "replicated"}
+    assert len(m["ranks"]) == 2 and set(m["modes"]) >= {"owner_python" if inject else "owner", "replicated"}
     assert "rank 0/2" in r.stderr and "rank 1/2" in r.stderr
