@@ -1191,9 +1191,6 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
             for (int k = lane; k < n_filled * 48; k += 64) {
                 const int row = k / 48, c = k - row * 48;
                 const int ch = c >> 4, s2 = c & 15;
-#ifdef GS_SHMM_NOFLUSH   // timing experiment
-                if (mine[k] != 12345.678f) continue;
-#endif
                 if (s2 < N_SH) global_add(g_rgb + (size_t)s_bidx[wave * MB + row] * C + ch * N_SH + s2, mine[k]);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1329,13 +1326,11 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                             aw = alpha * weight;
                             // grad_alpha (render_backward.cu:196-203); the record's colour is Y0 * coefficient
                             T c0 = g2.y, c1 = g2.z, c2 = g2.w;
-#ifndef GS_SHMM_NOCOL   // timing experiment
                             if constexpr (SHMM) {   // colour at this pixel's view direction
                                 T col[3];
                                 sh_to_rgb_contracted<T, N_SH>(s_col + i * CW, Y, col);
                                 c0 = col[0]; c1 = col[1]; c2 = col[2];
                             }
-#endif
                             const T ga = (c0 * weight - color_accum[0] * r1ma) * gi[0] +
                                          (c1 * weight - color_accum[1] * r1ma) * gi[1] +
                                          (c2 * weight - color_accum[2] * r1ma) * gi[2];
@@ -1367,9 +1362,6 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                     // column nb of the batch's B: this splat's aw at the wave's 64 pixels (0 where it does not contribute)
                     s_B[(wave * MB + nb) * BROW + lane] = aw;
                     if (lane == 0) s_bidx[wave * MB + nb] = s_idx[i];
-#ifdef GS_SHMM_NOMMA   // timing experiment
-                    if (nb == MB - 1) nb = 0;
-#endif
                     if (++nb == MB) {
                         mma_flush(MB);
                         nb = 0;
