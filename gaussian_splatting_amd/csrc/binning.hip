@@ -985,13 +985,17 @@ extern "C" {
 // every lane of a group repeats the Gaussian's setup, so the group shrinks as the frame grows)
 constexpr int SUBGROUP_SMALL = 16, SUBGROUP_SMALL_MAX_V = 1 << 17;
 constexpr int SUBGROUP_MID = 8, SUBGROUP_MID_MAX_V = 1 << 18;
-static bool use_private(int T, int V) {
-    return T <= PRIV_MAX_TILES && (int64_t)V * 8 > (int64_t)PRIV_NB * T;
+// Tb: tiles of the rows binned (a band, or the grid).  The histogram matrix (PRIV_NB x Tb ints) lives behind the
+// grid's T counters; gs_tile_workspace_ints reserves room for the largest matrix any row range of the grid can ask
+// for, PRIV_NB x min(T, PRIV_MAX_TILES) -- a band of a grid that is itself too large for the LDS histogram (4K and
+// up: T > 16384) still takes the LDS path.
+static bool use_private(int Tb, int V) {
+    return Tb > 0 && Tb <= PRIV_MAX_TILES && (int64_t)V * 8 > (int64_t)PRIV_NB * Tb;
 }
 
 size_t gs_tile_workspace_ints(int n_tiles) {
     const size_t T = n_tiles > 0 ? (size_t)n_tiles : 1;
-    return T <= (size_t)PRIV_MAX_TILES ? T * (1 + (size_t)PRIV_NB) : T;
+    return T + (size_t)PRIV_NB * (T <= (size_t)PRIV_MAX_TILES ? T : (size_t)PRIV_MAX_TILES);
 }
 
 int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visible_count,
@@ -1008,7 +1012,7 @@ int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visi
     const int T = n_tiles_x * n_tiles_y;
     const int t0 = tile_row0 * n_tiles_x, Tb = (tile_row1 - tile_row0) * n_tiles_x;   // the rows' tiles
     int32_t* counts = workspace;
-    const bool private_hist = Tb > 0 && use_private(Tb, V);
+    const bool private_hist = use_private(Tb, V);
     if (private_hist) {
         int32_t* hist = workspace + T;
         k_bin_count<<<PRIV_NB, PRIV_BLOCK, sizeof(int) * (size_t)Tb, s>>>(
@@ -1059,7 +1063,7 @@ int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void*
     const int T = n_tiles_x * n_tiles_y;
     const int Tb = (tile_row1 - tile_row0) * n_tiles_x;
     if (S <= 0 || V <= 0) return GS_OK;
-    if (Tb > 0 && use_private(Tb, V)) {
+    if (use_private(Tb, V)) {
         const int32_t* hist = workspace + T;
         k_bin_emit<<<PRIV_NB, PRIV_BLOCK, sizeof(int) * (size_t)Tb, s>>>(
             (const float*)uvs, (const float*)xyz_camera_frame, (const float*)conic, V, n_tiles_x,

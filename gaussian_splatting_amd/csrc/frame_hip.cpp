@@ -66,6 +66,20 @@ bool want_segments(int64_t n_instances, int64_t n_tiles) {
     if (g_segments == 0) return n_tiles > 0 && n_tiles < 1500 && n_instances >= 192 * n_tiles;
     return g_segments > 0 && n_tiles > 0;
 }
+// "auto" is decided ONCE per frame shape, from the exact instance count of the first frame of that shape (which is
+// never speculative), and kept: a speculative frame only knows a capacity (S * 1.25 + 4096), so near the
+// 192-entries-per-tile threshold the first frame and later frames of the same scene would pick different backward
+// kernels and their gradients would differ in the last bits from frame to frame (round-3 advisor finding).
+std::map<HintKey, bool> g_segment_choice;
+bool segments_for(const HintKey& key, int64_t n_instances, bool exact_count, int64_t n_tiles) {
+    if (g_segments != 0) return want_segments(n_instances, n_tiles);
+    std::lock_guard<std::mutex> lock(g_mutex);
+    auto it = g_segment_choice.find(key);
+    if (it != g_segment_choice.end()) return it->second;
+    const bool on = want_segments(n_instances, n_tiles);
+    if (exact_count) g_segment_choice[key] = on;
+    return on;
+}
 
 // optional per-entry-point timing (bench.py): events on the launch stream around every C-ABI call, so the
 // elapsed time of one entry point is the GPU time of the kernels it enqueues
@@ -159,7 +173,7 @@ struct RenderOut {
 
 RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* ranges, Tensor& sorted, Tensor& keys,
                          const Tensor& bg, int W, int H, int row0, int row1, bool whole, int sort_prefix, void* stream,
-                         int64_t image_rows = 0) {
+                         const HintKey& key, bool exact_count, int64_t image_rows = 0) {
     const int64_t P = (int64_t)W * H;
     // image_rows > H (multi-GPU, equal bands): the image block holds world_size full bands so that the band
     // images can be all-gathered in place; the kernels only see the first H rows
@@ -177,8 +191,8 @@ RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* 
     r.fw = r.buf.narrow(0, 3 * PI, P).view({H, W});
     r.nsp = r.buf.narrow(0, 3 * PI + P, P).view(torch::kInt32).view({H, W});
     int32_t* tile_cost = reinterpret_cast<int32_t*>(r.buf.data_ptr<float>()) + 3 * PI + 2 * P;
-    const bool segments = want_segments(sorted.size(0), (int64_t)(row1 - row0) * ntx);
-    r.seg = torch::empty({segments ? (int64_t)(gs_render_segment_workspace_bytes(W, H) / 4) : 0}, opt);
+    const bool segments = segments_for(key, sorted.size(0), exact_count, (int64_t)(row1 - row0) * ntx);
+    r.seg = torch::empty({segments ? (int64_t)(gs_render_segment_workspace_bytes(W, H, row0, row1) / 4) : 0}, opt);
     void* seg_p = segments ? r.seg.data_ptr() : nullptr;
     if (sort_prefix && sorted.size(0) > sort_prefix) {
         Tensor flags = torch::empty({(int64_t)ntx * nty}, opt.dtype(torch::kInt32));
@@ -275,7 +289,7 @@ struct Preprocess : public torch::autograd::Function<Preprocess> {
             emit_sort(capacity);
             if (g_early_render && sort_prefix && capacity > sort_prefix) {
                 out = render_forward(packed, rgbr, ranges_buf, sorted, keys, bg, (int)W, (int)H, (int)row0, (int)row1, whole,
-                                     sort_prefix, stream);
+                                     sort_prefix, stream, key, false);
                 rendered = true;
             }
         }
@@ -298,7 +312,7 @@ struct Preprocess : public torch::autograd::Function<Preprocess> {
         Tensor sorted_g = sorted.narrow(0, 0, S), keys_g = keys.narrow(0, 0, S);
         if (!rendered)
             out = render_forward(packed, rgbr, ranges_buf, sorted_g, keys_g, bg, (int)W, (int)H, (int)row0, (int)row1, whole,
-                                 sort_prefix, stream);
+                                 sort_prefix, stream, key, true);
 
         Tensor uv_t = far.block(1, 2 * (int64_t)N).view({N, 2}).narrow(0, 0, V);
         Tensor conic_t = far.block(3, 3 * (int64_t)N).view({N, 3}).narrow(0, 0, V);
@@ -642,7 +656,7 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
             emit_sort(capacity);
             if (g_early_render && sort_prefix && capacity > sort_prefix) {
                 fr.out = render_forward(packed, rgbr, ranges_buf, sorted, keys, fr.bg, W, H, row0, row1, whole, sort_prefix, stream,
-                                        image_rows);
+                                        key, false, image_rows);
                 rendered = true;
             }
         }
@@ -667,7 +681,7 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
         Tensor sorted_g = sorted.narrow(0, 0, S), keys_g = keys.narrow(0, 0, S);
         if (!rendered)
             fr.out = render_forward(packed, rgbr, ranges_buf, sorted_g, keys_g, fr.bg, W, H, row0, row1, whole, sort_prefix, stream,
-                                    image_rows);
+                                    key, true, image_rows);
         fr.v_lo = rec[2];
         fr.v_hi = rec[3];
         fr.send_splits.assign(rec + 4, rec + 4 + G);
@@ -709,7 +723,14 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
     static variable_list backward(AutogradContext* ctx, variable_list g) {
         variable_list out(7);
         FrameRec& fr = frame_of(ctx->saved_data["fr"].toTensor());
-        if (!fr.owned_rows.defined()) return out;
+        if (!fr.owned_rows.defined()) {
+            // the render node's backward did not run (no loss term on the image).  A loss on uv alone would be
+            // dropped silently: its gradient reaches only the owned rows through the render node's exchange
+            TORCH_CHECK(!g[0].defined(),
+                        "sharded_rasterize: a gradient arrived on uv but none on the image; the owner-sliced frame "
+                        "routes uv gradients through the image's backward -- put a (possibly zero-weight) loss term on the image");
+            return out;
+        }
         const auto dev = fr.xyz.device();
         const int n_sh = fr.n_sh;
         Tensor owned = fr.owned_rows;
@@ -876,6 +897,15 @@ std::tuple<Tensor, Tensor, Tensor> sharded_rasterize(
     }
     sp.band_pixel_rows = 16 * ((nty + G - 1) / G);
     sp.padded_height = sp.band_pixel_rows * G;
+    if (all_to_all_hook.is_none()) {
+        // the band images are all-gathered IN PLACE: rank r's band must start at row r * band_pixel_rows of the padded
+        // buffer, i.e. the bands must be the equal-band layout (sharded.band_of); cost-balanced bands gather otherwise
+        const int64_t rows_per = (nty + G - 1) / G;
+        for (int r = 0; r <= G; r++)
+            TORCH_CHECK(sp.bounds[r] == std::min<int64_t>(nty, r * rows_per),
+                        "sharded_rasterize gathers equal bands in place: bounds[", r, "] = ", sp.bounds[r], ", expected ",
+                        std::min<int64_t>(nty, r * rows_per));
+    }
     fr->row0 = sp.bounds[me];
     fr->row1 = sp.bounds[me + 1];
     TORCH_CHECK(0 <= fr->row0 && fr->row0 <= fr->row1 && fr->row1 <= nty, "bad tile row range");

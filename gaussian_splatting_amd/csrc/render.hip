@@ -502,19 +502,35 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int* __restrict__ cos
 constexpr int SEG_LEN = GS_SEG_LEN;   // entries per segment (a multiple of the 64-entry mask words)
 constexpr int SEG_MAX = GS_SEG_MAX;   // segments per tile; the last one is open-ended
 static_assert(SEG_LEN % 64 == 0 && SEG_MAX >= 2, "segment geometry");
+// the segmented backward walks whole chunks from seg_lo / GS_BWD_CHUNK with no `k >= seg_lo` guard: a segment must
+// start on a chunk boundary or its first chunk would re-visit the previous segment's entries
+static_assert(SEG_LEN % GS_BWD_CHUNK == 0, "a depth segment must be a whole number of backward chunks");
 struct SegState {              // views into the caller's workspace (gs_render_segment_workspace_bytes)
-    int* kend;                 // [H W]
-    float* oma_last;           // [H W]
-    float* bgw;                // [H W]
-    Vec4<float>* rec;          // [tiles][SEG_MAX][256]
+    int* kend;                 // [band pixels], by pixel index - pix0
+    float* oma_last;           // same
+    float* bgw;                // same
+    Vec4<float>* rec;          // [band tiles][SEG_MAX][256], by tile index - tile0
+    int tile0;                 // first tile of the band
+    int pix0;                  // first pixel of the band
 };
-__host__ __device__ inline SegState seg_state_of(void* ws, int W, int H) {
-    SegState st{nullptr, nullptr, nullptr, nullptr};
+constexpr SegState SEG_NONE{nullptr, nullptr, nullptr, nullptr, 0, 0};
+// The workspace covers the tile rows [row0, row1) only -- segments are on for bands (a multi-GPU rank's eighth of
+// the frame): 32 KB per tile of the BAND, not of the grid (round-3 advisor finding: ~1 GB per frame at 4K to use
+// an eighth of it).
+__host__ __device__ inline size_t seg_band_pixels(int W, int H, int row0, int row1) {
+    const int y0 = row0 * 16 < H ? row0 * 16 : H, y1 = row1 * 16 < H ? row1 * 16 : H;
+    return (size_t)W * (size_t)(y1 > y0 ? y1 - y0 : 0);
+}
+__host__ __device__ inline SegState seg_state_of(void* ws, int W, int H, int row0, int row1) {
+    SegState st = SEG_NONE;
     if (ws == nullptr) return st;
-    const size_t P = (size_t)W * H;
+    const size_t P = seg_band_pixels(W, H, row0, row1);
+    const size_t ntx = (size_t)((W + 15) / 16);
+    st.tile0 = (int)ntx * row0;
+    st.pix0 = W * (row0 * 16 < H ? row0 * 16 : H);
     char* p = (char*)ws;
     st.rec = (Vec4<float>*)p;   // first: 16-byte aligned
-    p += (size_t)((W + 15) / 16) * ((H + 15) / 16) * SEG_MAX * 256 * sizeof(Vec4<float>);
+    p += ntx * (size_t)(row1 - row0) * SEG_MAX * 256 * sizeof(Vec4<float>);
     st.kend = (int*)p;
     st.oma_last = (float*)(p + 4 * P);
     st.bgw = (float*)(p + 8 * P);
@@ -535,7 +551,7 @@ __device__ __forceinline__ void render_tile_fwd(
     T* __restrict__ fw_out, T* __restrict__ image, int sort_prefix, int* __restrict__ tile_flags,
     bool flagged_only, int64_t cap, int* __restrict__ tile_cost = nullptr,
     const T* __restrict__ src_opacity = nullptr, const T* __restrict__ src_conic = nullptr,
-    const SegState seg = SegState{nullptr, nullptr, nullptr, nullptr}) {
+    const SegState seg = SEG_NONE) {
     static_assert(!CK || (sizeof(T) == 4 && N_SH == 1), "segment checkpoints: the fused renderer's kernel only");
     constexpr bool fast = sizeof(T) == 4;
     // the tile's own duration in 16-cycle units: the launch-order key of the backward (k_tile_order)
@@ -594,7 +610,7 @@ __device__ __forceinline__ void render_tile_fwd(
             Vec4<float> r4;
             r4.x = segL; r4.y = sg0; r4.z = sg1; r4.w = sg2;
 #ifndef GS_CK_NOREC   // (A/B builds that time the parts of the extra work; wrong gradients)
-            seg.rec[((size_t)tile * SEG_MAX + b_cur) * RB + tid] = r4;
+            seg.rec[((size_t)(tile - seg.tile0) * SEG_MAX + b_cur) * RB + tid] = r4;
 #endif
             segL = 1; sg0 = 0; sg1 = 0; sg2 = 0;
         }
@@ -804,7 +820,7 @@ __device__ __forceinline__ void render_tile_fwd(
                 if (bw > Thr<T>::bgw_gt()) bgw = bw;
                 oma_last = T(1) - alpha;
             }
-            const size_t p = (size_t)px.v * W + px.u;
+            const size_t p = (size_t)px.v * W + px.u - seg.pix0;
             seg.kend[p] = kend;
             seg.oma_last[p] = oma_last;
             seg.bgw[p] = bgw;
@@ -1086,9 +1102,9 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
             weight = fw_in[p];
             if constexpr (SLOTS) {
                 if (seg_on) {
-                    kend = seg.kend[p];
-                    oma_last = seg.oma_last[p];
-                    bgw = seg.bgw[p];
+                    kend = seg.kend[p - seg.pix0];
+                    oma_last = seg.oma_last[p - seg.pix0];
+                    bgw = seg.bgw[p - seg.pix0];
                 }
             }
             gi[0] = grad_image[p * 3 + 0];
@@ -1215,7 +1231,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                 reach_end = 0;   // the pixel's walk ended in front of this segment
             } else if (kend > seg_hi) {
                 // the pixel's walk comes from behind: resume it with the state it has at the boundary
-                const Vec4<float>* rec = seg.rec + (size_t)tile * SEG_MAX * RB + tid;
+                const Vec4<float>* rec = seg.rec + (size_t)(tile - seg.tile0) * SEG_MAX * RB + tid;
                 const int e_p = min((kend - 1) / SEG_LEN, SEG_MAX - 1);        // segment of its last contributor
                 const int e_tile = min((n_used - 1) / SEG_LEN, SEG_MAX - 1);   // wave-uniform bound
                 const int k_m = kend - 1;
@@ -1715,7 +1731,7 @@ static int launch_render_fwd(const void* packed_or_uvs, const void* opacity, con
             (const float*)packed_or_uvs, (const float*)rgb, tile_ranges, sorted_gaussians,
             (const float*)background_rgb, W, H, ntx, tile_row0 * ntx, nt, num_splats_per_pixel,
             (float*)final_weight_per_pixel, (float*)image, 0, nullptr, INT64_MAX, nullptr,
-            seg_state_of(segment_state, W, H));
+            seg_state_of(segment_state, W, H, tile_row0, tile_row1));
         return check_launch("render_tiles");
     }
     DISPATCH_T(dtype, DISPATCH_SH(n_sh, (k_render_fwd<T, N_SH><<<grid, RB, 0, s>>>(
@@ -1749,10 +1765,10 @@ int gs_render_tiles_packed(const void* packed, const void* rgb, const void* view
                              final_weight_per_pixel, image, dtype, stream, segment_state);
 }
 
-size_t gs_render_segment_workspace_bytes(int W, int H) {
-    if (W <= 0 || H <= 0) return 0;
-    const size_t T = (size_t)((W + 15) / 16) * ((H + 15) / 16);
-    return T * SEG_MAX * 256 * sizeof(Vec4<float>) + (size_t)W * H * 12;
+size_t gs_render_segment_workspace_bytes(int W, int H, int tile_row0, int tile_row1) {
+    if (W <= 0 || H <= 0 || tile_row0 < 0 || tile_row1 <= tile_row0 || tile_row1 > (H + 15) / 16) return 0;
+    const size_t Tb = (size_t)((W + 15) / 16) * (size_t)(tile_row1 - tile_row0);
+    return Tb * SEG_MAX * 256 * sizeof(Vec4<float>) + seg_band_pixels(W, H, tile_row0, tile_row1) * 12;
 }
 
 int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* tile_ranges,
@@ -1771,7 +1787,7 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
     if (nt == 0) return GS_OK;
     const int grid = render_grid(nt);
     const int t0 = tile_row0 * ntx;
-    const SegState seg = seg_state_of(segment_state, W, H);
+    const SegState seg = seg_state_of(segment_state, W, H, tile_row0, tile_row1);
     // 1. provisional pass over the ordered prefixes; raises the flags
     if (segment_state)
         k_render_fwd_ck<<<grid, RB, 0, s>>>(
@@ -1819,7 +1835,7 @@ static int launch_render_bwd(const void* packed_or_uvs, const void* opacity, con
                                      (const T*)grad_image, W, H, ntx, tile_row0 * ntx, nt,
                                      (T*)grad_rgb, (T*)grad_opacity, (T*)grad_uv,
                                      (T*)grad_conic, 0, exact, nullptr, (const T*)opacity,
-                                     (const T*)conic, SegState{nullptr, nullptr, nullptr, nullptr}))));
+                                     (const T*)conic, SEG_NONE))));
     return check_launch("render_tiles_backward");
 }
 
@@ -1875,7 +1891,7 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
             (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
             (const float*)background_rgb, num_splats_per_pixel, (const float*)final_weight_per_pixel,
             (const float*)grad_image, W, H, ntx, tile_row0 * ntx, nt, (float*)grad_slab, nullptr,
-            nullptr, nullptr, 1, exact, nullptr, nullptr, nullptr, seg_state_of((void*)segment_state, W, H));
+            nullptr, nullptr, 1, exact, nullptr, nullptr, nullptr, seg_state_of((void*)segment_state, W, H, tile_row0, tile_row1));
         return check_launch("render_tiles_backward_slab");
     }
     const bool ordered = tile_cost != nullptr && nt >= GS_LPT_MIN_TILES;
@@ -1885,7 +1901,7 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
         (const float*)background_rgb, num_splats_per_pixel, (const float*)final_weight_per_pixel,
         (const float*)grad_image, W, H, ntx, tile_row0 * ntx, nt, (float*)grad_slab, nullptr,
         nullptr, nullptr, 1, exact, ordered ? tile_order : nullptr, nullptr, nullptr,
-        SegState{nullptr, nullptr, nullptr, nullptr});
+        SEG_NONE);
     return check_launch("render_tiles_backward_slab");
 }
 

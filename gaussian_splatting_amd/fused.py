@@ -321,6 +321,23 @@ def want_segments(n_instances, n_tiles):
     return bool(SEGMENTS) and n_tiles > 0
 
 
+_segment_choice = {}   # frame shape (the capacity hint's key) -> "auto"'s decision, fixed by the first exact count
+
+
+def segments_for(hint_key, n_instances, exact_count, n_tiles):
+    """want_segments, decided once per frame shape: a speculative frame only knows a capacity (1.25 S + 4096), so
+    near the threshold the first frame and the later frames of one scene would otherwise pick different backward
+    kernels (gradients differing in the last bits from frame to frame)."""
+    if SEGMENTS != "auto":
+        return want_segments(n_instances, n_tiles)
+    if hint_key in _segment_choice:
+        return _segment_choice[hint_key]
+    on = want_segments(n_instances, n_tiles)
+    if exact_count:
+        _segment_choice[hint_key] = on
+    return on
+
+
 def render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, width, tile_rows, sort_prefix,
                    image_rows=None, segments=None):
     """-> image, splat counts, final weights, tile costs, segment state.  image_rows > height: the image buffer
@@ -346,8 +363,8 @@ def render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, 
         segments = want_segments(sorted_g.shape[0], (row1 - row0) * ntx)
     seg = _empty(dev)
     if segments:
-        seg = torch.empty(_hip.lib().gs_render_segment_workspace_bytes(width, height) // 4, dtype=torch.float32,
-                          device=dev)
+        seg = torch.empty(_hip.lib().gs_render_segment_workspace_bytes(width, height, row0, row1) // 4,
+                          dtype=torch.float32, device=dev)
     seg_p = _p(seg) if segments else None
     if sort_prefix and sorted_g.shape[0] > sort_prefix:
         # provisional render from the ordered prefixes; tiles that ran out of prefix are flagged,
@@ -423,14 +440,16 @@ class _Preprocess(torch.autograd.Function):
             # the render (the _Render node's forward) is enqueued on the speculative tile lists before
             # the host waits for the frame's counts, so a short frame leaves no bubble on the GPU;
             # a too small capacity repeats it
-            def render():
+            def render(exact_count):
+                seg = segments_for(f.hint_key, f.sorted_buf.shape[0] if not exact_count else f.S, exact_count,
+                                   (f.row1 - f.row0) * f.ntx)
                 return render_forward(f.packed, f.rgb_render, f.ranges, f.sorted_buf, f.keys_buf, background_rgb,
-                                      height, width, tile_rows, sort_prefix)
+                                      height, width, tile_rows, sort_prefix, segments=seg)
 
             # (only gs_render_tiles_prefix takes the capacity and skips segments beyond it)
-            pre = render() if (f.speculative and f.capacity > sort_prefix) else None
+            pre = render(False) if (f.speculative and f.capacity > sort_prefix) else None
             if preprocess_finish(f) or pre is None:
-                pre = render()
+                pre = render(True)
         else:
             pre = ()
         V = f.V

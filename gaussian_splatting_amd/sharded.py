@@ -332,15 +332,18 @@ class _OwnerPreprocess(torch.autograd.Function):
         if not DEFER_HOST_READ:
             fused.preprocess_finish(f)
 
-        def render():
+        def render(exact_count):
+            seg = fused.segments_for(f.hint_key, f.S if exact_count else f.sorted_buf.shape[0], exact_count,
+                                     (f.row1 - f.row0) * f.ntx)
             return fused.render_forward(f.packed, f.rgb_render, f.ranges, f.sorted_buf, f.keys_buf, background_rgb,
-                                        height, width, tile_rows, sort_prefix, image_rows=rast.buffer_rows())
+                                        height, width, tile_rows, sort_prefix, image_rows=rast.buffer_rows(),
+                                        segments=seg)
 
         # the render is enqueued on the speculative tile lists before the host looks at the frame's
         # counts, so the GPU does not wait for the host; a too small capacity repeats it (rare)
-        out = render() if (f.speculative and DEFER_HOST_READ and sort_prefix and f.capacity > sort_prefix) else None
+        out = render(False) if (f.speculative and DEFER_HOST_READ and sort_prefix and f.capacity > sort_prefix) else None
         if (DEFER_HOST_READ and fused.preprocess_finish(f)) or out is None:
-            out = render()
+            out = render(True)
         fr.f, fr.rendered, fr.plan = f, out, finish_hip_plan(f, G, me)
         fr.full, fr.cam, fr.background = full, (camera_T_world, K), background_rgb
         rast.last_plan = fr.plan

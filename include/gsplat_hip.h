@@ -229,14 +229,15 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
                            void* final_weight_per_pixel, void* image, int32_t* tile_cost, void* segment_state,
                            void* stream);
 /* Depth segments of the fused backward (fp32, n_sh == 1; ABI 5).  segment_state (may be NULL): a 16-byte aligned
- * device workspace of gs_render_segment_workspace_bytes(W, H) bytes that gs_render_tiles_packed /
+ * device workspace of gs_render_segment_workspace_bytes(W, H, tile_row0, tile_row1) bytes (ABI 6: sized for the
+ * tile rows the three calls are given -- 32 KB per tile of the band, not of the grid) that gs_render_tiles_packed /
  * gs_render_tiles_prefix fill -- per (tile, 128-entry segment of its list, pixel) the transmittance at the
  * segment's far boundary and the colour the segment contributed, per pixel where its walk ends and what the
  * backward's first step does there -- and that gs_render_tiles_backward_slab, given the same pointer, uses to
  * launch one workgroup per (tile, segment) instead of one per tile: 3-4x more, shorter work items, the same
  * gradients up to fp32 rounding (what a multi-GPU rank's band of a few hundred tiles needs to fill the chip;
  * no reference counterpart).  The contents are private to the library. */
-size_t gs_render_segment_workspace_bytes(int W, int H);
+size_t gs_render_segment_workspace_bytes(int W, int H, int tile_row0, int tile_row1);
 /* render_tiles_backward_cuda (bindings.cpp:120; render_backward.cu:12-595), the reference's arguments in the
  * reference's order.  grad_rgb[V,3,n_sh], grad_opacity[V,1], grad_uv[V,2], grad_conic[V,3] are accumulated.
  * backward_mode: GS_BACKWARD_DEFAULT / _COMPAT / _EXACT (below); COMPAT is bug-compatible with

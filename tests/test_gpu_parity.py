@@ -250,6 +250,36 @@ def test_tile_lists_empty_and_row_restricted(hip_backend):
             assert n == 0
 
 
+def test_tile_lists_band_of_a_grid_beyond_the_lds_histogram(hip_backend):
+    """a grid of more than 16384 tiles (4 MP and up) whose band fits the LDS histogram and has enough Gaussians
+    per tile for it (binning.hip: use_private decides on the BAND's tiles): the histogram matrix is PRIV_NB x band
+    tiles and must fit the workspace gs_tile_workspace_ints sized from the grid.  Round-3 advisor finding: it did
+    not, and the count pass wrote ~16 MB past the allocation.  Lists of the band == the oracle's, whole grid too."""
+    _needs_tile_rows_extension(hip_backend)
+    orc = oracle()
+    W, H = 2320, 1840
+    ntx, nty = (W + 15) // 16, (H + 15) // 16
+    assert ntx * nty > 16384
+    rows = (60, 70)                      # 1450 tiles; LDS path needs V > 128 * 1450
+    d = cpu_stage_inputs(260000, W, H, 0, 12)
+    V = d["uv"].shape[0]
+    assert V * 8 > 1024 * (rows[1] - rows[0]) * ntx
+    full_s, full_r = orc.get_sorted_gaussian_list(1024, d["uv"], d["xyz_c"], d["conic"], ntx, nty, 3.0)
+    dev = [d[k].to(DEV) for k in ("uv", "xyz_c", "conic")]
+    guard = torch.full((1 << 22,), 7, dtype=torch.int32, device=DEV)   # a neighbour a stray write would land in
+    got_s, got_r = hip_backend.get_sorted_gaussian_list(1024, *dev, ntx, nty, 3.0, tile_rows=rows)
+    torch.cuda.synchronize()
+    assert int((guard != 7).sum()) == 0
+    got_s, got_r = got_s.cpu(), got_r.cpu()
+    t0, t1 = rows[0] * ntx, rows[1] * ntx
+    assert torch.equal(got_r[t0:t1 + 1] - got_r[t0], full_r[t0:t1 + 1] - full_r[t0])
+    assert int(got_r[t0]) == 0 and int(got_r[-1]) == int(got_r[t1])
+    assert torch.equal(got_s, full_s[full_r[t0]:full_r[t1]])
+    # the whole grid (atomic-counter path: the grid itself is too large for the LDS histogram)
+    all_s, all_r = hip_backend.get_sorted_gaussian_list(1024, *dev, ntx, nty, 3.0)
+    assert torch.equal(all_r.cpu(), full_r) and torch.equal(all_s.cpu(), full_s)
+
+
 # ---------------------------------------------------------------------------------------------------
 # render forward: bit exact;  backward: 1e-4
 # ---------------------------------------------------------------------------------------------------
