@@ -694,18 +694,20 @@ def valu_roofline(entry, launch_ms, workload):
             "note": "half- and quarter-rate instructions (DPP, v_cndmask, v_ldexp, fp64, v_rcp) count as one"}
 
 
-def parity_check(workload, fused_mod, dev, n_rows=2):
-    """Second half of the metric ("grad max-rel-err vs ref"): the CPU oracle, as the checker, renders a
-    band of tile rows of the timed workload forward + backward from the GPU's own per-splat inputs
-    (uv, conic, opacity, colour, tile lists); the GPU renders the same band.  Image: max abs difference
-    (0 == bit-identical).  Gradients w.r.t. those inputs: max |g - ref| / max(|ref|, 1 % of max|ref|)."""
+def parity_check(workload, fused_mod, dev, n_rows=None):
+    """Second half of the metric ("grad max-rel-err vs ref"): the CPU oracle, as the checker, renders the timed
+    workload's WHOLE frame forward + backward (n_rows=None; ~1.2 s of host time per pass at D) from the GPU's own
+    per-splat inputs (uv, conic, opacity, colour, tile lists); the GPU renders the same frame, so the figures belong
+    to the kernel the throughput half times (the full frame's unsegmented k_render_bwd -- a band of fewer than 1500
+    tiles would take the depth-segmented one).  Image: max abs difference (0 == bit-identical).  Gradients w.r.t.
+    those inputs: max |g - ref| / max(|ref|, 1 % of max|ref|).  n_rows: only that many central tile rows."""
     from gaussian_splatting_amd.synthetic import DEFAULTS, WORKLOADS, make_grad_image, make_scene
     from oracle import gs_oracle as orc
 
     orc.set_modes(0, 0)
     N, W, H, deg = WORKLOADS[workload]
     nty = (H + 15) // 16
-    rows = (nty // 2, min(nty, nty // 2 + n_rows))
+    rows = None if n_rows is None else (nty // 2, min(nty, nty // 2 + n_rows))
     g, cam, T = make_scene(N, W, H, deg, seed=0, device=dev)
     bg = torch.zeros(3, device=dev)
     for name in ("xyz", "rgb", "opacity", "scale", "quaternion", "sh"):
@@ -762,7 +764,10 @@ def parity_check(workload, fused_mod, dev, n_rows=2):
                 eo = (o[j].double() - b).abs()
                 worst["reorder_1e-6"] = max(worst["reorder_1e-6"], (eo / torch.clamp(b.abs(), min=1e-6 * top)).max().item())
                 worst["reorder_1e-2"] = max(worst["reorder_1e-2"], (eo / torch.clamp(b.abs(), min=1e-2 * top)).max().item())
-    y0, y1 = rows[0] * 16, min(H, rows[1] * 16)
+    y0, y1 = (0, H) if rows is None else (rows[0] * 16, min(H, rows[1] * 16))
+    ntx = (W + 15) // 16
+    n_tiles = ntx * (nty if rows is None else rows[1] - rows[0])
+    segmented = bool(fused_mod.want_segments(int(sorted_g.numel()), n_tiles))
     return {"grad_max_rel_err_floor_1e-6": worst["floor_1e-6"],
             "fp32_reorder_spread_floor_1e-6": worst["reorder_1e-6"],
             "grad_max_rel_err": worst["floor_1e-2"], "fp32_reorder_spread_floor_1e-2": worst["reorder_1e-2"],
@@ -775,8 +780,11 @@ def parity_check(workload, fused_mod, dev, n_rows=2):
                            "criterion resolves summation order, not kernel error -- tests/test_grad_noise_floor.py); "
                            "grad_max_rel_err = the same with a 1 % floor (asserted <= 1e-4 in tests/); the leaf-term "
                            "figure divides by the element's own sum of term magnitudes, no floor",
-            "sample": f"workload {workload}, tile rows [{rows[0]},{rows[1]}) rendered by GPU and by the CPU oracle "
-                      "from the same per-splat inputs and tile lists"}
+            "backward_kernel": "k_render_bwd<float,1>, " + ("depth-segmented" if segmented else
+                                                              "unsegmented (the kernel the timed frame runs)"),
+            "sample": f"workload {workload}, " + ("the whole frame (all %d tile rows)" % nty if rows is None else
+                                                  f"tile rows [{rows[0]},{rows[1]})") +
+                      " rendered by GPU and by the CPU oracle from the same per-splat inputs and tile lists"}
 
 
 def time_train_ops(workload, dev, steps=20):

@@ -131,14 +131,20 @@ def test_band_backward_from_the_oracles_own_inputs(workload):
 REORDER_FACTOR = {"rgb_render": 2.0, "opacity_act": 8.0, "uv": 8.0, "conic": 8.0}
 
 
-def test_gradient_error_is_within_the_fp32_reorder_spread():
+@pytest.mark.parametrize("segments", [False, True], ids=["unsegmented", "depth-segmented"])
+def test_gradient_error_is_within_the_fp32_reorder_spread(segments):
     """SURVEY.md 8(d) writes the gradient criterion with a floor of 1e-6 of the tensor's maximum; the HIP kernel
     reads ~1e-3 .. 3e-3 there at workload D (the first parity number of bench.py's line), target 1e-4.  Evidence
     that this is fp32 rounding of cancelling sums and not a kernel error: the oracle sums ITS OWN per-pixel terms
     (bit-identical terms) in fp32 in two fixed orders (tests/test_grad_noise_floor.py); the criterion between
     either of those and the double sum is the figure an fp32 implementation with the oracle's exact per-term
     arithmetic gets -- already 2e-4 .. 1.3e-3, above the target.  The kernel must stay within REORDER_FACTOR of
-    it, per tensor, at the 1e-6 floor, on the D band the bench reports."""
+    it, per tensor, at the 1e-6 floor, on a D band -- both backward kernels a band can take: the unsegmented walk
+    (what the full frame runs; tests/test_gpu_wholeframe_parity.py repeats this over all rows) and the
+    depth-segmented one (the default below 1500 tiles: a multi-GPU rank's band).  The segmented walk resumes a
+    pixel from products of stored factors instead of carrying one running weight through the whole list: one more
+    rounding per segment boundary on every weight behind it, on top of the order noise (uv read 4.8x the spread in
+    round 3, inside the factor asserted here)."""
     workload = "D"
     N, W, H, deg = WORKLOADS[workload]
     rows = BAND[workload]
@@ -148,7 +154,7 @@ def test_gradient_error_is_within_the_fp32_reorder_spread():
         getattr(g, k).requires_grad_(True)
     bg = torch.full((3,), 0.5, device=DEV)
     prev = fused.SEGMENTS
-    fused.SEGMENTS = False   # the kernel the bench line's figure comes from (the full frame is not segmented)
+    fused.SEGMENTS = segments
     try:
         img, mask, uv, aux = fused.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, tile_rows=rows,
                                              return_aux=True, **DEFAULTS)
@@ -170,7 +176,8 @@ def test_gradient_error_is_within_the_fp32_reorder_spread():
         spread = max(rel_err(ref_a[key], ref64[key], 1e-6), rel_err(ref_b[key], ref64[key], 1e-6))
         between = rel_err(ref_a[key], ref_b[key], 1e-6)
         kernel = rel_err(grads[name], ref64[key], 1e-6)
-        report("fp32_reorder_spread[D rows 26-28]", tensor=name, kernel_vs_double_floor_1e6=kernel,
+        report(f"fp32_reorder_spread[D rows 26-28, {'depth-segmented' if segments else 'unsegmented'}]", tensor=name,
+               kernel_vs_double_floor_1e6=kernel,
                fp32_order_vs_double_floor_1e6=spread, fp32_order_a_vs_b_floor_1e6=between,
                kernel_floor_1e2=rel_err(grads[name], ref64[key], 1e-2),
                fp32_order_floor_1e2=max(rel_err(ref_a[key], ref64[key], 1e-2), rel_err(ref_b[key], ref64[key], 1e-2)))
