@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(_HERE, "libgsplat_hi
 GS_F32 = 0
 GS_F64 = 1
 GS_SORT_PREFIX = 1024
+GS_CUT_HIST_BINS = 8192   # include/gsplat_hip.h
 GS_BACKWARD_DEFAULT = -1  # per-call argument of the render-backward entry points: the process default
 GS_BACKWARD_COMPAT = 0   # render backward bug-compatible with render_backward.cu:185 (default)
 GS_BACKWARD_EXACT = 1    # the exact gradient of the forward pass
@@ -48,6 +49,8 @@ EXPORTS = [
     "gs_band_project", "gs_halo_plan_masked", "gs_preprocess_forward_list",
     "gs_adam_step", "gs_accumulate_grad_stats", "gs_ssim_l1_workspace_bytes", "gs_ssim_l1_loss",
     "gs_densify_move",
+    "gs_cut_workspace_ints", "gs_cut_sample_stride", "gs_cut_supported", "gs_preprocess_forward_cut", "gs_tile_count_cut",
+    "gs_tile_emit_sort_cut", "gs_cut_debug_views", "gs_render_tiles_cut",
 ]
 
 _lib = None
@@ -76,6 +79,7 @@ def lib():
         _lib.gs_halo_workspace_ints.restype = ctypes.c_size_t
         _lib.gs_ssim_l1_workspace_bytes.restype = ctypes.c_size_t
         _lib.gs_render_segment_workspace_bytes.restype = ctypes.c_size_t
+        _lib.gs_cut_workspace_ints.restype = ctypes.c_size_t
     return _lib
 
 

@@ -314,7 +314,7 @@ std::tuple<torch::Tensor, torch::Tensor> get_sorted_gaussian_list(const int max_
     torch::Tensor ranges = torch::empty({T + 1}, i32);
     void* stream = dev_.stream();
     ok(gs_tile_count(uvs.data_ptr(), conic.data_ptr(), V, nullptr, nullptr, nullptr, n_tiles_x, n_tiles_y, mh_dist, 0,
-                     n_tiles_y, workspace.data_ptr<int32_t>(), ranges.data_ptr<int32_t>(), stream));
+                     n_tiles_y, workspace.data_ptr<int32_t>(), ranges.data_ptr<int32_t>(), nullptr, stream));
     const int64_t S = ranges[T].item<int32_t>();   // the one host read: sizes the result
     torch::Tensor sorted = torch::empty({S}, i32);
     if (S > 0) {

@@ -88,13 +88,12 @@ struct TileWalk {
     Window w;
 };
 
-__device__ inline TileWalk tile_walk_setup(const float* __restrict__ uvs, const float* __restrict__ conic, int g,
-                                           int ntx, int nty, float mh, int row0, int row1) {
+__device__ inline TileWalk tile_walk_setup_vals(float u, float v, float conic0, float conic1, float conic2,
+                                                int ntx, int nty, float mh, int row0, int row1) {
     TileWalk tw;
-    const float u = uvs[g * 2], v = uvs[g * 2 + 1];
-    const float a = conic[g * 3] + 0.25f;
-    const float b = conic[g * 3 + 1] / 2.0f;
-    const float c = conic[g * 3 + 2] + 0.25f;
+    const float a = conic0 + 0.25f;
+    const float b = conic1 / 2.0f;
+    const float c = conic2 + 0.25f;
     const Obb o = compute_obb(u, v, a, b, c, mh);
     Window w = candidate_window(u, v, o.radius_tiles, ntx, nty, row0, row1);
     tw.s = sat_setup(o);
@@ -118,6 +117,28 @@ __device__ inline TileWalk tile_walk_setup(const float* __restrict__ uvs, const 
     return tw;
 }
 
+__device__ inline TileWalk tile_walk_setup(const float* __restrict__ uvs, const float* __restrict__ conic, int g,
+                                           int ntx, int nty, float mh, int row0, int row1) {
+    return tile_walk_setup_vals(uvs[g * 2], uvs[g * 2 + 1], conic[g * 3], conic[g * 3 + 1], conic[g * 3 + 2], ntx, nty, mh,
+                                row0, row1);
+}
+
+// the 32-byte binning record of the depth-bucketed path (k_preprocess: u v conic0 conic1 | conic2 z - -): one
+// sector per Gaussian when the records are gathered through a bucket's index list
+struct BinRec {
+    float4 a, b;
+};
+__device__ inline BinRec load_bin_record(const float* __restrict__ rec, int g) {
+    const float4* p = reinterpret_cast<const float4*>(rec) + 2 * (size_t)g;
+    BinRec r;
+    r.a = p[0];
+    r.b = p[1];
+    return r;
+}
+__device__ inline TileWalk tile_walk_setup(const BinRec& r, int ntx, int nty, float mh, int row0, int row1) {
+    return tile_walk_setup_vals(r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, ntx, nty, mh, row0, row1);
+}
+
 __device__ inline float lane_bcast(float x, int src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src));
 }
@@ -133,9 +154,15 @@ __device__ inline int lane_bcast(int x, int src) { return __builtin_amdgcn_readl
 // LPG > 1 (a power of two): LPG consecutive lanes hold the SAME Gaussian (sub = its lane's index among them) and
 // share a small window's candidates round-robin -- for frames with few Gaussians, where one lane per Gaussian leaves
 // the chip a wave or two per SIMD, each a serial chain of tests and atomics (workload B: 90 k Gaussians).
+// want(tile): evaluated BEFORE the separating-axis test of a candidate (depth-bucketed path: a tile whose list is
+// already cut in front of this workgroup's depth bucket costs one LDS read instead of the test).
 constexpr int COOP_MIN = 48;
-template <int LPG = 1, typename F>
-__device__ inline void wave_for_each_tile(bool active, const TileWalk& tw, int ntx, uint64_t payload, F emit, int sub = 0) {
+struct AnyTile {
+    __device__ bool operator()(int) const { return true; }
+};
+template <int LPG = 1, typename F, typename P = AnyTile>
+__device__ inline void wave_for_each_tile(bool active, const TileWalk& tw, int ntx, uint64_t payload, F emit, int sub = 0,
+                                          P want = P()) {
     const Window& w = tw.w;
     const int area = active ? (w.ex - w.sx) * (w.ey - w.sy) : 0;
     if (area > 0 && area <= COOP_MIN) {
@@ -144,7 +171,7 @@ __device__ inline void wave_for_each_tile(bool active, const TileWalk& tw, int n
                 const float l = (float)tx * 16.0f, r = (float)(tx + 1) * 16.0f;
                 for (int ty = w.sy; ty < w.ey; ty++) {
                     const float t = (float)ty * 16.0f, b2 = (float)(ty + 1) * 16.0f;
-                    if (sat_overlaps(tw.s, l, r, t, b2)) emit(ty * ntx + tx, payload);
+                    if (want(ty * ntx + tx) && sat_overlaps(tw.s, l, r, t, b2)) emit(ty * ntx + tx, payload);
                 }
             }
         } else {
@@ -152,7 +179,8 @@ __device__ inline void wave_for_each_tile(bool active, const TileWalk& tw, int n
             for (int c = sub; c < area; c += LPG) {
                 const int cx = c / h;
                 const int tx = w.sx + cx, ty = w.sy + (c - cx * h);
-                if (sat_overlaps(tw.s, (float)tx * 16.0f, (float)(tx + 1) * 16.0f, (float)ty * 16.0f, (float)(ty + 1) * 16.0f))
+                if (want(ty * ntx + tx) &&
+                    sat_overlaps(tw.s, (float)tx * 16.0f, (float)(tx + 1) * 16.0f, (float)ty * 16.0f, (float)(ty + 1) * 16.0f))
                     emit(ty * ntx + tx, payload);
             }
         }
@@ -178,7 +206,8 @@ __device__ inline void wave_for_each_tile(bool active, const TileWalk& tw, int n
         for (int t = lane; t < n; t += 64) {
             const int cx = t / h;
             const int tx = sx + cx, ty = sy + (t - cx * h);
-            if (sat_overlaps(s, (float)tx * 16.0f, (float)(tx + 1) * 16.0f, (float)ty * 16.0f, (float)(ty + 1) * 16.0f))
+            if (want(ty * ntx + tx) &&
+                sat_overlaps(s, (float)tx * 16.0f, (float)(tx + 1) * 16.0f, (float)ty * 16.0f, (float)(ty + 1) * 16.0f))
                 emit(ty * ntx + tx, pl);
         }
     }
@@ -217,7 +246,8 @@ __global__ __launch_bounds__(BIN_BLOCK) void k_tile_count(const float* __restric
 // clear != 0: every count read is set to 0 (the atomic-counter path: the array is k_tile_emit's cursor next)
 __global__ __launch_bounds__(1024) void k_scan_tiles(int* __restrict__ counts, int T,
                                                      int* __restrict__ ranges,
-                                                     const int* __restrict__ v_dev, int t0, int Tb, int clear) {
+                                                     const int* __restrict__ v_dev, int t0, int Tb, int clear,
+                                                     int* __restrict__ host_mirror) {
     __shared__ int s_wave[16];
     __shared__ int s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -255,7 +285,16 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int* __restrict__ counts, i
     }
     if (tid == 0) {
         ranges[T] = s_carry;
-        if (v_dev) ranges[T + 1] = *v_dev;
+        const int V = v_dev ? *v_dev : 0;
+        if (v_dev) ranges[T + 1] = V;
+        // the frame's host read without a copy in the stream: (S, V) straight into the caller's pinned buffer (a
+        // device -> host hipMemcpyAsync of 8 bytes is a ~10 us blit kernel the next launch queues behind)
+        if (host_mirror != nullptr) {
+            host_mirror[0] = s_carry;
+            host_mirror[1] = V;
+            host_mirror[2] = s_carry;
+            __threadfence_system();
+        }
     }
 }
 
@@ -424,6 +463,361 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_emit(
             if (pos < cap) keys[pos] = k;
 #endif
         });
+    }
+}
+
+// ---- depth-bucketed binning ("depth cut") ---------------------------------------------------------------
+// The lists of a dense frame are several times longer than what the render consumes: at workload D a tile has
+// ~2800 entries, no pixel of any tile composites deeper than the 743rd, and the prefix sort already orders only the
+// 1024 nearest -- yet count, emit and sort handle all 12.2 M instances.  Not emitting what lies behind a tile's
+// 1024 nearest entries needs, per tile, the DEPTH below which there are at most 1024 of them -- before the emit.
+// The privatised count pass can provide exactly that if its workgroups are DEPTH BUCKETS instead of arbitrary
+// slices of the Gaussians: row b of the histogram matrix hist[b][t] is then "entries of tile t in depth bucket b",
+// the column scan that turns the rows into offsets is a cumulative depth histogram, and the cut of tile t is the
+// last bucket b*(t) at which it still holds <= GS_SORT_PREFIX entries -- exact counts, no estimate:
+//   k_depth_hist      the visible Gaussians are split into NBK = 1024 depth buckets of about equal population
+//                     (boundaries = quantiles of ~100 k sampled depths that k_cull_count left behind; every
+//                     workgroup derives the same boundaries from a fine histogram) and counted per (partition
+//                     workgroup, bucket)
+//   k_depth_scatter   counting sort of the Gaussian indices by bucket: list[] + bucket offsets boff[NBK + 1]
+//   k_bin_count       workgroup b walks bucket b (32-byte binning records gathered through the list: one sector per
+//                     Gaussian); rows of hist as before
+//   k_bin_colscan     + per tile: b*(t), n'(t) = entries in buckets <= b*(t) (<= 1024; everything if the tile has
+//                     no more than that), n(t) = all entries
+//   k_scan_tiles_cut  tile_ranges from n' (the lists that are emitted), full_ranges from n (where the complete list
+//                     of a tile goes if it has to be repaired), the deepest bucket any tile still wants
+//   k_bin_emit<CUT>   workgroups behind the deepest wanted bucket exit; a candidate tile that is cut in front of the
+//                     bucket is skipped before its separating-axis test
+// A truncated list is a true depth prefix of the complete one (buckets are depth intervals; equal depths share a
+// bucket), completely sorted by the ordinary <= 1024 sort.  It stays exact the way the prefix sort did: the
+// forward raises tile_flags[t] when a truncated tile reaches the end of its list with an unsaturated pixel, and
+// the same call enqueues k_bin_emit<REST> (complete lists of the flagged tiles into an overflow buffer at
+// full_ranges), their sort and a second render; the backward reads a flagged tile's list from the overflow.
+// All of it is enqueued without a host read; the repair kernels exit at once while nothing is flagged.
+constexpr int NBK = PRIV_NB;            // depth buckets == workgroups of the count / emit passes
+constexpr int DC_BLOCK = 1024;
+static_assert(NBK == GS_CUT_BUCKETS && NBK == DC_BLOCK, "one thread per bucket in the partition kernels");
+static_assert(GS_SORT_PREFIX == 1024, "a truncated list must fit the <= 1024 sort of k_tile_sort");
+
+__device__ inline uint32_t sortable_bits_u(float z) {   // (defined again below as sortable_bits: same map)
+    const uint32_t u = __float_as_uint(z);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// first index k in [0, n) with a[k] >= x (n if none); a ascending, in LDS
+__device__ inline int lower_bound_u32(const uint32_t* a, int n, uint32_t x) {
+    int lo = 0, len = n;
+    while (len > 0) {
+        const int half = len >> 1;
+        if (a[lo + half] < x) {
+            lo += half + 1;
+            len -= half + 1;
+        } else {
+            len = half;
+        }
+    }
+    return lo;
+}
+
+// block-wide exclusive prefix of one int per thread (1024 threads); returns the prefix, *total = the sum
+__device__ inline int block_scan_1024(int v, int* s_wave /*[17]*/, int* total) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    __syncthreads();   // s_wave may still be read from a previous call
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int off = 0, sum = 0;
+    for (int w = 0; w < 16; w++) {
+        if (w < wave) off += s_wave[w];
+        sum += s_wave[w];
+    }
+    if (total) *total = sum;
+    return off + incl - v;
+}
+
+// per (partition workgroup, bucket) counts of the visible Gaussians' bucket ids (written by the per-Gaussian stage:
+// preprocess.hip, k_preprocess).  The ids of a thread's elements are loaded before the LDS atomics are issued: one
+// workgroup per CU leaves 4 waves per SIMD, not enough to hide a load -> atomic chain per element.
+__global__ __launch_bounds__(DC_BLOCK) void k_depth_hist(const int* __restrict__ v_dev, CutState cs) {
+    __shared__ int s_cnt[NBK];
+    const int tid = threadIdx.x;
+    s_cnt[tid] = 0;
+    __syncthreads();
+    const int V = *v_dev;
+    const int chunk = (V + DC_PART - 1) / DC_PART;
+    const int v0 = min(V, (int)blockIdx.x * chunk), v1 = min(V, v0 + chunk);
+    for (int base = v0; base < v1; base += 4 * DC_BLOCK) {
+        int b[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int v = base + k * DC_BLOCK + tid;
+            b[k] = v < v1 ? (int)cs.bucket_of[v] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (b[k] >= 0) atomicAdd(&s_cnt[b[k]], 1);
+    }
+    __syncthreads();
+    cs.phist[(size_t)blockIdx.x * NBK + tid] = s_cnt[tid];
+}
+
+// counting sort of the visible indices by bucket.  Thread k owns bucket k: its total over all partition
+// workgroups, the part in front of this workgroup, and (block scan) the bucket's offset.  Inside a
+// (workgroup, bucket) run the order is whatever the LDS atomics hand out -- no result depends on it (tile lists
+// are ordered by unique keys afterwards; counts per (bucket, tile) do not depend on the order).
+__global__ __launch_bounds__(DC_BLOCK) void k_depth_scatter(const int* __restrict__ v_dev, CutState cs) {
+    __shared__ int s_cur[NBK];
+    __shared__ int s_wave[17];
+    const int tid = threadIdx.x;
+    int total = 0, before = 0;
+#pragma unroll 16
+    for (int w = 0; w < DC_PART; w++) {
+        const int c = cs.phist[(size_t)w * NBK + tid];
+        before += w < (int)blockIdx.x ? c : 0;
+        total += c;
+    }
+    int sum;
+    const int base = block_scan_1024(total, s_wave, &sum);
+    s_cur[tid] = base + before;
+    if (blockIdx.x == 0) {
+        cs.boff[tid] = base;
+        if (tid == 0) cs.boff[NBK] = sum;
+    }
+    __syncthreads();
+    const int V = *v_dev;
+    const int chunk = (V + DC_PART - 1) / DC_PART;
+    const int v0 = min(V, (int)blockIdx.x * chunk), v1 = min(V, v0 + chunk);
+    for (int b0 = v0; b0 < v1; b0 += 4 * DC_BLOCK) {
+        int b[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int v = b0 + k * DC_BLOCK + tid;
+            b[k] = v < v1 ? (int)cs.bucket_of[v] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (b[k] >= 0) cs.list[atomicAdd(&s_cur[b[k]], 1)] = b0 + k * DC_BLOCK + tid;
+    }
+}
+
+// k_bin_count of the depth-bucketed path: workgroup b walks the Gaussians of bucket b
+__global__ __launch_bounds__(PRIV_BLOCK) void k_bin_count_buckets(const float* __restrict__ rec, int ntx, int nty, float mh,
+                                                                  int row0, int row1, int* __restrict__ hist,
+                                                                  CutState cs) {
+    extern __shared__ int s_hist[];
+    const int t0 = row0 * ntx, Tb = (row1 - row0) * ntx;
+    for (int t = threadIdx.x; t < Tb; t += PRIV_BLOCK) s_hist[t] = 0;
+    __syncthreads();
+    const int sl = blockIdx.x;
+    const int g0 = cs.boff[sl], g1 = cs.boff[sl + 1];
+    // the next iteration's record (list entry -> 32-byte gather) is in flight while this one's tiles are walked
+    BinRec nxt;
+    bool nxt_active = g0 + (int)threadIdx.x < g1;
+    if (nxt_active) nxt = load_bin_record(rec, cs.list[g0 + threadIdx.x]);
+    for (int base = g0; base < g1; base += PRIV_BLOCK) {   // wave-uniform trip count
+        const BinRec cur = nxt;
+        const bool active = nxt_active;
+        const int i2 = base + PRIV_BLOCK + threadIdx.x;
+        nxt_active = i2 < g1;
+        if (nxt_active) nxt = load_bin_record(rec, cs.list[i2]);
+        TileWalk tw;
+        if (active) tw = tile_walk_setup(cur, ntx, nty, mh, row0, row1);
+        wave_for_each_tile(active, tw, ntx, 0, [&](int tile, uint64_t) { atomicAdd(&s_hist[tile - t0], 1); });
+    }
+    __syncthreads();
+    int* row = hist + (size_t)sl * Tb;
+    for (int t = threadIdx.x; t < Tb; t += PRIV_BLOCK) row[t] = s_hist[t];
+}
+
+// k_bin_colscan + the cut: b*(t) = the last NON-EMPTY bucket at which the tile's cumulative count is <= kcut (the
+// qualifying buckets are a prefix: counts only grow), n'(t) = the count there, n(t) = all.  -1 / 0 when already the
+// first non-empty bucket exceeds kcut (such a tile is rendered from its complete list by the repair pass).
+template <int CS_TILES>
+__global__ __launch_bounds__(1024) void k_bin_colscan_cut(int* __restrict__ hist, int T, int* __restrict__ counts,
+                                                          int* __restrict__ totals, int* __restrict__ bstar, int kcut) {
+    constexpr int CS_SEGS = 1024 / CS_TILES;
+    constexpr int CS_ROWS = NBK / CS_SEGS;
+    __shared__ int s_seg[CS_SEGS][CS_TILES];
+    __shared__ int s_best[CS_SEGS][CS_TILES];
+    __shared__ int s_bn[CS_SEGS][CS_TILES];
+    const int lt = threadIdx.x & (CS_TILES - 1);
+    const int seg = threadIdx.x / CS_TILES;
+    const int t = blockIdx.x * CS_TILES + lt;
+    int* col = hist + (size_t)seg * CS_ROWS * T + t;
+    int sum = 0;
+    if (t < T) {
+#pragma unroll 8
+        for (int r = 0; r < CS_ROWS; r++) sum += col[(size_t)r * T];
+    }
+    s_seg[seg][lt] = sum;
+    __syncthreads();
+    int run = 0;
+    for (int s2 = 0; s2 < seg; s2++) run += s_seg[s2][lt];
+    int best = -1, bn = 0;
+    if (t < T) {
+#pragma unroll 8
+        for (int r = 0; r < CS_ROWS; r++) {
+            const int h = col[(size_t)r * T];
+            col[(size_t)r * T] = run;
+            run += h;
+            if (h > 0 && run <= kcut) {
+                best = seg * CS_ROWS + r;
+                bn = run;
+            }
+        }
+    }
+    s_best[seg][lt] = best;
+    s_bn[seg][lt] = bn;
+    __syncthreads();
+    if (t < T && seg == CS_SEGS - 1) {
+        for (int s2 = 0; s2 < CS_SEGS; s2++)
+            if (s_best[s2][lt] > best) {
+                best = s_best[s2][lt];
+                bn = s_bn[s2][lt];
+            }
+        counts[t] = bn;
+        totals[t] = run;   // the last segment's running count is the column total
+        bstar[t] = best;
+    }
+}
+
+// exclusive prefixes of the kept counts (-> ranges) and of the totals (-> full_ranges), the deepest wanted bucket;
+// clears the frame's flag counter.  One workgroup.  Only [t0, t0 + Tb) was written by the column scan.
+// ranges[T] = S' (entries emitted), ranges[T + 1] = V, ranges[T + 2] = S (all entries): the frame's host read
+__global__ __launch_bounds__(1024) void k_scan_tiles_cut(const int* __restrict__ counts, const int* __restrict__ totals,
+                                                         const int* __restrict__ bstar, int T, int* __restrict__ ranges,
+                                                         int* __restrict__ full_ranges, const int* __restrict__ v_dev,
+                                                         int t0, int Tb, int* __restrict__ ctrl,
+                                                         int* __restrict__ host_mirror) {
+    // both prefixes in one scan: (complete count << 32 | kept count) -- neither half exceeds 2^31
+    __shared__ unsigned long long s_wave[16];
+    __shared__ unsigned long long s_carry;
+    __shared__ int s_bmax;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        s_bmax = -1;
+        s_carry = 0;
+    }
+    __syncthreads();
+    int bmax = -1;
+    for (int base = 0; base < T; base += 4 * 1024) {
+        unsigned long long v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = base + tid * 4 + k;
+            const bool in = i >= t0 && i < t0 + Tb;
+            v[k] = in ? ((unsigned long long)(unsigned)totals[i] << 32) | (unsigned)counts[i] : 0ull;
+            if (in) bmax = max(bmax, bstar[i]);
+            sum += v[k];
+        }
+        unsigned long long incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long n = __shfl_up(incl, d);
+            if (lane >= d) incl += n;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        unsigned long long run = s_carry + incl - sum;
+        for (int w = 0; w < wave; w++) run += s_wave[w];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = base + tid * 4 + k;
+            if (i < T) {
+                ranges[i] = (int)(unsigned)run;
+                full_ranges[i] = (int)(run >> 32);
+            }
+            run += v[k];
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = run;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) bmax = max(bmax, __shfl_xor(bmax, d));
+    if (lane == 0) atomicMax(&s_bmax, bmax);
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long c = s_carry;
+        ranges[T] = (int)(unsigned)c;
+        ranges[T + 1] = v_dev ? *v_dev : 0;
+        ranges[T + 2] = (int)(c >> 32);
+        full_ranges[T] = (int)(c >> 32);
+        ctrl[0] = s_bmax;
+        ctrl[1] = 0;
+        if (host_mirror != nullptr) {   // (see k_scan_tiles)
+            host_mirror[0] = (int)(unsigned)c;
+            host_mirror[1] = v_dev ? *v_dev : 0;
+            host_mirror[2] = (int)(c >> 32);
+            __threadfence_system();
+        }
+    }
+}
+
+// k_bin_emit of the depth-bucketed path.  MODE 1 (cut): keys of the buckets <= b*(t) into the tile's (truncated)
+// segment of `keys`; MODE 2 (rest): the COMPLETE lists of the flagged tiles into the overflow buffer at
+// full_ranges -- the repair pass, exits at once while the frame has no flagged tile.  hist holds, after the column
+// scan, the tile's entries in front of bucket b: the offset in either layout.
+#ifndef GS_CUT_EMIT_BLOCK
+// Only the buckets in front of the deepest cut do anything (42 % of them at workload D): with the count pass's 512
+// threads per bucket a CU is left with one or two 8-wave workgroups; 1024 threads per bucket halve the trips.
+#define GS_CUT_EMIT_BLOCK 1024
+#endif
+template <int MODE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_bin_emit_buckets(const float* __restrict__ rec, int ntx, int nty, float mh,
+                                                                 int row0, int row1, const int* __restrict__ ranges,
+                                                                 const int* __restrict__ hist, uint64_t* __restrict__ keys,
+                                                                 int64_t cap, const int* __restrict__ flags, CutState cs) {
+    extern __shared__ int s_cursor[];
+    const int sl = blockIdx.x;
+    // (the flag counter belongs to the render that follows this emit: cleared here so that a repeated emit + render
+    // of the same frame -- a capacity miss -- starts from zero as well)
+    if (MODE == 1 && sl == 0 && threadIdx.x == 0) cs.ctrl[1] = 0;
+    if (MODE == 1 && sl > cs.ctrl[0]) return;
+    if (MODE == 2 && cs.ctrl[1] == 0) return;
+    const int t0 = row0 * ntx, Tb = (row1 - row0) * ntx;
+    const int* row = hist + (size_t)sl * Tb;
+    for (int t = threadIdx.x; t < Tb; t += BLOCK) {
+        const bool want = MODE == 1 ? sl <= cs.bstar[t0 + t] : flags[t0 + t] != 0;
+        s_cursor[t] = want ? ranges[t0 + t] + row[t] : -1;
+    }
+    const int g0 = cs.boff[sl], g1 = cs.boff[sl + 1];
+    BinRec nxt;
+    int nxt_g = 0;
+    bool nxt_active = g0 + (int)threadIdx.x < g1;
+    if (nxt_active) {
+        nxt_g = cs.list[g0 + threadIdx.x];
+        nxt = load_bin_record(rec, nxt_g);
+    }
+    __syncthreads();
+    for (int base = g0; base < g1; base += BLOCK) {   // wave-uniform trip count
+        const BinRec r = nxt;
+        const int g = nxt_g;
+        const bool active = nxt_active;
+        const int i2 = base + BLOCK + threadIdx.x;
+        nxt_active = i2 < g1;
+        if (nxt_active) {
+            nxt_g = cs.list[i2];
+            nxt = load_bin_record(rec, nxt_g);
+        }
+        TileWalk tw;
+        uint64_t key = 0;
+        if (active) {
+            key = ((uint64_t)sortable_bits_u(r.b.y) << 32) | (uint32_t)g;
+            tw = tile_walk_setup(r, ntx, nty, mh, row0, row1);
+        }
+        wave_for_each_tile(
+            active, tw, ntx, key,
+            [&](int tile, uint64_t k) {
+                const int pos = atomicAdd(&s_cursor[tile - t0], 1);
+                if (pos < cap) keys[pos] = k;
+            },
+            0, [&](int tile) { return s_cursor[tile - t0] >= 0; });
     }
 }
 
@@ -970,6 +1364,55 @@ int sort_flagged_tiles(const int* ranges, const uint64_t* keys, int* sorted, int
     return launch_sort_flagged(ranges, keys, sorted, tile0, nt, S, flags, s);
 }
 
+// repair pass of the depth cut: complete sort of the flagged tiles' lists in the overflow buffer (any length);
+// a small grid walks the flags and exits at once while the frame has none
+__global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_overflow(const int* __restrict__ full_ranges,
+                                                                   uint64_t* __restrict__ okeys, int* __restrict__ osorted,
+                                                                   int tile0, int nt, int64_t cap,
+                                                                   const int* __restrict__ flags,
+                                                                   const int* __restrict__ ctrl) {
+    extern __shared__ uint64_t s_keys[];
+    if (ctrl[1] == 0) return;
+    const int tid = threadIdx.x;
+    for (int t = blockIdx.x; t < nt; t += gridDim.x) {
+        const int tile = tile0 + t;
+        if (flags[tile] == 0) continue;
+        const int s0 = full_ranges[tile];
+        const int n = full_ranges[tile + 1] - s0;
+        if (n <= 0 || (int64_t)s0 + n > cap) continue;
+        if (n <= SORT_MAX_LDS_KEYS) {
+            for (int i = tid; i < n; i += SORT_BLOCK) s_keys[slot(i)] = okeys[s0 + i];
+            __syncthreads();
+            if (n > 1) lds_bitonic_sort(s_keys, n, tid);
+            for (int i = tid; i < n; i += SORT_BLOCK) osorted[s0 + i] = (int)(uint32_t)s_keys[slot(i)];
+        } else {
+            global_sort_tile(okeys + s0, osorted + s0, n, tid);
+        }
+        __syncthreads();
+    }
+}
+
+int depth_cut_repair(const float* bin_records, int N, int ntx, int nty, float mh, int row0, int row1,
+                     const int* full_ranges, int32_t* workspace, int32_t* cut_ws, uint64_t* okeys, int64_t ocap,
+                     int* osorted, const int* flags, hipStream_t s) {
+    const int T = ntx * nty, t0 = row0 * ntx, Tb = (row1 - row0) * ntx;
+    if (Tb <= 0) return GS_OK;
+    const CutState cs = cut_state_of(cut_ws, N, T);
+    k_bin_emit_buckets<2, PRIV_BLOCK><<<NBK, PRIV_BLOCK, sizeof(int) * (size_t)Tb, s>>>(
+        bin_records, ntx, nty, mh, row0, row1, full_ranges, workspace + T, okeys, ocap, flags, cs);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_tile_sort_overflow, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)sort_lds_bytes(SORT_MAX_LDS_KEYS));
+        attr_set = true;
+    }
+    k_tile_sort_overflow<<<Tb < WALK_GRID ? Tb : WALK_GRID, SORT_BLOCK, sort_lds_bytes(SORT_MAX_LDS_KEYS), s>>>(
+        full_ranges, okeys, osorted, t0, Tb, ocap, flags, cs.ctrl);
+    return GS_OK;
+}
+
+int* depth_cut_flag_counter(int32_t* cut_ws, int N, int T) { return cut_state_of(cut_ws, N, T).ctrl + 1; }
+
 }  // namespace gs
 
 using namespace gs;
@@ -1001,7 +1444,7 @@ size_t gs_tile_workspace_ints(int n_tiles) {
 int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visible_count,
                   const int32_t* subset, const int32_t* subset_count, int n_tiles_x, int n_tiles_y,
                   float mh_dist, int tile_row0, int tile_row1, int32_t* workspace,
-                  int32_t* tile_ranges, void* stream) {
+                  int32_t* tile_ranges, int32_t* host_mirror, void* stream) {
     GS_REQUIRE((subset == nullptr) == (subset_count == nullptr),
                "subset and subset_count go together");
     const Items items{visible_count, subset, subset_count};
@@ -1042,7 +1485,7 @@ int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visi
     }
     // (the histogram path writes the counts of the rows' tiles only; the atomic path zero-fills all of them)
     k_scan_tiles<<<1, 1024, 0, s>>>(counts, T, tile_ranges, visible_count, private_hist ? t0 : 0, private_hist ? Tb : T,
-                                    private_hist ? 0 : 1);
+                                    private_hist ? 0 : 1, host_mirror);
     return check_launch("tile_count");
 }
 
@@ -1097,6 +1540,74 @@ int gs_tile_sort_flagged(const int32_t* tile_ranges, const uint64_t* keys, int64
     launch_sort_flagged(tile_ranges, keys, sorted_gaussians, tile_row0 * n_tiles_x,
                         (tile_row1 - tile_row0) * n_tiles_x, S, tile_flags, (hipStream_t)stream);
     return check_launch("tile_sort_flagged");
+}
+
+// ---- depth-bucketed binning (see "depth cut" above) -------------------------------------------------------
+size_t gs_cut_workspace_ints(int n_gaussians, int n_tiles) { return cut_ws_ints(n_gaussians, n_tiles); }
+
+int gs_cut_sample_stride(int n_gaussians) {
+    return n_gaussians <= GS_CUT_MAX_SAMPLES ? 1 : (n_gaussians + GS_CUT_MAX_SAMPLES - 1) / GS_CUT_MAX_SAMPLES;
+}
+
+int gs_cut_supported(int n_tiles_x, int tile_row0, int tile_row1, int n_gaussians) {
+    return use_private((tile_row1 - tile_row0) * n_tiles_x, n_gaussians) ? 1 : 0;
+}
+
+int gs_tile_count_cut(const void* bin_records, int N, const int32_t* visible_count, int n_tiles_x, int n_tiles_y,
+                      float mh_dist, int tile_row0, int tile_row1, int32_t* workspace, int32_t* cut_workspace,
+                      int32_t* tile_ranges, int32_t* full_ranges, int32_t* host_mirror, void* stream) {
+    GS_REQUIRE(n_tiles_x > 0 && n_tiles_y > 0, "tile grid must be positive");
+    GS_REQUIRE(tile_row0 >= 0 && tile_row1 <= n_tiles_y && tile_row0 <= tile_row1, "bad tile row range");
+    GS_REQUIRE(visible_count != nullptr, "visible_count must not be null");
+    hipStream_t s = (hipStream_t)stream;
+    const int T = n_tiles_x * n_tiles_y;
+    const int t0 = tile_row0 * n_tiles_x, Tb = (tile_row1 - tile_row0) * n_tiles_x;
+    GS_REQUIRE(use_private(Tb, N), "the depth-bucketed binning needs the LDS-histogram regime (gs_cut_supported)");
+    const CutState cs = cut_state_of(cut_workspace, N, T);
+    int32_t* counts = workspace;
+    int32_t* hist = workspace + T;
+    k_depth_hist<<<DC_PART, DC_BLOCK, 0, s>>>(visible_count, cs);
+    k_depth_scatter<<<DC_PART, DC_BLOCK, 0, s>>>(visible_count, cs);
+    k_bin_count_buckets<<<NBK, PRIV_BLOCK, sizeof(int) * (size_t)Tb, s>>>((const float*)bin_records, n_tiles_x, n_tiles_y,
+                                                                          mh_dist, tile_row0, tile_row1, hist, cs);
+    if (Tb >= 2048)
+        k_bin_colscan_cut<GS_CS_TILES><<<div_up(Tb, GS_CS_TILES), 1024, 0, s>>>(hist, Tb, counts + t0, cs.totals + t0,
+                                                                                 cs.bstar + t0, GS_SORT_PREFIX);
+    else
+        k_bin_colscan_cut<16><<<div_up(Tb, 16), 1024, 0, s>>>(hist, Tb, counts + t0, cs.totals + t0, cs.bstar + t0,
+                                                              GS_SORT_PREFIX);
+    k_scan_tiles_cut<<<1, 1024, 0, s>>>(counts, cs.totals, cs.bstar, T, tile_ranges, full_ranges, visible_count, t0, Tb,
+                                        cs.ctrl, host_mirror);
+    return check_launch("tile_count_cut");
+}
+
+int gs_tile_emit_sort_cut(const void* bin_records, int N, int n_tiles_x, int n_tiles_y, float mh_dist, int tile_row0,
+                          int tile_row1, const int32_t* tile_ranges, int32_t* workspace, int32_t* cut_workspace,
+                          uint64_t* keys, int64_t S, int32_t* sorted_gaussians, void* stream) {
+    GS_REQUIRE(tile_row0 >= 0 && tile_row1 <= n_tiles_y && tile_row0 <= tile_row1, "bad tile row range");
+    hipStream_t s = (hipStream_t)stream;
+    const int T = n_tiles_x * n_tiles_y;
+    const int t0 = tile_row0 * n_tiles_x, Tb = (tile_row1 - tile_row0) * n_tiles_x;
+    if (S <= 0 || Tb <= 0) return GS_OK;
+    const CutState cs = cut_state_of(cut_workspace, N, T);
+    k_bin_emit_buckets<1, GS_CUT_EMIT_BLOCK><<<NBK, GS_CUT_EMIT_BLOCK, sizeof(int) * (size_t)Tb, s>>>(
+        (const float*)bin_records, n_tiles_x, n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, workspace + T, keys,
+        S, nullptr, cs);
+    // every kept list has at most GS_SORT_PREFIX entries: the wave-level sorts order it completely
+    k_tile_sort<false><<<Tb, SORT_BLOCK, 0, s>>>(tile_ranges, keys, sorted_gaussians, t0, S);
+    return check_launch("tile_emit_sort_cut");
+}
+
+// test / tool access to the cut's per-tile results: copies b*(t), n(t) (device -> device) and the bucket bounds
+int gs_cut_debug_views(int32_t* cut_workspace, int N, int n_tiles, int32_t** bstar, int32_t** totals, uint32_t** bounds,
+                       int32_t** bucket_offsets, int32_t** ctrl) {
+    const CutState cs = cut_state_of(cut_workspace, N, n_tiles);
+    if (bstar) *bstar = cs.bstar;
+    if (totals) *totals = cs.totals;
+    if (bounds) *bounds = cs.bounds;
+    if (bucket_offsets) *bucket_offsets = cs.boff;
+    if (ctrl) *ctrl = cs.ctrl;
+    return GS_OK;
 }
 
 }  // extern "C"

@@ -40,12 +40,16 @@ constexpr int SLAB_WIDTH = 9;   // rgb 3 | opacity 1 | uv 2 | conic 3
 // ---- per-process state: capacity guesses, pinned read buffers, counters ---------------------------------
 struct HintKey {
     int dev, N, T, row0, row1;
+    int mode = 0;   // 1: the frame's lists are depth-cut (their instance count is another quantity)
     bool operator<(const HintKey& o) const {
-        return std::tie(dev, N, T, row0, row1) < std::tie(o.dev, o.N, o.T, o.row0, o.row1);
+        return std::tie(dev, N, T, row0, row1, mode) < std::tie(o.dev, o.N, o.T, o.row0, o.row1, o.mode);
     }
 };
 std::mutex g_mutex;
 std::map<HintKey, int64_t> g_capacity;
+// depth cut (include/gsplat_hip.h "depth-bucketed binning"): capacity of the overflow buffers (the frame's complete
+// instance count) and the complete instance count of the latest frame of a shape (what "auto" decides on)
+std::map<HintKey, int64_t> g_overflow_capacity, g_complete_count;
 struct PinnedRing {
     std::vector<Tensor> bufs;
     std::vector<hipEvent_t> events;
@@ -53,7 +57,7 @@ struct PinnedRing {
 };
 std::map<int, PinnedRing> g_pinned;   // per device
 struct Counters {
-    int64_t frames = 0, speculative = 0, misses = 0, s_min = -1, s_max = -1, slab_copies = 0;
+    int64_t frames = 0, speculative = 0, misses = 0, s_min = -1, s_max = -1, slab_copies = 0, cut_frames = 0;
 } g_counters;
 std::vector<Tensor> g_flag_log;
 Tensor g_last_flags;   // tile_flags of the latest prefix-mode render (tests / tools)
@@ -62,6 +66,28 @@ bool g_sort_prefix = true, g_early_render = true;
 // bands of fewer than 1500 tiles whose lists average >= 192 entries: a multi-GPU rank's band), 1 = always, -1 = never
 int g_segments = 0;
 bool g_band_compact = true;   // multi-GPU: band-compact per-Gaussian stage (OwnerPreprocess)
+// depth cut: 0 = auto (whole frames in the LDS-histogram regime whose lists averaged g_cut_min_mean_list entries or
+// more in an earlier frame of the same shape), 1 = always (where supported), -1 = never
+int g_depth_cut = 0;
+int64_t g_cut_min_mean_list = 2048;
+// the histogram gs_preprocess_forward_cut fills and returns to zero: one per (device, stream), zeroed once
+int32_t* depth_hist_of(const torch::Device& dev, void* stream) {
+    static std::map<std::pair<int, void*>, Tensor> hists;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    auto key = std::make_pair((int)dev.index(), stream);
+    auto it = hists.find(key);
+    if (it == hists.end())
+        it = hists.emplace(key, torch::zeros({GS_CUT_HIST_BINS}, torch::TensorOptions().dtype(torch::kInt32).device(dev))).first;
+    return it->second.data_ptr<int32_t>();
+}
+bool want_depth_cut(const HintKey& shape, int N, int ntx, int row0, int row1, bool whole, int sort_prefix) {
+    if (g_depth_cut < 0 || !whole || !sort_prefix) return false;
+    if (!gs_cut_supported(ntx, row0, row1, N)) return false;
+    if (g_depth_cut > 0) return true;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    auto it = g_complete_count.find(shape);
+    return it != g_complete_count.end() && it->second >= g_cut_min_mean_list * (int64_t)(row1 - row0) * ntx;
+}
 bool want_segments(int64_t n_instances, int64_t n_tiles) {
     if (g_segments == 0) return n_tiles > 0 && n_tiles < 1500 && n_instances >= 192 * n_tiles;
     return g_segments > 0 && n_tiles > 0;
@@ -169,11 +195,20 @@ void require_f32_cuda(const Tensor& t, const char* name, c10::Device dev, std::i
 
 struct RenderOut {
     Tensor buf, image, fw, nsp, seg;   // seg: state for the depth-segmented backward (empty: not segmented)
+    Tensor cut_flags, overflow_sorted;   // depth-cut frames: flagged tiles and their complete lists (else undefined)
+};
+// what gs_render_tiles_cut needs from the frame's binning
+struct CutRef {
+    const float* bin_rec;
+    int32_t *tile_counts, *cut_ws, *full_ranges;
+    int N;
+    float mh;
+    int64_t overflow_capacity;
 };
 
 RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* ranges, Tensor& sorted, Tensor& keys,
                          const Tensor& bg, int W, int H, int row0, int row1, bool whole, int sort_prefix, void* stream,
-                         const HintKey& key, bool exact_count, int64_t image_rows = 0) {
+                         const HintKey& key, bool exact_count, int64_t image_rows = 0, const CutRef* cut = nullptr) {
     const int64_t P = (int64_t)W * H;
     // image_rows > H (multi-GPU, equal bands): the image block holds world_size full bands so that the band
     // images can be all-gathered in place; the kernels only see the first H rows
@@ -191,6 +226,26 @@ RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* 
     r.fw = r.buf.narrow(0, 3 * PI, P).view({H, W});
     r.nsp = r.buf.narrow(0, 3 * PI + P, P).view(torch::kInt32).view({H, W});
     int32_t* tile_cost = reinterpret_cast<int32_t*>(r.buf.data_ptr<float>()) + 3 * PI + 2 * P;
+    if (cut != nullptr) {
+        // depth-cut lists: kept prefixes, then (on the device, only if a tile was flagged) the complete lists of the
+        // flagged tiles from the overflow buffers
+        r.seg = torch::empty({0}, opt);
+        r.cut_flags = torch::empty({T}, opt.dtype(torch::kInt32));
+        r.overflow_sorted = torch::empty({cut->overflow_capacity}, opt.dtype(torch::kInt32));
+        Tensor okeys = torch::empty({cut->overflow_capacity}, opt.dtype(torch::kInt64));
+        timed("gs_render_tiles_prefix", stream, [&] {
+            return gs_render_tiles_cut(packed, rgbr, ranges, sorted.data_ptr<int32_t>(), sorted.size(0), cut->full_ranges,
+                                       cut->bin_rec, cut->N, cut->mh, cut->tile_counts, cut->cut_ws,
+                                       (uint64_t*)okeys.data_ptr<int64_t>(), r.overflow_sorted.data_ptr<int32_t>(),
+                                       cut->overflow_capacity, bg.data_ptr(), W, H, row0, row1,
+                                       r.cut_flags.data_ptr<int32_t>(), r.nsp.data_ptr<int32_t>(), r.fw.data_ptr(),
+                                       r.image.data_ptr(), tile_cost, stream);
+        });
+        std::lock_guard<std::mutex> lock(g_mutex);
+        if (g_flag_log.size() < 512) g_flag_log.push_back(r.cut_flags);
+        g_last_flags = r.cut_flags;
+        return r;
+    }
     const bool segments = segments_for(key, sorted.size(0), exact_count, (int64_t)(row1 - row0) * ntx);
     r.seg = torch::empty({segments ? (int64_t)(gs_render_segment_workspace_bytes(W, H, row0, row1) / 4) : 0}, opt);
     void* seg_p = segments ? r.seg.data_ptr() : nullptr;
@@ -233,25 +288,57 @@ struct Preprocess : public torch::autograd::Function<Preprocess> {
         const int sort_prefix = g_sort_prefix ? GS_SORT_PREFIX : 0;
         void* stream = cur_stream();
 
+        const HintKey shape{(int)dev.index(), N, T, (int)row0, (int)row1, 0};
+        const bool cut = want_depth_cut(shape, N, ntx, (int)row0, (int)row1, whole, sort_prefix);
+        const int stride = cut ? gs_cut_sample_stride(N) : 1;
         const int64_t n_ws = (int64_t)gs_preprocess_workspace_ints(N), n_tc = (int64_t)gs_tile_workspace_ints(T);
-        Arena iar(torch::kInt32, dev, {n_ws, 1, N, N, n_tc, T + 2, (N + 3) / 4});
-        Arena far(torch::kFloat32, dev, {3, 2 * (int64_t)N, 3 * (int64_t)N, 3 * (int64_t)N, N, 3 * (int64_t)N, 12 * (int64_t)N});
+        const int64_t n_cut = cut ? (int64_t)gs_cut_workspace_ints(N, T) : 0;
+        // int blocks: workspace | V | rank | vis_idx | tile workspace | ranges (+ S', V, S) | mask bytes | cut workspace |
+        // complete ranges;  float blocks: centre | uv | xyz_cam | conic | opacity | colour | packed | binning records.
+        // With the depth cut, uv / conic / z live in the 32-byte binning records (columns 0-1, 2-4, 5) and the separate
+        // arrays are not written: the tensors this node hands on are strided views of the records.
+        const int64_t nn = N;
+        Arena iar(torch::kInt32, dev, {n_ws, 1, N, N, n_tc, T + 3, (N + 3) / 4, n_cut, cut ? T + 1 : 0});
+        Arena far(torch::kFloat32, dev, {3, cut ? 0 : 2 * nn, cut ? 0 : 3 * nn, cut ? 0 : 3 * nn, N, 3 * nn, 12 * nn,
+                                         cut ? 8 * nn : 0});
         int32_t *ws = iar.ptr<int32_t>(0), *count = iar.ptr<int32_t>(1), *rank = iar.ptr<int32_t>(2),
                 *vis_idx = iar.ptr<int32_t>(3), *tile_counts = iar.ptr<int32_t>(4), *ranges_buf = iar.ptr<int32_t>(5);
         uint8_t* mask = (uint8_t*)iar.ptr<int32_t>(6);
+        int32_t *cut_ws = iar.ptr<int32_t>(7), *full_ranges = iar.ptr<int32_t>(8);
         float *center = far.ptr<float>(0), *uv = far.ptr<float>(1), *xyz_cam = far.ptr<float>(2), *conic = far.ptr<float>(3),
-              *opa = far.ptr<float>(4), *rgbr = far.ptr<float>(5), *packed = far.ptr<float>(6);
+              *opa = far.ptr<float>(4), *rgbr = far.ptr<float>(5), *packed = far.ptr<float>(6), *bin_rec = far.ptr<float>(7);
+        int32_t* depth_hist = cut ? depth_hist_of(dev, stream) : nullptr;
         timed("gs_preprocess_forward", stream, [&] {
-            return gs_preprocess_forward(xyz.data_ptr(), quaternion.data_ptr(), scale.data_ptr(), opacity.data_ptr(),
-                                         rgb.data_ptr(), has_sh ? sh.data_ptr() : nullptr, n_sh, camera_T_world.data_ptr(),
-                                         K.data_ptr(), N, (int)W, (int)H, (float)near_thresh, (float)far_thresh, (float)padding,
-                                         (float)mh_dist, (int)row0, (int)row1, ws, center, count, mask, rank, vis_idx, uv,
-                                         xyz_cam, conic, opa, rgbr, packed, stream);
+            return gs_preprocess_forward_cut(xyz.data_ptr(), quaternion.data_ptr(), scale.data_ptr(), opacity.data_ptr(),
+                                             rgb.data_ptr(), has_sh ? sh.data_ptr() : nullptr, n_sh, camera_T_world.data_ptr(),
+                                             K.data_ptr(), N, (int)W, (int)H, (float)near_thresh, (float)far_thresh,
+                                             (float)padding, (float)mh_dist, (int)row0, (int)row1, ws, center, count, mask, rank,
+                                             vis_idx, cut ? nullptr : uv, cut ? nullptr : xyz_cam, cut ? nullptr : conic, opa,
+                                             rgbr, packed, cut ? bin_rec : nullptr, cut ? cut_ws : nullptr, depth_hist, stride,
+                                             stream);
         });
+        HintKey key = shape;
+        key.mode = cut ? 1 : 0;
+        int64_t guess = -1, guess_overflow = -1;
+        int32_t* host;
+        hipEvent_t ready;
+        {
+            std::lock_guard<std::mutex> lock(g_mutex);
+            auto it = g_capacity.find(key);
+            if (it != g_capacity.end()) guess = it->second;
+            auto io = g_overflow_capacity.find(key);
+            if (io != g_overflow_capacity.end()) guess_overflow = io->second;
+            std::tie(host, ready) = pinned_slot((int)dev.index());
+        }
         timed("gs_tile_count", stream, [&] {
+            if (cut)
+                return gs_tile_count_cut(bin_rec, N, count, ntx, nty, (float)mh_dist, (int)row0, (int)row1, tile_counts, cut_ws,
+                                         ranges_buf, full_ranges, host, stream);
             return gs_tile_count(uv, conic, N, count, nullptr, nullptr, ntx, nty, (float)mh_dist, (int)row0, (int)row1,
-                                 tile_counts, ranges_buf, stream);
+                                 tile_counts, ranges_buf, host, stream);
         });
+        // (the scan kernel of the count wrote the frame's counts into the pinned slot: no copy in the stream)
+        hip_ok(hipEventRecord(ready, (hipStream_t)stream));
 
         auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(dev);
         Tensor sorted, keys;
@@ -260,74 +347,90 @@ struct Preprocess : public torch::autograd::Function<Preprocess> {
             keys = torch::empty({capacity}, i32.dtype(torch::kInt64));
             if (capacity > 0)
                 timed("gs_tile_emit_sort", stream, [&] {
+                    if (cut)
+                        return gs_tile_emit_sort_cut(bin_rec, N, ntx, nty, (float)mh_dist, (int)row0, (int)row1, ranges_buf,
+                                                     tile_counts, cut_ws, (uint64_t*)keys.data_ptr<int64_t>(), capacity,
+                                                     sorted.data_ptr<int32_t>(), stream);
                     return gs_tile_emit_sort(uv, xyz_cam, conic, N, count, nullptr, nullptr, ntx, nty, (float)mh_dist, (int)row0,
                                              (int)row1, ranges_buf, tile_counts, (uint64_t*)keys.data_ptr<int64_t>(), capacity,
                                              sorted.data_ptr<int32_t>(), sort_prefix, stream);
                 });
         };
 
-        // the frame's only device->host read: (S, V), to size the outputs.  With a capacity guessed from
-        // earlier frames of this shape, emit + sort + render are enqueued before the host waits.
-        const HintKey key{(int)dev.index(), N, T, (int)row0, (int)row1};
-        int64_t guess = -1;
-        int32_t* host;
-        hipEvent_t ready;
-        {
-            std::lock_guard<std::mutex> lock(g_mutex);
-            auto it = g_capacity.find(key);
-            if (it != g_capacity.end()) guess = it->second;
-            std::tie(host, ready) = pinned_slot((int)dev.index());
-        }
-        hip_ok(hipMemcpyAsync(host, ranges_buf + T, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
-        hip_ok(hipEventRecord(ready, (hipStream_t)stream));
-        const bool speculative = guess >= 0;
+        // the frame's only device->host read: (S, V) -- with the depth cut (S' kept, V, S complete) --, to size the
+        // outputs.  With capacities guessed from earlier frames of this shape, emit + sort + render are enqueued before
+        // the host waits.
+        const bool speculative = guess >= 0 && (!cut || guess_overflow >= 0);
+        CutRef cref{bin_rec, tile_counts, cut_ws, full_ranges, N, (float)mh_dist, 0};
         RenderOut out;
         bool rendered = false;
         int64_t capacity = 0;
         if (speculative) {
             capacity = guess;
+            cref.overflow_capacity = guess_overflow;
             emit_sort(capacity);
-            if (g_early_render && sort_prefix && capacity > sort_prefix) {
+            if (g_early_render && sort_prefix && (cut || capacity > sort_prefix)) {
                 out = render_forward(packed, rgbr, ranges_buf, sorted, keys, bg, (int)W, (int)H, (int)row0, (int)row1, whole,
-                                     sort_prefix, stream, key, false);
+                                     sort_prefix, stream, shape, false, 0, cut ? &cref : nullptr);
                 rendered = true;
             }
         }
         hip_ok(hipEventSynchronize(ready));
-        const int64_t S = host[0], V = host[1];
+        const int64_t S = host[0], V = host[1], S_complete = cut ? host[2] : host[0];
+        const bool miss = speculative && (S > capacity || (cut && S_complete > cref.overflow_capacity));
         {
             std::lock_guard<std::mutex> lock(g_mutex);
             g_counters.frames++;
             g_counters.speculative += speculative;
-            g_counters.s_min = g_counters.s_min < 0 ? S : std::min(g_counters.s_min, S);
-            g_counters.s_max = std::max(g_counters.s_max, S);
-            if (!speculative || S > capacity) g_counters.misses += speculative;
+            g_counters.cut_frames += cut;
+            g_counters.s_min = g_counters.s_min < 0 ? S_complete : std::min(g_counters.s_min, S_complete);
+            g_counters.s_max = std::max(g_counters.s_max, S_complete);
+            g_counters.misses += miss;
             int64_t& hint = g_capacity[key];
             hint = std::max(hint, S + S / 4 + 4096);
+            if (cut) {
+                int64_t& ho = g_overflow_capacity[key];
+                ho = std::max(ho, S_complete + S_complete / 4 + 4096);
+            }
+            g_complete_count[shape] = S_complete;
         }
-        if (!speculative || S > capacity) {
+        if (!speculative || miss) {
+            cref.overflow_capacity = S_complete;
             emit_sort(S);
             rendered = false;
         }
         Tensor sorted_g = sorted.narrow(0, 0, S), keys_g = keys.narrow(0, 0, S);
         if (!rendered)
             out = render_forward(packed, rgbr, ranges_buf, sorted_g, keys_g, bg, (int)W, (int)H, (int)row0, (int)row1, whole,
-                                 sort_prefix, stream, key, true);
+                                 sort_prefix, stream, shape, true, 0, cut ? &cref : nullptr);
 
-        Tensor uv_t = far.block(1, 2 * (int64_t)N).view({N, 2}).narrow(0, 0, V);
-        Tensor conic_t = far.block(3, 3 * (int64_t)N).view({N, 3}).narrow(0, 0, V);
+        Tensor uv_t, conic_t;
+        if (cut) {
+            Tensor rec = far.block(7, 8 * nn).view({N, 8}).narrow(0, 0, V);
+            uv_t = rec.narrow(1, 0, 2);
+            conic_t = rec.narrow(1, 2, 3);
+        } else {
+            uv_t = far.block(1, 2 * nn).view({N, 2}).narrow(0, 0, V);
+            conic_t = far.block(3, 3 * nn).view({N, 3}).narrow(0, 0, V);
+        }
         Tensor opa_t = far.block(4, N).view({N, 1}).narrow(0, 0, V);
         Tensor rgbr_t = far.block(5, 3 * (int64_t)N).view({N, 3}).narrow(0, 0, V);
         Tensor packed_t = far.block(6, 12 * (int64_t)N).view({N, 12});
         Tensor ranges_t = iar.block(5, T + 1);
         Tensor mask_t = iar.block(6, (N + 3) / 4).view(torch::kBool).narrow(0, 0, N);
+        // depth-cut frames: what the backward needs to read a repaired tile's complete list (empty otherwise)
+        Tensor flags_t = cut ? out.cut_flags : torch::empty({0}, i32);
+        Tensor full_ranges_t = cut ? iar.block(8, T + 1) : torch::empty({0}, i32);
+        Tensor overflow_t = cut ? out.overflow_sorted : torch::empty({0}, i32);
         ctx->save_for_backward({xyz, quaternion, scale, camera_T_world, K, far.block(0, 3), iar.block(2, N),
                                 far.block(4, N).view({N, 1})});
         ctx->saved_data["n_sh"] = (int64_t)n_sh;
         ctx->saved_data["V"] = V;
         ctx->set_materialize_grads(false);
-        ctx->mark_non_differentiable({packed_t, ranges_t, sorted_g, mask_t, out.image, out.fw, out.nsp, out.seg});
-        return {uv_t, conic_t, opa_t, rgbr_t, packed_t, ranges_t, sorted_g, mask_t, out.image, out.fw, out.nsp, out.seg};
+        ctx->mark_non_differentiable({packed_t, ranges_t, sorted_g, mask_t, out.image, out.fw, out.nsp, out.seg, flags_t,
+                                      full_ranges_t, overflow_t});
+        return {uv_t, conic_t, opa_t, rgbr_t, packed_t, ranges_t, sorted_g, mask_t, out.image, out.fw, out.nsp, out.seg,
+                flags_t, full_ranges_t, overflow_t};
     }
 
     static variable_list backward(AutogradContext* ctx, variable_list g) {
@@ -392,8 +495,8 @@ struct Preprocess : public torch::autograd::Function<Preprocess> {
 struct Render : public torch::autograd::Function<Render> {
     static Tensor forward(AutogradContext* ctx, Tensor uv, Tensor conic, Tensor opacity, Tensor rgbr, Tensor packed,
                           Tensor ranges, Tensor sorted_g, Tensor bg, Tensor image, Tensor fw, Tensor nsp, Tensor seg,
-                          int64_t row0, int64_t row1) {
-        ctx->save_for_backward({packed, rgbr, ranges, sorted_g, bg, nsp, fw, seg});
+                          Tensor cut_flags, Tensor full_ranges, Tensor overflow_sorted, int64_t row0, int64_t row1) {
+        ctx->save_for_backward({packed, rgbr, ranges, sorted_g, bg, nsp, fw, seg, cut_flags, full_ranges, overflow_sorted});
         ctx->saved_data["row0"] = row0;
         ctx->saved_data["row1"] = row1;
         ctx->saved_data["V"] = uv.size(0);
@@ -405,11 +508,12 @@ struct Render : public torch::autograd::Function<Render> {
     }
 
     static variable_list backward(AutogradContext* ctx, variable_list g) {
-        variable_list out(14);
+        variable_list out(17);
         if (!g[0].defined()) return out;
         auto s = ctx->get_saved_variables();
         const Tensor &packed = s[0], &rgbr = s[1], &ranges = s[2], &sorted_g = s[3], &bg = s[4], &nsp = s[5], &fw = s[6],
-                     &seg = s[7];
+                     &seg = s[7], &cut_flags = s[8], &full_ranges = s[9], &overflow_sorted = s[10];
+        const bool cut = cut_flags.numel() > 0;
         const int64_t V = ctx->saved_data["V"].toInt();
         const int H = (int)nsp.size(0), W = (int)nsp.size(1);
         Tensor grad_image = g[0].contiguous();
@@ -429,6 +533,9 @@ struct Render : public torch::autograd::Function<Render> {
                                                  fw.data_ptr(), grad_image.data_ptr(), W, H, row0, row1, slab.data_ptr(),
                                                  ordered ? tile_cost : nullptr, ordered ? tile_cost + T : nullptr,
                                                  segmented ? seg.data_ptr() : nullptr,
+                                                 cut ? cut_flags.data_ptr<int32_t>() : nullptr,
+                                                 cut ? full_ranges.data_ptr<int32_t>() : nullptr,
+                                                 cut ? overflow_sorted.data_ptr<int32_t>() : nullptr,
                                                  (int)ctx->saved_data["bwd_mode"].toInt(), stream);
         });
         Tensor rows = slab.narrow(0, 0, V);
@@ -471,7 +578,7 @@ std::tuple<Tensor, Tensor, Tensor> rasterize(Tensor xyz, Tensor quaternion, Tens
                                rgb.contiguous(), sh, camera_T_world.contiguous(), K.contiguous(), background_rgb.contiguous(),
                                width, height, near_thresh, far_thresh, cull_mask_padding, mh_dist, row0, row1);
     Tensor image = Render::apply(o[0], o[1], o[2], o[3], o[4], o[5], o[6], background_rgb.contiguous(), o[8], o[9], o[10],
-                                 o[11], row0, row1);
+                                 o[11], o[12], o[13], o[14], row0, row1);
     return std::make_tuple(image, o[7], o[0]);
 }
 
@@ -616,7 +723,7 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
         }
         timed("gs_tile_count", stream, [&] {
             return gs_tile_count(bin_uv, bin_conic, N, items_n, subset, subset_n, ntx, nty, (float)fr.mh_dist, row0, row1,
-                                 tile_counts, ranges_buf, stream);
+                                 tile_counts, ranges_buf, nullptr, stream);
         });
         auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(dev);
         Tensor sorted, keys;
@@ -805,7 +912,7 @@ struct OwnerRender : public torch::autograd::Function<OwnerRender> {
                                                  fr.sorted_g.data_ptr<int32_t>(), fr.bg.data_ptr(), fr.out.nsp.data_ptr<int32_t>(),
                                                  fr.out.fw.data_ptr(), grad_image.data_ptr(), W, H, fr.row0, fr.row1,
                                                  slab.data_ptr(), nullptr, nullptr, segmented ? fr.out.seg.data_ptr() : nullptr,
-                                                 fr.bwd_mode, stream);
+                                                 nullptr, nullptr, nullptr, fr.bwd_mode, stream);
         });
         // rows of the send list -> owners; rows of the owned range <- the ranks whose band they reach
         int64_t n_send = 0, n_recv = 0;
@@ -966,6 +1073,7 @@ py::dict counters() {
     d["S_min"] = c.s_min < 0 ? py::object(py::none()) : py::object(py::int_(c.s_min));
     d["S_max"] = c.s_max < 0 ? py::object(py::none()) : py::object(py::int_(c.s_max));
     d["slab_copies"] = c.slab_copies;   // backward calls that could not read the render node's slab in place
+    d["depth_cut_frames"] = c.cut_frames;
     d["prefix_repaired_tiles"] = repaired;
     d["prefix_frames_logged"] = (int64_t)log.size();
     return d;
@@ -1020,6 +1128,10 @@ py::dict collect_timing() {
 }
 
 void set_segments(int mode) { g_segments = mode; }
+void set_depth_cut(int mode, int64_t min_mean_list) {
+    g_depth_cut = mode;
+    if (min_mean_list > 0) g_cut_min_mean_list = min_mean_list;
+}
 void set_band_compact(bool on) { g_band_compact = on; }
 
 void set_modes(bool sort_prefix, bool early_render) {
@@ -1042,6 +1154,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("reset_counters", &reset_counters);
     m.def("set_modes", &set_modes, py::arg("sort_prefix"), py::arg("early_render"));
     m.def("set_segments", &set_segments, py::arg("mode"));
+    m.def("set_depth_cut", &set_depth_cut, py::arg("mode"), py::arg("min_mean_list") = 0);
     m.def("set_band_compact", &set_band_compact, py::arg("on"));
     m.def("last_tile_flags", &last_tile_flags, py::arg("clear") = false);
     m.def("enable_timing", &enable_timing, py::arg("on"), py::arg("only") = std::string());

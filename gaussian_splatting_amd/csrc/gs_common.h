@@ -198,6 +198,44 @@ __host__ __device__ inline bool prefix_sorted_tile(int n, int sort_prefix) {
 int sort_flagged_tiles(const int* ranges, const uint64_t* keys, int* sorted, int tile0, int nt,
                        int64_t S, const int* flags, hipStream_t s);
 
+// ---- depth-bucketed binning (binning.hip "depth cut") ------------------------------------------------------
+constexpr int DC_PART = 256;            // workgroups of the partition passes
+struct CutState {                       // views into the caller's cut workspace (gs_cut_workspace_ints)
+    int* ctrl;                          // [0] deepest bucket any tile wants, [1] flagged tiles of this frame
+    int* totals;                        // [T]  n(t)
+    int* bstar;                         // [T]  b*(t), -1: nothing kept
+    int* boff;                          // [BUCKETS + 1]
+    uint32_t* bounds;                   // [BUCKETS] inclusive upper depth bound (sortable bits) of each bucket
+    int* phist;                         // [DC_PART][BUCKETS]
+    int* list;                          // [N]
+    uint16_t* bucket_of;                // [N]
+};
+__host__ __device__ inline size_t cut_ws_ints(int N, int T) {
+    const size_t n = (size_t)(N > 0 ? N : 1), t = (size_t)(T > 0 ? T : 1);
+    return 8 + 2 * t + (GS_CUT_BUCKETS + 8) + GS_CUT_BUCKETS + (size_t)DC_PART * GS_CUT_BUCKETS + n + (n + 1) / 2 + 16;
+}
+__host__ __device__ inline CutState cut_state_of(int32_t* ws, int N, int T) {
+    const size_t n = (size_t)(N > 0 ? N : 1), t = (size_t)(T > 0 ? T : 1);
+    CutState c;
+    int* p = ws;
+    c.ctrl = p; p += 8;
+    c.totals = p; p += t;
+    c.bstar = p; p += t;
+    c.boff = p; p += GS_CUT_BUCKETS + 8;
+    c.bounds = (uint32_t*)p; p += GS_CUT_BUCKETS;
+    c.phist = p; p += (size_t)DC_PART * GS_CUT_BUCKETS;
+    c.list = p; p += n;
+    c.bucket_of = (uint16_t*)p;
+    return c;
+}
+
+// binning.hip "depth cut": repair pass (complete lists of the flagged tiles -> overflow buffers, sorted) and the
+// frame's flagged-tile counter inside the cut workspace
+int depth_cut_repair(const float* bin_records, int N, int ntx, int nty, float mh, int row0, int row1,
+                     const int* full_ranges, int32_t* workspace, int32_t* cut_ws, uint64_t* okeys, int64_t ocap,
+                     int* osorted, const int* flags, hipStream_t s);
+int* depth_cut_flag_counter(int32_t* cut_ws, int N, int T);
+
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace gs

@@ -64,11 +64,25 @@ __device__ inline bool is_culled(const float* c, const float* __restrict__ K, co
            (uv[1] < fr.v_lo) | (uv[1] > fr.v_hi);
 }
 
+// sortable bits of a depth (monotone float -> uint) and its bin in the quantile histogram: GS_CUT_HIST_BINS bins over
+// the sortable-bit range of [near, far] (a visible Gaussian's depth lies inside)
+__device__ inline uint32_t depth_bits(float z) {
+    const uint32_t u = __float_as_uint(z);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline int depth_bin(float z, const Frustum& fr) {
+    const uint32_t lo = depth_bits(fr.near), hi = depth_bits(fr.far);
+    const uint64_t range = (uint64_t)(hi - lo) + 1;
+    const uint32_t x = min(max(depth_bits(z), lo), hi);
+    return (int)(((uint64_t)(x - lo) * GS_CUT_HIST_BINS) / range);
+}
+
 __global__ __launch_bounds__(PP_BLOCK) void k_cull_count(const float* __restrict__ xyz,
                                                          const float* __restrict__ M,
                                                          const float* __restrict__ K, int N,
                                                          Frustum fr, int* __restrict__ block_counts,
-                                                         float* __restrict__ center) {
+                                                         float* __restrict__ center,
+                                                         int* __restrict__ depth_hist, int sample_stride) {
     __shared__ int s_cnt[PP_BLOCK / GS_WAVE];
     const int g = blockIdx.x * PP_BLOCK + threadIdx.x;
     if (g == 0) camera_center(M, center);
@@ -77,6 +91,11 @@ __global__ __launch_bounds__(PP_BLOCK) void k_cull_count(const float* __restrict
         float c[3], uv[2];
         to_camera(M, xyz[g * 3 + 0], xyz[g * 3 + 1], xyz[g * 3 + 2], c);
         vis = !is_culled(c, K, fr, uv);
+        // depth-bucketed binning (binning.hip "depth cut"): a histogram of the depths of every sample_stride-th
+        // Gaussian that is visible, over [near, far] in sortable-bit (log-like) space; the bucket boundaries are
+        // its quantiles (k_scan_counts).  ~65 k device-scope atomics per frame, behind the kernel's xyz stream.
+        if (depth_hist != nullptr && vis && g % sample_stride == 0)
+            atomicAdd(&depth_hist[depth_bin(c[2], fr)], 1);
     }
     const int n = __popcll(__ballot(vis));
     if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = n;
@@ -85,12 +104,77 @@ __global__ __launch_bounds__(PP_BLOCK) void k_cull_count(const float* __restrict
 }
 
 // exclusive prefix of counts[n] in place of offsets[n]; total -> total_out[0].  One workgroup.
+// depth_hist != nullptr (depth-bucketed binning): also turns k_cull_count's depth histogram into GS_CUT_BUCKETS - 1
+// bucket boundaries of about equal population -- boundary k is where the cumulative sample count reaches
+// (k + 1) / GS_CUT_BUCKETS, interpolated linearly inside its bin -- and returns the histogram to zero for the next
+// frame.  bounds[k] = inclusive upper bound of bucket k in sortable depth bits, bounds[last] = all ones.
+template <bool CUT>
 __global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ counts, int n,
                                                       int* __restrict__ offsets,
-                                                      int* __restrict__ total_out) {
+                                                      int* __restrict__ total_out, int* __restrict__ depth_hist,
+                                                      uint32_t* __restrict__ bounds, Frustum fr) {
     __shared__ int s_wave[16];
     __shared__ int s_carry;
+    __shared__ int s_cum[CUT ? GS_CUT_HIST_BINS : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if constexpr (CUT) {
+        constexpr int PER = GS_CUT_HIST_BINS / 1024;
+        static_assert(GS_CUT_HIST_BINS % 1024 == 0 && GS_CUT_BUCKETS == 1024, "one thread per bucket, PER bins per thread");
+        int v[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            v[k] = depth_hist[tid * PER + k];
+            depth_hist[tid * PER + k] = 0;
+            sum += v[k];
+        }
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int run = incl - sum, valid = 0;
+        for (int w = 0; w < 16; w++) {
+            if (w < wave) run += s_wave[w];
+            valid += s_wave[w];
+        }
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            run += v[k];
+            s_cum[tid * PER + k] = run;
+        }
+        __syncthreads();
+        uint32_t bound = 0xffffffffu;
+        if (tid < GS_CUT_BUCKETS - 1 && valid > 0) {
+            // target count as a fraction: (tid + 1) * valid / BUCKETS, kept exact as target_num / BUCKETS
+            const int64_t target_num = (int64_t)(tid + 1) * valid;
+            int lo_i = 0, len = GS_CUT_HIST_BINS;
+            while (len > 0) {   // first bin j with cum[j] * BUCKETS >= target_num
+                const int half = len >> 1;
+                if ((int64_t)s_cum[lo_i + half] * GS_CUT_BUCKETS < target_num) {
+                    lo_i += half + 1;
+                    len -= half + 1;
+                } else {
+                    len = half;
+                }
+            }
+            const int j = min(lo_i, GS_CUT_HIST_BINS - 1);
+            const int64_t prev = j > 0 ? s_cum[j - 1] : 0, h = max(s_cum[j] - (int)prev, 1);
+            // position inside bin j: (target - prev) / h of its width
+            const uint32_t lo = depth_bits(fr.near), hi = depth_bits(fr.far);
+            const uint64_t range = (uint64_t)(hi - lo) + 1;
+            // (double arithmetic: the boundaries only have to be ascending and the same for everybody who reads
+            // them -- this workgroup is their one source; every step below is monotone in the position)
+            const double frac = (double)(target_num - prev * GS_CUT_BUCKETS) / ((double)h * GS_CUT_BUCKETS);   // (0, 1]
+            const double pos = ((double)j + frac) / (double)GS_CUT_HIST_BINS;                                // (0, 1]
+            const uint64_t b = (uint64_t)lo + (uint64_t)(pos * (double)range);
+            bound = (uint32_t)min(b, (uint64_t)hi);
+        }
+        if (tid < GS_CUT_BUCKETS) bounds[tid] = bound;
+        __syncthreads();   // s_wave is reused below
+    }
     if (tid == 0) s_carry = 0;
     __syncthreads();
     for (int base = 0; base < n; base += 4096) {
@@ -138,6 +222,10 @@ struct PreOut {
     int* vis_idx;     // [V]    visible -> Gaussian
     int* rank;        // [N]    Gaussian -> visible index or -1
     uint8_t* culled;  // [N]    culling mask (1 = culled), rasterize.py:33-49
+    // depth-bucketed binning (binning.hip "depth cut"), all three or none:
+    float* bin_rec;             // [V,8]  u v conic0 conic1 | conic2 z 0 0 -- what the binning reads, one 32-byte sector
+    const uint32_t* bounds;     // [GS_CUT_BUCKETS] bucket boundaries (k_scan_counts)
+    uint16_t* bucket_of;        // [V]    the visible Gaussian's depth bucket
 };
 
 // tile-row band of a multi-GPU rank and what is needed to evaluate the candidate window
@@ -165,8 +253,13 @@ __global__ __launch_bounds__(PP_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))
     constexpr int SHW = 3 * (N_SH - 1);
     constexpr int HALF = PP_BLOCK / 2;
     __shared__ alignas(16) float s_sh[(N_SH > 1 && !BAND) ? HALF * SHW : 4];
+    __shared__ uint32_t s_bounds[BAND ? 1 : GS_CUT_BUCKETS];
     const int g = blockIdx.x * PP_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if constexpr (!BAND) {
+        if (o.bin_rec != nullptr)
+            for (int k = threadIdx.x; k < GS_CUT_BUCKETS; k += PP_BLOCK) s_bounds[k] = o.bounds[k];
+    }
     bool vis = false;
     float c[3] = {0, 0, 1}, uv[2] = {0, 0}, p[3] = {0, 0, 0};
     if (g < N) {
@@ -189,11 +282,15 @@ __global__ __launch_bounds__(PP_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))
     bool in_band = true;
     if (act) {
         o.vis_idx[v] = g;
-        o.uv[v * 2 + 0] = uv[0];
-        o.uv[v * 2 + 1] = uv[1];
-        o.xyz_cam[v * 3 + 0] = c[0];
-        o.xyz_cam[v * 3 + 1] = c[1];
-        o.xyz_cam[v * 3 + 2] = c[2];
+        if (o.uv != nullptr) {
+            o.uv[v * 2 + 0] = uv[0];
+            o.uv[v * 2 + 1] = uv[1];
+        }
+        if (o.xyz_cam != nullptr) {
+            o.xyz_cam[v * 3 + 0] = c[0];
+            o.xyz_cam[v * 3 + 1] = c[1];
+            o.xyz_cam[v * 3 + 2] = c[2];
+        }
 
         const float q4[4] = {quat[g * 4 + 0], quat[g * 4 + 1], quat[g * 4 + 2], quat[g * 4 + 3]};
         const float s3[3] = {scale[g * 3 + 0], scale[g * 3 + 1], scale[g * 3 + 2]};
@@ -207,12 +304,34 @@ __global__ __launch_bounds__(PP_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))
         J6[4] = K[4] / c[2];
         J6[5] = -K[4] * c[1] / (c[2] * c[2]);
         conic_of(J6, W, S9, c3);
-        o.conic[v * 3 + 0] = c3[0];
-        o.conic[v * 3 + 1] = c3[1];
-        o.conic[v * 3 + 2] = c3[2];
+        if (o.conic != nullptr) {
+            o.conic[v * 3 + 0] = c3[0];
+            o.conic[v * 3 + 1] = c3[1];
+            o.conic[v * 3 + 2] = c3[2];
+        }
 
         opa = sigmoid_det(opacity[g]);
         o.opacity[v] = opa;
+        if constexpr (!BAND) {
+            if (o.bin_rec != nullptr) {
+                float4* br = reinterpret_cast<float4*>(o.bin_rec) + 2 * (size_t)v;
+                br[0] = make_float4(uv[0], uv[1], c3[0], c3[1]);
+                br[1] = make_float4(c3[2], c[2], 0.0f, 0.0f);
+                // the depth bucket: first boundary >= the depth's sortable bits (equal depths share a bucket)
+                const uint32_t x = depth_bits(c[2]);
+                int lo_i = 0, len = GS_CUT_BUCKETS - 1;
+                while (len > 0) {
+                    const int half = len >> 1;
+                    if (s_bounds[lo_i + half] < x) {
+                        lo_i += half + 1;
+                        len -= half + 1;
+                    } else {
+                        len = half;
+                    }
+                }
+                o.bucket_of[v] = (uint16_t)lo_i;
+            }
+        }
 
         if constexpr (BAND) {
             const float a = c3[0] + 0.25f, b = c3[1] / 2.0f, cc = c3[2] + 0.25f;   // tile_culling.cu:142-144
@@ -604,15 +723,21 @@ extern "C" {
 
 size_t gs_preprocess_workspace_ints(int N) { return (size_t)div_up(N > 0 ? N : 1, PP_BLOCK) * 2 + 8; }
 
-int gs_preprocess_forward(const void* xyz, const void* quaternion, const void* scale,
-                          const void* opacity, const void* rgb, const void* sh, int n_sh,
-                          const void* camera_T_world, const void* K, int N, int W, int H,
-                          float near_thresh, float far_thresh, float cull_mask_padding,
-                          float mh_dist, int band_row0, int band_row1,
-                          int32_t* workspace, void* camera_center, int32_t* visible_count,
-                          uint8_t* culling_mask, int32_t* rank, int32_t* vis_idx, void* uv,
-                          void* xyz_camera_frame, void* conic, void* opacity_act, void* rgb_render,
-                          void* packed, void* stream) {
+int gs_preprocess_forward_cut(const void* xyz, const void* quaternion, const void* scale,
+                              const void* opacity, const void* rgb, const void* sh, int n_sh,
+                              const void* camera_T_world, const void* K, int N, int W, int H,
+                              float near_thresh, float far_thresh, float cull_mask_padding,
+                              float mh_dist, int band_row0, int band_row1,
+                              int32_t* workspace, void* camera_center, int32_t* visible_count,
+                              uint8_t* culling_mask, int32_t* rank, int32_t* vis_idx, void* uv,
+                              void* xyz_camera_frame, void* conic, void* opacity_act, void* rgb_render,
+                              void* packed, void* bin_records, int32_t* cut_workspace, int32_t* depth_hist,
+                              int sample_stride, void* stream) {
+    GS_REQUIRE((bin_records == nullptr) == (cut_workspace == nullptr) && (bin_records == nullptr) == (depth_hist == nullptr),
+               "bin_records, cut_workspace and depth_hist go together");
+    GS_REQUIRE(depth_hist == nullptr || sample_stride >= 1, "sample_stride must be gs_cut_sample_stride(N)");
+    GS_REQUIRE(bin_records != nullptr || (uv != nullptr && xyz_camera_frame != nullptr && conic != nullptr),
+               "uv, xyz_camera_frame and conic may only be omitted together with bin_records");
     GS_REQUIRE(n_sh == 1 || sh != nullptr, "sh must be given when n_sh > 1");
     hipStream_t s = (hipStream_t)stream;
     const Frustum fr = make_frustum(W, H, near_thresh, far_thresh, cull_mask_padding);
@@ -620,8 +745,16 @@ int gs_preprocess_forward(const void* xyz, const void* quaternion, const void* s
     int* block_counts = workspace;
     int* block_offsets = workspace + nb;
     k_cull_count<<<nb, PP_BLOCK, 0, s>>>((const float*)xyz, (const float*)camera_T_world,
-                                         (const float*)K, N, fr, block_counts, (float*)camera_center);
-    k_scan_counts<<<1, 1024, 0, s>>>(block_counts, nb, block_offsets, visible_count);
+                                         (const float*)K, N, fr, block_counts, (float*)camera_center, depth_hist,
+                                         sample_stride > 0 ? sample_stride : 1);
+    const int n_tiles = ((W + GS_TILE - 1) / GS_TILE) * ((H + GS_TILE - 1) / GS_TILE);
+    CutState cs{};
+    if (cut_workspace != nullptr) {
+        cs = cut_state_of(cut_workspace, N, n_tiles);
+        k_scan_counts<true><<<1, 1024, 0, s>>>(block_counts, nb, block_offsets, visible_count, depth_hist, cs.bounds, fr);
+    } else {
+        k_scan_counts<false><<<1, 1024, 0, s>>>(block_counts, nb, block_offsets, visible_count, nullptr, nullptr, fr);
+    }
     PreOut o;
     o.uv = (float*)uv;
     o.conic = (float*)conic;
@@ -632,6 +765,9 @@ int gs_preprocess_forward(const void* xyz, const void* quaternion, const void* s
     o.vis_idx = vis_idx;
     o.rank = rank;
     o.culled = culling_mask;
+    o.bin_rec = (float*)bin_records;
+    o.bounds = cs.bounds;
+    o.bucket_of = cs.bucket_of;
     Band band;
     band.ntx = (W + GS_TILE - 1) / GS_TILE;
     band.nty = (H + GS_TILE - 1) / GS_TILE;
@@ -640,6 +776,7 @@ int gs_preprocess_forward(const void* xyz, const void* quaternion, const void* s
     band.mh = mh_dist;
     GS_REQUIRE(band_row0 >= 0 && band_row1 <= band.nty && band_row0 <= band_row1, "bad tile row band");
     const bool banded = !(band_row0 == 0 && band_row1 == band.nty);
+    GS_REQUIRE(!(banded && bin_records != nullptr), "the depth-bucketed binning serves whole frames");
     if (banded) {
         DISPATCH_SH(n_sh, (k_preprocess<N_SH, true><<<nb, PP_BLOCK, 0, s>>>(
                               (const float*)xyz, (const float*)quaternion, (const float*)scale,
@@ -669,8 +806,8 @@ int gs_band_project(const void* xyz, const void* scale, const void* opacity, con
     int* block_counts = workspace;
     int* block_offsets = workspace + nb;
     k_cull_count<<<nb, PP_BLOCK, 0, s>>>((const float*)xyz, (const float*)camera_T_world, (const float*)K, N, fr,
-                                         block_counts, (float*)camera_center);
-    k_scan_counts<<<1, 1024, 0, s>>>(block_counts, nb, block_offsets, visible_count);
+                                         block_counts, (float*)camera_center, nullptr, 1);
+    k_scan_counts<false><<<1, 1024, 0, s>>>(block_counts, nb, block_offsets, visible_count, nullptr, nullptr, fr);
     BandRows rows;
     for (int i = 0; i <= GS_MAX_RANKS; i++) rows.v[i] = i <= G ? band_rows[i] : 0;
     const int nty = (H + GS_TILE - 1) / GS_TILE;
@@ -681,6 +818,21 @@ int gs_band_project(const void* xyz, const void* scale, const void* opacity, con
     // per-block bit counts by visible index: the first block of gs_halo_workspace_ints' layout
     k_band_bit_counts<<<nb, PP_BLOCK, 0, s>>>(mask, visible_count, G, halo_workspace, nb);
     return check_launch("band_project");
+}
+
+int gs_preprocess_forward(const void* xyz, const void* quaternion, const void* scale,
+                          const void* opacity, const void* rgb, const void* sh, int n_sh,
+                          const void* camera_T_world, const void* K, int N, int W, int H,
+                          float near_thresh, float far_thresh, float cull_mask_padding,
+                          float mh_dist, int band_row0, int band_row1,
+                          int32_t* workspace, void* camera_center, int32_t* visible_count,
+                          uint8_t* culling_mask, int32_t* rank, int32_t* vis_idx, void* uv,
+                          void* xyz_camera_frame, void* conic, void* opacity_act, void* rgb_render,
+                          void* packed, void* stream) {
+    return gs_preprocess_forward_cut(xyz, quaternion, scale, opacity, rgb, sh, n_sh, camera_T_world, K, N, W, H, near_thresh,
+                                     far_thresh, cull_mask_padding, mh_dist, band_row0, band_row1, workspace, camera_center,
+                                     visible_count, culling_mask, rank, vis_idx, uv, xyz_camera_frame, conic, opacity_act,
+                                     rgb_render, packed, nullptr, nullptr, nullptr, 0, stream);
 }
 
 int gs_preprocess_forward_list(const void* xyz, const void* quaternion, const void* scale, const void* rgb, const void* sh,

@@ -551,7 +551,8 @@ __device__ __forceinline__ void render_tile_fwd(
     T* __restrict__ fw_out, T* __restrict__ image, int sort_prefix, int* __restrict__ tile_flags,
     bool flagged_only, int64_t cap, int* __restrict__ tile_cost = nullptr,
     const T* __restrict__ src_opacity = nullptr, const T* __restrict__ src_conic = nullptr,
-    const SegState seg = SEG_NONE) {
+    const SegState seg = SEG_NONE, const int* __restrict__ full_ranges = nullptr,
+    int* __restrict__ flag_counter = nullptr) {
     static_assert(!CK || (sizeof(T) == 4 && N_SH == 1), "segment checkpoints: the fused renderer's kernel only");
     constexpr bool fast = sizeof(T) == 4;
     // the tile's own duration in 16-cycle units: the launch-order key of the backward (k_tile_order)
@@ -575,6 +576,9 @@ __device__ __forceinline__ void render_tile_fwd(
     // prefix mode (binning.hip "prefix sort"): only the first sort_prefix entries are there
     const bool prefix_only = !flagged_only && prefix_sorted_tile(n_tile, sort_prefix);
     const int n_list = prefix_only ? sort_prefix : n_tile;
+    // depth cut (binning.hip "depth cut"): `ranges` describe the kept depth prefix of every list, full_ranges the
+    // complete ones; a tile whose list was cut short and that reaches its end unsaturated is flagged and redone
+    const bool truncated = !flagged_only && full_ranges != nullptr && full_ranges[tile + 1] - full_ranges[tile] > n_tile;
 
     T Y[N_SH];
     if constexpr (N_SH > 1) {
@@ -678,8 +682,16 @@ __device__ __forceinline__ void render_tile_fwd(
                         }
                         if (!(alpha < Thr<T>::alpha_min())) {               // render.cu:145
                             GS_STAT_SET(st_hit);
-                            fw = 1.0 - acc;
-                            const T weight = alpha * (1.0 - acc);           // double, narrowed
+                            // render.cu:149-150: final_weight = 1.0 - acc and weight = alpha * (1.0 - acc), the literal
+                            // making both double expressions that are narrowed to float -- six fp64-rate instructions
+                            // per contributing visit when written that way.  acc is 0 or >= 1/255 here (it only grows,
+                            // and the first weight is an alpha >= 1/255), so 1.0 - (double)acc is EXACT; hence
+                            // (a) its narrowing is the correctly rounded float difference, i.e. the float subtraction;
+                            // (b) alpha (1 - acc) = alpha - alpha acc as real numbers, and one double fma rounds that
+                            // once, exactly as the reference's double multiplication rounds its exact operands.
+                            // Same bits, four fp64-rate instructions and one fp32.
+                            fw = 1.0f - acc;
+                            const T weight = (T)__builtin_fma((double)alpha, -(double)acc, (double)alpha);
                             img[0] += r.g2.y * weight;
                             img[1] += r.g2.z * weight;
                             img[2] += r.g2.w * weight;
@@ -794,8 +806,12 @@ __device__ __forceinline__ void render_tile_fwd(
     GS_STAT_FLUSH(0);
     if (tile_cost != nullptr && tid == 0)
         tile_cost[tile] = (int)min((__builtin_readcyclecounter() - cost_c0) >> 4, 0x3fffffffull);
-    // an unsaturated pixel at the end of the prefix: the tile is redone from its full list
-    if (tile_flags != nullptr && !flagged_only && tid == 0) tile_flags[tile] = prefix_only && !all_done;
+    // an unsaturated pixel at the end of the prefix / of the cut list: the tile is redone from its full list
+    if (tile_flags != nullptr && !flagged_only && tid == 0) {
+        const bool flag = (prefix_only || truncated) && !all_done;
+        tile_flags[tile] = flag;
+        if (flag && flag_counter != nullptr) atomicAdd(flag_counter, 1);
+    }
 
     if constexpr (CK) {
         if (!wave_fin) write_record();   // the segment the list (or its ordered prefix) ended in
@@ -846,12 +862,13 @@ __global__ __launch_bounds__(RB) void k_render_fwd(
     const int* __restrict__ ranges, const int* __restrict__ sorted, const T* __restrict__ bg,
     int W, int H, int ntx, int tile0, int nt, int* __restrict__ nsp_out, T* __restrict__ fw_out,
     T* __restrict__ image, int sort_prefix, int* __restrict__ tile_flags, int64_t cap,
-    int* __restrict__ tile_cost, const T* __restrict__ src_opacity, const T* __restrict__ src_conic) {
+    int* __restrict__ tile_cost, const T* __restrict__ src_opacity, const T* __restrict__ src_conic,
+    const int* __restrict__ full_ranges, int* __restrict__ flag_counter) {
     const int t_local = tile_of_block(blockIdx.x, nt);
     if (t_local >= nt) return;
     render_tile_fwd<T, N_SH>(tile0 + t_local, packed, rgb, view_dir, ranges, sorted, bg, W, H, ntx,
                              nsp_out, fw_out, image, sort_prefix, tile_flags, false, cap, tile_cost, src_opacity,
-                             src_conic);
+                             src_conic, SEG_NONE, full_ranges, flag_counter);
 }
 
 // the fused renderer's forward that also leaves the state for the depth-segmented backward
@@ -877,7 +894,9 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(GS_FWD_CK_WA
     const float* __restrict__ packed, const float* __restrict__ rgb, const int* __restrict__ ranges,
     const int* __restrict__ sorted, const float* __restrict__ bg, int W, int H, int ntx, int tile0,
     int nt, int* __restrict__ nsp_out, float* __restrict__ fw_out, float* __restrict__ image,
-    int* __restrict__ tile_flags, int64_t cap, int* __restrict__ tile_cost, const SegState seg) {
+    int* __restrict__ tile_flags, int64_t cap, int* __restrict__ tile_cost, const SegState seg,
+    const int* __restrict__ flag_counter) {
+    if (flag_counter != nullptr && *flag_counter == 0) return;   // (depth cut: no tile of the frame is flagged)
     for (int t = blockIdx.x; t < nt; t += gridDim.x) {
         if (tile_flags[tile0 + t] == 0) continue;
         render_tile_fwd<float, 1, CK>(tile0 + t, packed, rgb, nullptr, ranges, sorted, bg, W, H, ntx,
@@ -1037,7 +1056,8 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     const int* __restrict__ nsp_in, const T* __restrict__ fw_in, const T* __restrict__ grad_image,
     int W, int H, int ntx, int tile0, int nt, T* __restrict__ g_rgb, T* __restrict__ g_opa,
     T* __restrict__ g_uv, T* __restrict__ g_conic, int slab, int exact, const int* __restrict__ tile_order,
-    const T* __restrict__ src_opacity, const T* __restrict__ src_conic, const SegState seg) {
+    const T* __restrict__ src_opacity, const T* __restrict__ src_conic, const SegState seg,
+    const int* __restrict__ cut_flags, const int* __restrict__ full_ranges, const int* __restrict__ overflow_sorted) {
     constexpr bool fast = sizeof(T) == 4;
     constexpr int CW = ColW<N_SH>::value;
     constexpr int C = 3 * N_SH;
@@ -1084,8 +1104,14 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const PixelMap px = pixel_of_thread(tile % ntx, tile / ntx, tid);
     const bool valid = px.u < W && px.v < H;
-    const int s0 = ranges[tile];
-    const int n_tile = ranges[tile + 1] - s0;
+    int s0 = ranges[tile];
+    int n_tile = ranges[tile + 1] - s0;
+    // depth cut: a tile the forward had to redo from its complete list reads that list from the overflow buffer
+    if (cut_flags != nullptr && cut_flags[tile] != 0) {
+        s0 = full_ranges[tile];
+        n_tile = full_ranges[tile + 1] - s0;
+        sorted = overflow_sorted;
+    }
     if (n_tile <= 0) return;
 
     int nsp = 0;
@@ -1740,7 +1766,8 @@ static int launch_render_fwd(const void* packed_or_uvs, const void* opacity, con
                                             sorted_gaussians, (const T*)background_rgb, W, H, ntx,
                                             tile_row0 * ntx, nt, num_splats_per_pixel,
                                             (T*)final_weight_per_pixel, (T*)image, 0,
-                                            nullptr, INT64_MAX, nullptr, (const T*)opacity, (const T*)conic))));
+                                            nullptr, INT64_MAX, nullptr, (const T*)opacity, (const T*)conic, nullptr,
+                                            nullptr))));
     return check_launch("render_tiles");
 }
 
@@ -1798,7 +1825,8 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
         k_render_fwd<float, 1><<<grid, RB, 0, s>>>(
             (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
             (const float*)background_rgb, W, H, ntx, t0, nt, num_splats_per_pixel,
-            (float*)final_weight_per_pixel, (float*)image, GS_SORT_PREFIX, tile_flags, S, tile_cost, nullptr, nullptr);
+            (float*)final_weight_per_pixel, (float*)image, GS_SORT_PREFIX, tile_flags, S, tile_cost, nullptr, nullptr,
+            nullptr, nullptr);
     if (S > GS_SORT_PREFIX) {
         // 2. + 3. flagged tiles: full sort, render again (no-ops on a dense scene)
         sort_flagged_tiles(tile_ranges, keys, sorted_gaussians, t0, nt, S, tile_flags, s);
@@ -1806,9 +1834,43 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
         again<<<nt < 512 ? nt : 512, RB, 0, s>>>(
             (const float*)packed, (const float*)rgb, tile_ranges, sorted_gaussians,
             (const float*)background_rgb, W, H, ntx, t0, nt, num_splats_per_pixel,
-            (float*)final_weight_per_pixel, (float*)image, tile_flags, S, tile_cost, seg);
+            (float*)final_weight_per_pixel, (float*)image, tile_flags, S, tile_cost, seg, nullptr);
     }
     return check_launch("render_tiles_prefix");
+}
+
+// the fused renderer's forward on depth-cut lists (binning.hip "depth cut"; gs_tile_count_cut / gs_tile_emit_sort_cut)
+int gs_render_tiles_cut(const void* packed, const void* rgb, const int32_t* tile_ranges, const int32_t* sorted_gaussians,
+                        int64_t S, const int32_t* full_ranges, const void* bin_records, int N, float mh_dist,
+                        int32_t* workspace, int32_t* cut_workspace, uint64_t* overflow_keys, int32_t* overflow_sorted,
+                        int64_t overflow_capacity, const void* background_rgb, int W, int H, int tile_row0, int tile_row1,
+                        int32_t* tile_flags, int32_t* num_splats_per_pixel, void* final_weight_per_pixel, void* image,
+                        int32_t* tile_cost, void* stream) {
+    GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
+    GS_REQUIRE(tile_flags != nullptr && full_ranges != nullptr, "tile_flags and full_ranges must not be null");
+    if (int e = check_rows(H, tile_row0, tile_row1)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    const int ntx = (W + 15) / 16, nty = (H + 15) / 16;
+    const int nt = (tile_row1 - tile_row0) * ntx;
+    if (nt == 0) return GS_OK;
+    const int grid = render_grid(nt);
+    const int t0 = tile_row0 * ntx;
+    int* flag_counter = depth_cut_flag_counter(cut_workspace, N, ntx * nty);
+    // 1. every tile from its kept (completely sorted) depth prefix; raises the flags
+    k_render_fwd<float, 1><<<grid, RB, 0, s>>>(
+        (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians, (const float*)background_rgb, W, H,
+        ntx, t0, nt, num_splats_per_pixel, (float*)final_weight_per_pixel, (float*)image, 0, tile_flags, S, tile_cost,
+        nullptr, nullptr, full_ranges, flag_counter);
+    // 2. + 3. flagged tiles: complete lists into the overflow buffers, sorted, rendered again (all three exit at once
+    // while the frame has no flagged tile)
+    if (int e = depth_cut_repair((const float*)bin_records, N, ntx, nty, mh_dist, tile_row0, tile_row1, full_ranges, workspace,
+                                 cut_workspace, overflow_keys, overflow_capacity, overflow_sorted, tile_flags, s))
+        return e;
+    k_render_fwd_flagged<false><<<nt < 512 ? nt : 512, RB, 0, s>>>(
+        (const float*)packed, (const float*)rgb, full_ranges, overflow_sorted, (const float*)background_rgb, W, H, ntx, t0,
+        nt, num_splats_per_pixel, (float*)final_weight_per_pixel, (float*)image, tile_flags, overflow_capacity, tile_cost,
+        SEG_NONE, flag_counter);
+    return check_launch("render_tiles_cut");
 }
 
 static int launch_render_bwd(const void* packed_or_uvs, const void* opacity, const void* conic, const void* rgb,
@@ -1835,7 +1897,7 @@ static int launch_render_bwd(const void* packed_or_uvs, const void* opacity, con
                                      (const T*)grad_image, W, H, ntx, tile_row0 * ntx, nt,
                                      (T*)grad_rgb, (T*)grad_opacity, (T*)grad_uv,
                                      (T*)grad_conic, 0, exact, nullptr, (const T*)opacity,
-                                     (const T*)conic, SEG_NONE))));
+                                     (const T*)conic, SEG_NONE, nullptr, nullptr, nullptr))));
     return check_launch("render_tiles_backward");
 }
 
@@ -1872,9 +1934,12 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
                                   const void* final_weight_per_pixel, const void* grad_image, int W,
                                   int H, int tile_row0, int tile_row1, void* grad_slab,
                                   const int32_t* tile_cost, int32_t* tile_order, const void* segment_state,
+                                  const int32_t* cut_flags, const int32_t* full_ranges, const int32_t* overflow_sorted,
                                   int backward_mode, void* stream) {
     GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
     GS_REQUIRE((tile_cost == nullptr) == (tile_order == nullptr), "tile_cost and tile_order go together");
+    GS_REQUIRE((cut_flags == nullptr) == (full_ranges == nullptr) && (cut_flags == nullptr) == (overflow_sorted == nullptr),
+               "cut_flags, full_ranges and overflow_sorted go together");
     GS_REQUIRE(segment_state == nullptr || ((uintptr_t)segment_state & 15) == 0, "segment_state must be 16-byte aligned");
     if (int e = check_rows(H, tile_row0, tile_row1)) return e;
     int exact = 0;
@@ -1891,7 +1956,8 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
             (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
             (const float*)background_rgb, num_splats_per_pixel, (const float*)final_weight_per_pixel,
             (const float*)grad_image, W, H, ntx, tile_row0 * ntx, nt, (float*)grad_slab, nullptr,
-            nullptr, nullptr, 1, exact, nullptr, nullptr, nullptr, seg_state_of((void*)segment_state, W, H, tile_row0, tile_row1));
+            nullptr, nullptr, 1, exact, nullptr, nullptr, nullptr, seg_state_of((void*)segment_state, W, H, tile_row0, tile_row1),
+            cut_flags, full_ranges, overflow_sorted);
         return check_launch("render_tiles_backward_slab");
     }
     const bool ordered = tile_cost != nullptr && nt >= GS_LPT_MIN_TILES;
@@ -1901,7 +1967,7 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
         (const float*)background_rgb, num_splats_per_pixel, (const float*)final_weight_per_pixel,
         (const float*)grad_image, W, H, ntx, tile_row0 * ntx, nt, (float*)grad_slab, nullptr,
         nullptr, nullptr, 1, exact, ordered ? tile_order : nullptr, nullptr, nullptr,
-        SEG_NONE);
+        SEG_NONE, cut_flags, full_ranges, overflow_sorted);
     return check_launch("render_tiles_backward_slab");
 }
 

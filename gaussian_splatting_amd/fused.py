@@ -19,6 +19,7 @@ The four stages are plain functions (preprocess_forward, render_forward, render_
 preprocess_backward) that gaussian_splatting_amd.sharded composes differently for multi-GPU frames.
 """
 import ctypes
+import os
 from types import SimpleNamespace
 
 import torch
@@ -50,6 +51,16 @@ SORT_PREFIX = True
 LPT_MIN_MEAN_LIST = 256
 # Enqueue the render on the speculative tile lists before waiting for the frame's host read.
 EARLY_RENDER = True
+
+# Depth cut (csrc/binning.hip "depth cut"; include/gsplat_hip.h): the count pass walks the Gaussians in depth buckets,
+# every tile learns the last bucket up to which it holds <= 1024 entries, and only those are emitted and sorted; a
+# truncated tile that runs out of list unsaturated is repaired on the device from its complete list.  Exact.
+# "auto": whole frames in the LDS-histogram regime whose lists averaged DEPTH_CUT_MIN_MEAN_LIST entries or more in
+# an earlier frame of the same shape (the partition of the Gaussians by depth costs ~0.03 ms: it must buy more than
+# that); True / False force it.  Callers that want the complete lists back (return_aux) never get it.
+DEPTH_CUT = {"0": False, "1": True}.get(os.environ.get("GSPLAT_DEPTH_CUT", "auto"), "auto")   # (env: A/B runs of bench.py)
+DEPTH_CUT_MIN_MEAN_LIST = 2048
+_mean_list_hint = {}   # frame shape -> complete instance count of the latest frame
 
 last_tile_flags = None   # int32[T] of the latest prefix-mode frame of the Python path (see last_flags())
 # Frames without hooks go through the native orchestration (csrc/frame_hip.cpp: the same C-ABI calls and
@@ -113,12 +124,13 @@ def _pinned_ints(dev, n):
 
 
 # ---- frame counters (bench.py --moving-camera reports them) ---------------------------------------------
-_counters = {"frames": 0, "speculative_frames": 0, "capacity_misses": 0, "S_min": None, "S_max": None}
+_counters = {"frames": 0, "speculative_frames": 0, "capacity_misses": 0, "S_min": None, "S_max": None,
+             "depth_cut_frames": 0}
 _flag_log = []   # tile_flags of recent prefix-mode frames (device tensors: summed only when counters() is asked)
 
 
 def reset_counters():
-    _counters.update(frames=0, speculative_frames=0, capacity_misses=0, S_min=None, S_max=None)
+    _counters.update(frames=0, speculative_frames=0, capacity_misses=0, S_min=None, S_max=None, depth_cut_frames=0)
     _flag_log.clear()
     if _native_mod is not None:
         _native_mod.reset_counters()
@@ -135,7 +147,8 @@ def counters():
     if _native_mod is not None:
         nat = _native_mod.counters()
         if nat["frames"]:
-            for k in ("frames", "speculative_frames", "capacity_misses", "prefix_repaired_tiles", "prefix_frames_logged"):
+            for k in ("frames", "speculative_frames", "capacity_misses", "prefix_repaired_tiles", "prefix_frames_logged",
+                      "depth_cut_frames"):
                 out[k] += nat[k]
             lo = [x for x in (out["S_min"], nat["S_min"]) if x is not None]
             hi = [x for x in (out["S_max"], nat["S_max"]) if x is not None]
@@ -161,9 +174,20 @@ class _Arena:
 # ---------------------------------------------------------------------------------------------------
 # stages
 # ---------------------------------------------------------------------------------------------------
+def want_depth_cut(hint_key, N, ntx, row0, row1, whole):
+    """the "auto" policy of DEPTH_CUT for one frame"""
+    if DEPTH_CUT is False or not whole:
+        return False
+    if not _hip.lib().gs_cut_supported(ntx, row0, row1, N):
+        return False
+    if DEPTH_CUT is True:
+        return True
+    return _mean_list_hint.get(hint_key, 0) >= DEPTH_CUT_MIN_MEAN_LIST * (row1 - row0) * ntx
+
+
 def preprocess_forward(xyz, quaternion, scale, opacity, rgb, sh, camera_T_world, K, width, height, near_thresh,
                        far_thresh, cull_mask_padding, mh_dist, tile_rows, sort_prefix, plan=None, plan_ints=0,
-                       defer=False):
+                       defer=False, depth_cut=False):
     """Per-Gaussian stage, binning and per-tile sort of one frame.  `plan`, if given, is called as
     plan(f) after the per-Gaussian stage is enqueued and fills the device record f.record
     (plan_ints int32) that rides on the frame's one host read (its host copy is left in f.host:
@@ -182,6 +206,11 @@ def preprocess_forward(xyz, quaternion, scale, opacity, rgb, sh, camera_T_world,
                         mh_dist=mh_dist, sort_prefix=sort_prefix)
 
     stream = f.stream = _stream()
+    f.hint_key = (dev.index, N, T, row0, row1)
+    if depth_cut:
+        assert plan is None and not defer, "the depth cut is a single-GPU, whole-frame path in the Python orchestration"
+        return _preprocess_forward_cut(f, xyz, quaternion, scale, opacity, rgb, sh, camera_T_world, K, near_thresh,
+                                       far_thresh, cull_mask_padding)
     # two allocations for the stage's buffers (host time matters at ~1 ms per frame): an int32 arena
     # for the bookkeeping and a float32 arena for the per-Gaussian outputs, blocks 16-byte aligned
     n_ws = _hip.lib().gs_preprocess_workspace_ints(N)
@@ -193,6 +222,7 @@ def preprocess_forward(xyz, quaternion, scale, opacity, rgb, sh, camera_T_world,
     f.center, uv, xyz_cam, conic, opa, rgbr, packed = far.blocks()
     f.uv, f.xyz_cam, f.conic = uv.view(N, 2), xyz_cam.view(N, 3), conic.view(N, 3)
     f.opacity_act, f.rgb_render, f.packed = opa.view(N, 1), rgbr.view(N, 3), packed.view(N, 12)
+    f.cut = None
     _hip.call("gs_preprocess_forward", _p(xyz), _p(quaternion), _p(scale), _p(opacity), _p(rgb), _p(sh), n_sh,
               _p(camera_T_world), _p(K), N, width, height, _cf(near_thresh), _cf(far_thresh),
               _cf(cull_mask_padding), _cf(mh_dist), row0, row1, _p(f.ws), _p(f.center), _p(f.count),
@@ -206,7 +236,7 @@ def preprocess_forward(xyz, quaternion, scale, opacity, rgb, sh, camera_T_world,
         plan(f)
     subset, subset_n = f.subset
     _hip.call("gs_tile_count", _p(f.uv), _p(f.conic), N, _p(f.count), _p(subset), _p(subset_n), ntx, nty,
-              _cf(mh_dist), row0, row1, _p(f.tile_counts), _p(f.ranges_buf), stream)
+              _cf(mh_dist), row0, row1, _p(f.tile_counts), _p(f.ranges_buf), None, stream)
 
     def emit_sort(capacity):
         sorted_buf = torch.empty(capacity, **i32)
@@ -222,7 +252,6 @@ def preprocess_forward(xyz, quaternion, scale, opacity, rgb, sh, camera_T_world,
     # guessed from it, so the GPU keeps working while the host waits for the integers; the kernels
     # never write beyond the capacity and the step is repeated only if S turned out larger.
     f.emit_sort = emit_sort
-    f.hint_key = (dev.index, N, T, row0, row1)
     guess = _capacity_hint.get(f.hint_key)
     f.host_buf = _pinned_ints(dev, 2 + plan_ints)
 
@@ -244,6 +273,71 @@ def preprocess_forward(xyz, quaternion, scale, opacity, rgb, sh, camera_T_world,
     f.deferred = defer
     if not defer:
         preprocess_finish(f)
+    return f
+
+
+_DEPTH_HIST = {}
+
+
+def _depth_hist(dev):
+    """the depth histogram gs_preprocess_forward_cut fills and returns to zero: one per (device, stream), zeroed once"""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    if key not in _DEPTH_HIST:
+        _DEPTH_HIST[key] = torch.zeros(_hip.GS_CUT_HIST_BINS, dtype=torch.int32, device=dev)
+    return _DEPTH_HIST[key]
+
+
+def _preprocess_forward_cut(f, xyz, quaternion, scale, opacity, rgb, sh, camera_T_world, K, near_thresh, far_thresh,
+                            cull_mask_padding):
+    """preprocess_forward with the depth-bucketed binning (DEPTH_CUT).  The Python orchestration of this mode reads
+    the frame's counts before it emits (no speculative capacity): it serves tests and tools; frames without hooks
+    run through csrc/frame_hip.cpp."""
+    lib = _hip.lib()
+    dev = xyz.device
+    N, T, ntx, nty, row0, row1 = f.N, f.T, f.ntx, f.nty, f.row0, f.row1
+    stream = f.stream
+    stride = lib.gs_cut_sample_stride(N)
+    n_ws = lib.gs_preprocess_workspace_ints(N)
+    n_tc = lib.gs_tile_workspace_ints(T)
+    n_cut = lib.gs_cut_workspace_ints(N, T)
+    iar = _Arena(torch.int32, dev, (n_ws, 1, N, N, n_tc, T + 3, (N + 3) // 4, n_cut, T + 1))
+    f.ws, f.count, f.rank, f.vis_idx, f.tile_counts, f.ranges_buf, mask_bytes, cut_ws, full_ranges = iar.blocks()
+    f.culling_mask = mask_bytes.view(torch.bool)[:N]
+    far = _Arena(torch.float32, dev, (3, 2 * N, 3 * N, 3 * N, N, 3 * N, 12 * N, 8 * N))
+    f.center, uv, xyz_cam, conic, opa, rgbr, packed, bin_rec = far.blocks()
+    f.uv, f.xyz_cam, f.conic = uv.view(N, 2), xyz_cam.view(N, 3), conic.view(N, 3)
+    f.opacity_act, f.rgb_render, f.packed = opa.view(N, 1), rgbr.view(N, 3), packed.view(N, 12)
+    _hip.call("gs_preprocess_forward_cut", _p(xyz), _p(quaternion), _p(scale), _p(opacity), _p(rgb), _p(sh), f.n_sh,
+              _p(camera_T_world), _p(K), N, f.width, f.height, _cf(near_thresh), _cf(far_thresh),
+              _cf(cull_mask_padding), _cf(f.mh_dist), row0, row1, _p(f.ws), _p(f.center), _p(f.count),
+              _p(f.culling_mask), _p(f.rank), _p(f.vis_idx), _p(f.uv), _p(f.xyz_cam), _p(f.conic),
+              _p(f.opacity_act), _p(f.rgb_render), _p(f.packed), _p(bin_rec), _p(cut_ws), _p(_depth_hist(dev)), stride,
+              stream)
+    _hip.call("gs_tile_count_cut", _p(bin_rec), N, _p(f.count), ntx, nty, _cf(f.mh_dist), row0, row1,
+              _p(f.tile_counts), _p(cut_ws), _p(f.ranges_buf), _p(full_ranges), None, stream)
+    f.subset = (None, None)
+    f.record = f.ranges_buf[T + 3:]
+    f.host_buf = _pinned_ints(dev, 3)
+    f.host_buf.copy_(f.ranges_buf[T:T + 3])
+    S, V, S_full = (int(x) for x in f.host_buf.tolist())
+    sorted_buf = torch.empty(S, dtype=torch.int32, device=dev)
+    keys = torch.empty(S, dtype=torch.int64, device=dev)
+    if S > 0:
+        _hip.call("gs_tile_emit_sort_cut", _p(bin_rec), N, ntx, nty, _cf(f.mh_dist), row0, row1, _p(f.ranges_buf),
+                  _p(f.tile_counts), _p(cut_ws), _p(keys), ctypes.c_int64(S), _p(sorted_buf), stream)
+    c = _counters
+    c["frames"] += 1
+    c["depth_cut_frames"] += 1
+    c["S_min"] = S_full if c["S_min"] is None else min(c["S_min"], S_full)
+    c["S_max"] = S_full if c["S_max"] is None else max(c["S_max"], S_full)
+    _mean_list_hint[f.hint_key] = S_full
+    f.ranges = f.ranges_buf[:T + 1]
+    f.speculative, f.deferred, f.capacity = False, False, S
+    f.sorted_buf = f.sorted_g = sorted_buf
+    f.keys_buf = f.keys = keys
+    f.S, f.V, f.host = S, V, []
+    f.cut = SimpleNamespace(bin_rec=bin_rec, cut_ws=cut_ws, full_ranges=full_ranges, S_full=S_full, N=N,
+                            tile_counts=f.tile_counts, mh_dist=f.mh_dist, flags=None, overflow_sorted=None)
     return f
 
 
@@ -269,6 +363,7 @@ def preprocess_finish(f):
     # the guess is the largest count seen for this frame shape plus a margin: views of a training run
     # differ by tens of percent in S, and a miss costs a repeated emit + sort + render
     _capacity_hint[f.hint_key] = max(_capacity_hint.get(f.hint_key, 0), int(S * 1.25) + 4096)
+    _mean_list_hint[f.hint_key] = S
     f.host = f.host_buf.tolist()[2:]
     f.S, f.V = S, V
     f.sorted_g = f.sorted_buf[:S]
@@ -339,8 +434,9 @@ def segments_for(hint_key, n_instances, exact_count, n_tiles):
 
 
 def render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, width, tile_rows, sort_prefix,
-                   image_rows=None, segments=None):
-    """-> image, splat counts, final weights, tile costs, segment state.  image_rows > height: the image buffer
+                   image_rows=None, segments=None, cut=None):
+    """cut: the frame's depth-cut record (preprocess_forward(depth_cut=True).cut) -> gs_render_tiles_cut.
+    -> image, splat counts, final weights, tile costs, segment state.  image_rows > height: the image buffer
     gets that many rows (the multi-GPU gather wants equal-sized bands); the kernels only see the first `height`.
     tile costs: int32[n_tiles], how long each tile took (prefix mode; empty otherwise) -- the launch-order
     hint render_backward hands back to the library.  segment state: the workspace for the depth-segmented
@@ -366,6 +462,24 @@ def render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, 
         seg = torch.empty(_hip.lib().gs_render_segment_workspace_bytes(width, height, row0, row1) // 4,
                           dtype=torch.float32, device=dev)
     seg_p = _p(seg) if segments else None
+    if cut is not None:
+        # depth-cut lists (preprocess_forward(depth_cut=True)): kept prefixes first, flagged tiles repaired from
+        # their complete lists in the overflow buffers -- one call, the host never looks at the flags
+        assert not segments, "depth segments and the depth cut are not combined"
+        scratch = torch.empty(2 * ntx * nty, dtype=torch.int32, device=dev)
+        flags, cost = scratch[:ntx * nty], scratch[ntx * nty:]
+        okeys = torch.empty(cut.S_full, dtype=torch.int64, device=dev)
+        osorted = torch.empty(cut.S_full, dtype=torch.int32, device=dev)
+        _hip.call("gs_render_tiles_cut", _p(packed), _p(rgb), _p(ranges), _p(sorted_g), ctypes.c_int64(sorted_g.shape[0]),
+                  _p(cut.full_ranges), _p(cut.bin_rec), cut.N, _cf(cut.mh_dist), _p(cut.tile_counts), _p(cut.cut_ws),
+                  _p(okeys), _p(osorted), ctypes.c_int64(cut.S_full), _p(background_rgb), width, height, row0, row1,
+                  _p(flags), _p(nsp), _p(fw), _p(image), _p(cost), stream)
+        cut.flags, cut.overflow_sorted = flags, osorted
+        global last_tile_flags
+        last_tile_flags = flags
+        if len(_flag_log) < 512:
+            _flag_log.append(flags)
+        return image, nsp, fw, cost, seg
     if sort_prefix and sorted_g.shape[0] > sort_prefix:
         # provisional render from the ordered prefixes; tiles that ran out of prefix are flagged,
         # sorted in full and rendered again -- one call, the host never looks at the flags
@@ -374,7 +488,6 @@ def render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, 
         _hip.call("gs_render_tiles_prefix", _p(packed), _p(rgb), _p(ranges), _p(sorted_g), _p(keys),
                   ctypes.c_int64(sorted_g.shape[0]), _p(background_rgb), width, height, row0, row1, _p(flags),
                   _p(nsp), _p(fw), _p(image), _p(cost), seg_p, stream)
-        global last_tile_flags
         last_tile_flags = flags
         if len(_flag_log) < 512:
             _flag_log.append(flags)
@@ -386,7 +499,7 @@ def render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, 
 
 
 def render_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, grad_image, height, width, tile_rows,
-                    V, tile_cost=None, backward_mode=None, seg_state=None):
+                    V, tile_cost=None, backward_mode=None, seg_state=None, cut=None):
     """-> the slab [V, 9] of accumulated render gradients (rgb 3 | opacity 1 | uv 2 | conic 3).
     tile_cost: render_forward's fourth output (the tiles are then started longest-first).
     seg_state: render_forward's fifth output; non-empty -> one workgroup per (tile, depth segment).
@@ -406,6 +519,8 @@ def render_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, grad
               _p(nsp), _p(fw), _p(grad_image), width, height, row0, row1, _p(slab),
               _p(cost) if cost is not None else None, _p(order) if order is not None else None,
               _p(seg_state) if seg_on else None,
+              _p(cut.flags) if cut is not None else None, _p(cut.full_ranges) if cut is not None else None,
+              _p(cut.overflow_sorted) if cut is not None else None,
               _hip.GS_BACKWARD_DEFAULT if backward_mode is None else int(backward_mode), _stream())
     return slab[:V]
 
@@ -432,11 +547,23 @@ def _as_slab(g_uv, g_conic, g_opa, g_rgb, V, dev):
 class _Preprocess(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, quaternion, scale, opacity, rgb, sh, camera_T_world, K, width, height, near_thresh,
-                far_thresh, cull_mask_padding, mh_dist, tile_rows, sort_prefix=0, background_rgb=None):
+                far_thresh, cull_mask_padding, mh_dist, tile_rows, sort_prefix=0, background_rgb=None, cut_box=None):
+        # cut_box: a list; when the frame takes the depth cut its record (what _Render's two passes need) is left in it
+        ntx = (width + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
+        nty = (height + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
+        row0, row1 = tile_rows if tile_rows is not None else (0, nty)
+        cut = (cut_box is not None and background_rgb is not None and sort_prefix != 0 and
+               want_depth_cut((xyz.device.index, xyz.shape[0], ntx * nty, row0, row1), xyz.shape[0], ntx, row0, row1,
+                              tile_rows is None))
         f = preprocess_forward(xyz, quaternion, scale, opacity, rgb, sh, camera_T_world, K, width, height,
                                near_thresh, far_thresh, cull_mask_padding, mh_dist, tile_rows, sort_prefix,
-                               defer=EARLY_RENDER and background_rgb is not None and sort_prefix != 0)
-        if f.deferred:
+                               defer=(not cut) and EARLY_RENDER and background_rgb is not None and sort_prefix != 0,
+                               depth_cut=cut)
+        if cut:
+            cut_box.append(f.cut)
+            pre = render_forward(f.packed, f.rgb_render, f.ranges, f.sorted_g, f.keys, background_rgb, height, width,
+                                 tile_rows, sort_prefix, segments=False, cut=f.cut)
+        elif f.deferred:
             # the render (the _Render node's forward) is enqueued on the speculative tile lists before
             # the host waits for the frame's counts, so a short frame leaves no bubble on the GPU;
             # a too small capacity repeats it
@@ -466,16 +593,17 @@ class _Preprocess(torch.autograd.Function):
         xyz, quaternion, scale, camera_T_world, K = ctx.saved_tensors
         slab = _as_slab(g_uv, g_conic, g_opa, g_rgb, ctx.f.V, xyz.device)
         grads = preprocess_backward(xyz, quaternion, scale, camera_T_world, K, ctx.f, slab)
-        return grads + (None,) * 11
+        return grads + (None,) * 12
 
 
 class _Render(torch.autograd.Function):
     @staticmethod
     def forward(ctx, uv, conic, opacity, rgb, packed, ranges, sorted_g, background_rgb, height, width, tile_rows,
-                slab_sync=None, keys=None, sort_prefix=0, rendered=None):
+                slab_sync=None, keys=None, sort_prefix=0, rendered=None, cut=None):
         # rendered: (image, nsp, fw, cost, seg) when _Preprocess.forward already enqueued this node's kernels
         image, nsp, fw, cost, seg = rendered if rendered else render_forward(
             packed, rgb, ranges, sorted_g, keys, background_rgb, height, width, tile_rows, sort_prefix)
+        ctx.cut = cut   # depth-cut frame: flags, complete ranges and overflow lists for the backward
         ctx.save_for_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, cost, seg)
         ctx.set_materialize_grads(False)
         ctx.dims = (height, width, tile_rows, uv.shape[0])
@@ -490,13 +618,13 @@ class _Render(torch.autograd.Function):
         packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, cost, seg = ctx.saved_tensors
         height, width, tile_rows, V = ctx.dims
         if grad_image is None:
-            return (None,) * 15
+            return (None,) * 16
         slab = render_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, grad_image.contiguous(),
-                               height, width, tile_rows, V, cost, ctx.backward_mode, seg)
+                               height, width, tile_rows, V, cost, ctx.backward_mode, seg, cut=ctx.cut)
         if ctx.slab_sync is not None:
             ctx.slab_sync(slab.view(-1))   # multi-GPU: sum the partial gradients of all bands in place
         # the four gradients are views of the one slab; _Preprocess.backward recognises that
-        return (slab[:, SLAB_UV], slab[:, SLAB_CONIC], slab[:, SLAB_OPACITY], slab[:, SLAB_RGB]) + (None,) * 11
+        return (slab[:, SLAB_UV], slab[:, SLAB_CONIC], slab[:, SLAB_OPACITY], slab[:, SLAB_RGB]) + (None,) * 12
 
 
 class _GatherRows(torch.autograd.Function):
@@ -655,23 +783,25 @@ def rasterize(gaussians, camera_T_world, camera, near_thresh, far_thresh, cull_m
     if nat is not None:
         nat.set_modes(bool(SORT_PREFIX), bool(EARLY_RENDER))
         nat.set_segments(0 if SEGMENTS == "auto" else (1 if SEGMENTS else -1))
+        nat.set_depth_cut(0 if DEPTH_CUT == "auto" else (1 if DEPTH_CUT else -1), int(DEPTH_CUT_MIN_MEAN_LIST))
         row0, row1 = tile_rows if tile_rows is not None else (0, -1)
         return nat.rasterize(g.xyz, g.quaternion, g.scale, g.opacity, g.rgb, g.sh, camera_T_world, camera.K,
                              int(camera.width), int(camera.height), near_thresh, far_thresh, cull_mask_padding, mh_dist,
                              background_rgb, row0, row1)
     sh = g.sh.contiguous() if g.sh is not None else None
     sort_prefix = _hip.GS_SORT_PREFIX if (SORT_PREFIX and not return_aux) else 0
+    cut_box = [] if not (return_aux or grad_sync or slab_sync or frame_hook) else None
     out = _Preprocess.apply(
         g.xyz.contiguous(), g.quaternion.contiguous(), g.scale.contiguous(), g.opacity.contiguous(),
         g.rgb.contiguous(), sh, camera_T_world.contiguous(), camera.K.contiguous(), int(camera.width),
         int(camera.height), near_thresh, far_thresh, cull_mask_padding, mh_dist, tile_rows, sort_prefix,
-        background_rgb.contiguous())
+        background_rgb.contiguous(), cut_box)
     uv, conic, opacity, rgb, packed, xyz_cam, culling_mask, ranges, sorted_g, vis_idx, keys = out[:11]
     if frame_hook is not None:   # multi-GPU cost-balanced bands: the band's tile ranges
         frame_hook(dict(ranges=ranges, ntx=(int(camera.width) + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX))
     image = _Render.apply(uv, conic, opacity, rgb, packed, ranges, sorted_g, background_rgb.contiguous(),
                           int(camera.height), int(camera.width), tile_rows, slab_sync, keys, sort_prefix,
-                          tuple(out[11:]))
+                          tuple(out[11:]), cut_box[0] if cut_box else None)
     if return_aux:
         return image, culling_mask, uv, dict(conic=conic, opacity=opacity, rgb=rgb, packed=packed,
                                              xyz_camera_frame=xyz_cam, tile_ranges=ranges,

@@ -223,7 +223,7 @@ def get_sorted_gaussian_list(max_tiles_per_gaussian, uvs, xyz_camera_frame, coni
     ranges = torch.empty(T + 1, dtype=torch.int32, device=dev)
     mh = ctypes.c_float(mh_dist)
     _hip.call("gs_tile_count", _p(uvs), _p(conic), V, None, None, None, int(n_tiles_x), int(n_tiles_y), mh, row0, row1, _p(counts),
-                          _p(ranges), _stream())
+                          _p(ranges), None, _stream())
     S = int(ranges[T].item())   # the one host read: sizes the result
     sorted_g = torch.empty(S, dtype=torch.int32, device=dev)
     if S > 0:

@@ -98,6 +98,9 @@ int gs_precompute_rgb_from_sh_backward(const void* xyz, const void* matrix, cons
  *                      Gaussian index.
  *
  * uvs[V,2], xyz_camera_frame[V,3], conic[V,3]; n_tiles = n_tiles_x*n_tiles_y.
+ * host_mirror (gs_tile_count, gs_tile_count_cut; may be NULL): a device-accessible pointer to 3 ints of PINNED HOST
+ *   memory that receives (instance count, visible count, complete instance count) when the scan finishes -- the
+ *   frame's host read without a copy kernel in the stream (record an event behind the call and wait for it).
  * visible_count: NULL, or a device pointer to the number of valid rows when the inputs are
  *   capacity-V buffers whose fill level only the device knows (gs_preprocess_forward); rows
  *   beyond it are ignored and tile_ranges then has T+2 entries, [T+1] = *visible_count, so that
@@ -125,7 +128,7 @@ size_t gs_tile_workspace_ints(int n_tiles);
 int gs_tile_count(const void* uvs, const void* conic, int V, const int32_t* visible_count,
                   const int32_t* subset, const int32_t* subset_count, int n_tiles_x, int n_tiles_y,
                   float mh_dist, int tile_row0, int tile_row1, int32_t* workspace,
-                  int32_t* tile_ranges /*[T+1] or [T+2]*/, void* stream);
+                  int32_t* tile_ranges /*[T+1] or [T+2]*/, int32_t* host_mirror, void* stream);
 int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void* conic, int V,
                       const int32_t* visible_count, const int32_t* subset,
                       const int32_t* subset_count, int n_tiles_x, int n_tiles_y, float mh_dist,
@@ -137,6 +140,48 @@ int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void*
 int gs_tile_sort_flagged(const int32_t* tile_ranges, const uint64_t* keys, int64_t S,
                          const int32_t* tile_flags, int n_tiles_x, int tile_row0, int tile_row1,
                          int32_t* sorted_gaussians, void* stream);
+
+/* ---- depth-bucketed binning ("depth cut", fp32, ABI 6; no reference counterpart) ----------------------------
+ * For dense frames the tile lists are several times longer than what the render consumes (workload D: ~2800
+ * entries per tile, no pixel composites deeper than the 743rd).  Here the count pass walks the visible Gaussians
+ * in NBK = 1024 DEPTH BUCKETS of about equal population (one workgroup per bucket), so that its per-workgroup tile
+ * histograms are a cumulative depth histogram per tile and every tile knows, exactly, the last bucket b*(t) up to
+ * which it holds at most GS_SORT_PREFIX entries.  Only those are emitted and sorted (a true depth prefix of the
+ * complete list, completely ordered).  Exact like the prefix sort: gs_render_tiles_cut flags a truncated tile
+ * that reaches the end of its list with an unsaturated pixel, emits + sorts the COMPLETE lists of the flagged tiles
+ * into the caller's overflow buffers at full_ranges and renders them again; gs_render_tiles_backward_slab reads a
+ * flagged tile's list from there.  No host read in between.
+ *
+ *   gs_preprocess_forward_cut   gs_preprocess_forward + bin_records float[N,8] (u v conic0 conic1 | conic2 z 0 0 per
+ *                               visible Gaussian: what the binning reads, one 32-byte sector), and inside cut_workspace
+ *                               the bucket boundaries and every visible Gaussian's bucket.  depth_hist: int32
+ *                               [GS_CUT_HIST_BINS] that is ALL ZERO on entry and all zero again on exit (allocate once,
+ *                               zero once, hand to every frame on the stream): the depth histogram of every
+ *                               sample_stride-th visible Gaussian (sample_stride = gs_cut_sample_stride(N)) whose
+ *                               quantiles are the boundaries.  uv, xyz_camera_frame and conic may be NULL here (their
+ *                               values are in bin_records: uv = columns 0-1, conic = columns 2-4, z = column 5).
+ *   gs_tile_count_cut           buckets, counts, cut: tile_ranges[T+3] (prefix of the KEPT counts; [T] = entries kept
+ *                               S', [T+1] = V, [T+2] = all entries S), full_ranges[T+1] (prefix of the complete counts)
+ *   gs_tile_emit_sort_cut       keys + sorted lists of the kept entries (capacity S as in gs_tile_emit_sort)
+ * workspace: int32[gs_tile_workspace_ints(T)] as for gs_tile_count; cut_workspace: int32[gs_cut_workspace_ints(N, T)],
+ * both untouched until the frame's backward has run.  Needs the LDS-histogram regime: gs_cut_supported(...) != 0. */
+#define GS_CUT_BUCKETS 1024
+#define GS_CUT_HIST_BINS 8192
+#define GS_CUT_MAX_SAMPLES 65536
+size_t gs_cut_workspace_ints(int n_gaussians, int n_tiles);
+int gs_cut_sample_stride(int n_gaussians);
+int gs_cut_supported(int n_tiles_x, int tile_row0, int tile_row1, int n_gaussians);
+int gs_tile_count_cut(const void* bin_records, int N, const int32_t* visible_count, int n_tiles_x, int n_tiles_y,
+                      float mh_dist, int tile_row0, int tile_row1, int32_t* workspace, int32_t* cut_workspace,
+                      int32_t* tile_ranges /*[T+3]*/, int32_t* full_ranges /*[T+1]*/, int32_t* host_mirror, void* stream);
+int gs_tile_emit_sort_cut(const void* bin_records, int N, int n_tiles_x, int n_tiles_y, float mh_dist, int tile_row0,
+                          int tile_row1, const int32_t* tile_ranges, int32_t* workspace, int32_t* cut_workspace,
+                          uint64_t* keys, int64_t S, int32_t* sorted_gaussians, void* stream);
+/* tests / tools: device pointers into the cut workspace -- b*(t) int32[T], complete counts int32[T], bucket bounds
+ * uint32[1024] (sortable depth bits, inclusive upper bound), bucket offsets int32[1025], control int32[2] (deepest
+ * bucket any tile wants, flagged tiles of the frame) */
+int gs_cut_debug_views(int32_t* cut_workspace, int N, int n_tiles, int32_t** bstar, int32_t** totals, uint32_t** bounds,
+                       int32_t** bucket_offsets, int32_t** ctrl);
 
 /* ---- fused per-Gaussian stage (fp32) ----------------------------------------------------------------
  * One pass replacing the PyTorch glue and per-Gaussian kernels of rasterize()
@@ -176,6 +221,16 @@ int gs_preprocess_forward(const void* xyz, const void* quaternion, const void* s
  * the parameter / rank / output pointers advanced to row i0, N = i1 - i0, and a slab that holds
  * the rows of the slice's visible Gaussians with v_base = their first visible index;
  * opacity_act stays the full array (it is indexed by v). */
+int gs_preprocess_forward_cut(const void* xyz, const void* quaternion, const void* scale,
+                              const void* opacity, const void* rgb, const void* sh, int n_sh,
+                              const void* camera_T_world, const void* K, int N, int W, int H,
+                              float near_thresh, float far_thresh, float cull_mask_padding,
+                              float mh_dist, int band_row0, int band_row1,
+                              int32_t* workspace, void* camera_center, int32_t* visible_count,
+                              uint8_t* culling_mask, int32_t* rank, int32_t* vis_idx, void* uv,
+                              void* xyz_camera_frame, void* conic, void* opacity_act, void* rgb_render,
+                              void* packed, void* bin_records, int32_t* cut_workspace, int32_t* depth_hist,
+                              int sample_stride, void* stream);
 int gs_preprocess_backward(const void* xyz, const void* quaternion, const void* scale, int n_sh,
                            const void* camera_T_world, const void* K, const void* camera_center,
                            const int32_t* rank, const void* opacity_act, const void* grad_slab,
@@ -264,14 +319,30 @@ int gs_render_tiles_backward_packed(const void* packed, const void* rgb, const v
  * int32[n_tiles + 8] workspace, the tiles' workgroups are started longest-first (shorter drain at the end of
  * the kernel; grids below 2048 tiles keep the natural order).  The gradients do not depend on it.
  * segment_state (may be NULL): the workspace the forward filled -> (tile, depth segment) work items, see
- * gs_render_segment_workspace_bytes; tile_cost / tile_order are then not used. */
+ * gs_render_segment_workspace_bytes; tile_cost / tile_order are then not used.
+ * cut_flags / full_ranges / overflow_sorted (all NULL, or all given; ABI 6): a frame rendered by gs_render_tiles_cut --
+ * a tile with cut_flags[t] != 0 reads its (complete) list from overflow_sorted at full_ranges[t]. */
 int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int32_t* tile_ranges,
                                   const int32_t* sorted_gaussians, const void* background_rgb,
                                   const int32_t* num_splats_per_pixel,
                                   const void* final_weight_per_pixel, const void* grad_image, int W,
                                   int H, int tile_row0, int tile_row1, void* grad_slab,
                                   const int32_t* tile_cost, int32_t* tile_order, const void* segment_state,
+                                  const int32_t* cut_flags, const int32_t* full_ranges, const int32_t* overflow_sorted,
                                   int backward_mode, void* stream);
+/* Forward render of a frame binned by gs_tile_count_cut / gs_tile_emit_sort_cut (fp32, one colour coefficient per
+ * channel; ABI 6).  tile_ranges / sorted_gaussians: the kept depth prefixes (capacity S as in gs_render_tiles_prefix);
+ * a truncated tile that ends with an unsaturated pixel gets tile_flags[t] = 1, the complete lists of such tiles are
+ * emitted into overflow_keys / overflow_sorted (capacity overflow_capacity >= full_ranges[T], the frame's complete
+ * instance count; only flagged tiles' segments are written) and they are rendered again -- plain enqueues, no host
+ * read; the three repair launches exit at once while nothing is flagged.  bin_records, workspace, cut_workspace: as
+ * given to gs_tile_count_cut.  Results are those of gs_render_tiles_packed on the complete sorted lists, bit for bit. */
+int gs_render_tiles_cut(const void* packed, const void* rgb, const int32_t* tile_ranges, const int32_t* sorted_gaussians,
+                        int64_t S, const int32_t* full_ranges, const void* bin_records, int N, float mh_dist,
+                        int32_t* workspace, int32_t* cut_workspace, uint64_t* overflow_keys, int32_t* overflow_sorted,
+                        int64_t overflow_capacity, const void* background_rgb, int W, int H, int tile_row0, int tile_row1,
+                        int32_t* tile_flags, int32_t* num_splats_per_pixel, void* final_weight_per_pixel, void* image,
+                        int32_t* tile_cost, void* stream);
 /* Gradient mode of the render backward: the `backward_mode` argument of the three entry points above
  * (ABI 5: per call, so that a trainer switching modes cannot race a backward that the autograd engine's
  * own thread has queued).  GS_BACKWARD_DEFAULT takes the process-wide default, which gs_set_backward_mode

@@ -49,7 +49,7 @@ def pre(stream):
 
 def binning(stream):
     _hip.check(lib.gs_tile_count(p(f.uv), p(f.conic), N, p(f.count), None, None, f.ntx, f.nty, cf(d["mh_dist"]), 0, f.nty,
-                                 p(tws), p(ranges), stream))
+                                 p(tws), p(ranges), None, stream))
     _hip.check(lib.gs_tile_emit_sort(p(f.uv), p(f.xyz_cam), p(f.conic), N, p(f.count), None, None, f.ntx, f.nty,
                                      cf(d["mh_dist"]), 0, f.nty, p(ranges), p(tws), p(keys), ctypes.c_int64(S), p(out),
                                      _hip.GS_SORT_PREFIX, stream))

@@ -44,7 +44,7 @@ def run(subset, subset_n, prefix):
     keys = torch.empty(S, dtype=torch.int64, device=dev)
     out = torch.empty(S, dtype=torch.int32, device=dev)
     _hip.call("gs_tile_count", p(f.uv), p(f.conic), N, p(f.count), p(subset), p(subset_n), ntx, nty, mh, 0, nty, p(ws),
-              p(ranges), stream)
+              p(ranges), None, stream)
     _hip.call("gs_tile_emit_sort", p(f.uv), p(f.xyz_cam), p(f.conic), N, p(f.count), p(subset), p(subset_n), ntx, nty, mh,
               0, nty, p(ranges), p(ws), p(keys), ctypes.c_int64(S), p(out), prefix, stream)
     return ranges, out

@@ -32,7 +32,7 @@ out = [torch.empty(N, k, device="cuda") for k in (3, 4, 3, 1, 3)] + [torch.empty
 
 def count(stream):
     _hip.call("gs_tile_count", _p(f.uv), _p(f.conic), N, _p(f.count), None, None, ntx, nty, _cf(DEFAULTS["mh_dist"]),
-              0, nty, _p(f.tile_counts), _p(f.ranges_buf), stream)
+              0, nty, _p(f.tile_counts), _p(f.ranges_buf), None, stream)
 
 
 def hbm(stream):

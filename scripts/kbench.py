@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--natural-order", action="store_true", help="backward without the longest-first tile order")
     ap.add_argument("--binning-only", action="store_true")
     ap.add_argument("--segments", type=int, default=0, help="1: depth-segmented backward (forward leaves the state)")
+    ap.add_argument("--depth-cut", type=int, default=0, help="1: depth-bucketed binning (csrc/binning.hip 'depth cut')")
     ap.add_argument("--rows", type=int, nargs=2, default=None, metavar=("R0", "R1"),
                     help="render forward / backward only the tile rows [R0, R1) (a multi-GPU rank's band)")
     args = ap.parse_args()
@@ -48,7 +49,7 @@ def main():
     def stage1():
         return fused.preprocess_forward(g.xyz, g.quaternion, g.scale, g.opacity, g.rgb, g.sh, T, cam.K, W, H,
                                         d["near_thresh"], d["far_thresh"], d["cull_mask_padding"], d["mh_dist"], None,
-                                        _hip.GS_SORT_PREFIX)
+                                        _hip.GS_SORT_PREFIX, depth_cut=bool(args.depth_cut))
 
     rows = tuple(args.rows) if args.rows else None
     if args.binning_only:
@@ -72,11 +73,11 @@ def main():
 
     def fwd():
         return fused.render_forward(f.packed, rgb_v, f.ranges, f.sorted_g, f.keys, bg, H, W, rows, _hip.GS_SORT_PREFIX,
-                                    segments=args.segments)
+                                    segments=args.segments, cut=f.cut)
 
     def bwd(nsp, fw, cost=None, seg=None):
         return fused.render_backward(f.packed, rgb_v, f.ranges, f.sorted_g, bg, nsp, fw, gi, H, W, rows, V, cost,
-                                     seg_state=seg)
+                                     seg_state=seg, cut=f.cut)
 
     image, nsp, fw, cost, seg = fwd()
     slab = bwd(nsp, fw, None if args.natural_order else cost, seg)
@@ -90,6 +91,8 @@ def main():
     for _ in range(args.reps):
         if args.full:
             f2 = stage1()
+            if args.depth_cut:
+                f = f2   # (the render passes read the frame's own cut record)
         image, nsp, fw, cost, seg = fwd()
         slab = bwd(nsp, fw, None if args.natural_order else cost, seg)
         if args.full:

@@ -628,7 +628,7 @@ def test_backward_longest_first_tile_order(W, H, monkeypatch):
     order = torch.full((nt + 8,), -7, dtype=torch.int32, device=DEV)
     slab = torch.zeros(V, 9, device=DEV)
     _hip.call("gs_render_tiles_backward_slab", p(f.packed), p(rgb_v), p(f.ranges), p(f.sorted_g), p(bg), p(nsp), p(fw),
-              p(gi), W, H, 0, (H + 15) // 16, p(slab), p(cost), p(order), None, _hip.GS_BACKWARD_DEFAULT,
+              p(gi), W, H, 0, (H + 15) // 16, p(slab), p(cost), p(order), None, None, None, None, _hip.GS_BACKWARD_DEFAULT,
               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     o = order.cpu()
@@ -647,12 +647,12 @@ def test_backward_longest_first_tile_order(W, H, monkeypatch):
     # cost without order (or the reverse) is refused
     with pytest.raises(RuntimeError, match="go together"):
         _hip.call("gs_render_tiles_backward_slab", p(f.packed), p(rgb_v), p(f.ranges), p(f.sorted_g), p(bg), p(nsp),
-                  p(fw), p(gi), W, H, 0, (H + 15) // 16, p(slab), p(cost), None, None, _hip.GS_BACKWARD_DEFAULT,
+                  p(fw), p(gi), W, H, 0, (H + 15) // 16, p(slab), p(cost), None, None, None, None, None, _hip.GS_BACKWARD_DEFAULT,
                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     # the gradient mode is an argument of the call (ABI 5): anything but DEFAULT / COMPAT / EXACT is refused
     with pytest.raises(RuntimeError, match="backward mode"):
         _hip.call("gs_render_tiles_backward_slab", p(f.packed), p(rgb_v), p(f.ranges), p(f.sorted_g), p(bg), p(nsp),
-                  p(fw), p(gi), W, H, 0, (H + 15) // 16, p(slab), None, None, None, 7,
+                  p(fw), p(gi), W, H, 0, (H + 15) // 16, p(slab), None, None, None, None, None, None, 7,
                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
 
 

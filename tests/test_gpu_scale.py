@@ -270,7 +270,7 @@ def test_prefix_sort_selects_the_nearest_entries():
     ws = torch.empty(_hip.lib().gs_tile_workspace_ints(ntx), dtype=torch.int32, device=DEV)
     ranges = torch.empty(ntx + 1, dtype=torch.int32, device=DEV)
     _hip.call("gs_tile_count", p(uv_d), p(conic_d), V, None, None, None, ntx, 1, ctypes.c_float(3.0), 0, 1, p(ws),
-              p(ranges), stream)
+              p(ranges), None, stream)
     assert torch.equal(ranges.cpu(), ref_ranges)
     S = int(ranges[-1])
     keys = torch.empty(S, dtype=torch.int64, device=DEV)
