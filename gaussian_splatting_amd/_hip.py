@@ -51,6 +51,7 @@ EXPORTS = [
     "gs_densify_move",
     "gs_cut_workspace_ints", "gs_cut_sample_stride", "gs_cut_supported", "gs_preprocess_forward_cut", "gs_tile_count_cut",
     "gs_tile_emit_sort_cut", "gs_cut_debug_views", "gs_render_tiles_cut",
+    "gs_band_row_costs", "gs_band_assemble",
 ]
 
 _lib = None

@@ -32,6 +32,7 @@
 // the eigenvector (b, lambda1 - a) instead of atan2f/cosf/sinf (whose last bits differ between
 // libdevice, OCML and glibc).
 #include "tile_math.h"
+#include "tile_sort.h"
 
 namespace gs {
 
@@ -566,32 +567,76 @@ __global__ __launch_bounds__(DC_BLOCK) void k_depth_hist(const int* __restrict__
     cs.phist[(size_t)blockIdx.x * NBK + tid] = s_cnt[tid];
 }
 
-// counting sort of the visible indices by bucket.  Thread k owns bucket k: its total over all partition
-// workgroups, the part in front of this workgroup, and (block scan) the bucket's offset.  Inside a
-// (workgroup, bucket) run the order is whatever the LDS atomics hand out -- no result depends on it (tile lists
-// are ordered by unique keys afterwards; counts per (bucket, tile) do not depend on the order).
-__global__ __launch_bounds__(DC_BLOCK) void k_depth_scatter(const int* __restrict__ v_dev, CutState cs) {
-    __shared__ int s_cur[NBK];
-    __shared__ int s_wave[17];
-    const int tid = threadIdx.x;
-    int total = 0, before = 0;
-#pragma unroll 16
-    for (int w = 0; w < DC_PART; w++) {
-        const int c = cs.phist[(size_t)w * NBK + tid];
-        before += w < (int)blockIdx.x ? c : 0;
-        total += c;
+// phist[w][b] <- entries of bucket b in the partition workgroups before w; boff[b + 1] <- bucket b's total
+// (k_depth_scatter turns the totals into offsets itself: 4 KB per workgroup).  64 buckets x 16 row segments per
+// workgroup, as k_bin_colscan: sixteen workgroups share the 1 MB matrix -- one workgroup alone reads ~100 GB/s,
+// and every scatter workgroup summing the 256 rows for itself was 256 MB of L2 reads (25 of that kernel's 39 us).
+__global__ __launch_bounds__(1024) void k_depth_colscan(CutState cs) {
+    constexpr int CT = 64, SEGS = 1024 / CT, ROWS = DC_PART / SEGS;
+    __shared__ int s_seg[SEGS][CT];
+    const int lt = threadIdx.x & (CT - 1), seg = threadIdx.x / CT;
+    const int b = blockIdx.x * CT + lt;
+    int* col = cs.phist + (size_t)seg * ROWS * NBK + b;
+    int v[ROWS], sum = 0;
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        v[r] = col[(size_t)r * NBK];
+        sum += v[r];
     }
-    int sum;
-    const int base = block_scan_1024(total, s_wave, &sum);
-    s_cur[tid] = base + before;
-    if (blockIdx.x == 0) {
-        cs.boff[tid] = base;
-        if (tid == 0) cs.boff[NBK] = sum;
-    }
+    s_seg[seg][lt] = sum;
     __syncthreads();
+    int run = 0, total = 0;
+    for (int s2 = 0; s2 < SEGS; s2++) {
+        if (s2 < seg) run += s_seg[s2][lt];
+        total += s_seg[s2][lt];
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        col[(size_t)r * NBK] = run;
+        run += v[r];
+    }
+    if (seg == 0) cs.boff[b + 1] = total;
+}
+
+// counting sort of the visible indices by bucket: workgroup w places its chunk.  The chunk is first ordered by
+// bucket in LDS (local cursor per bucket), then written out: consecutive LDS slots of one bucket go to consecutive
+// list positions, so a wave's store covers runs of ~10 entries instead of 64 unrelated 4-byte sectors.  Inside a
+// (workgroup, bucket) run the order is whatever the LDS atomics hand out -- no result depends on it (tile lists are
+// ordered by unique keys afterwards; counts per (bucket, tile) do not depend on the order).
+constexpr int DC_STAGE = 12 * 1024;   // LDS slots: the chunk of a partition workgroup (V / 256) up to 3.1 M visible
+__global__ __launch_bounds__(DC_BLOCK) void k_depth_scatter(const int* __restrict__ v_dev, CutState cs) {
+    __shared__ int s_lbase[NBK + 1];   // first LDS slot of each bucket's run
+    __shared__ int s_cur[NBK];
+    __shared__ int s_gbase[NBK];
+    __shared__ int s_wave[17];
+    __shared__ int s_list[DC_STAGE];
+    const int tid = threadIdx.x;
     const int V = *v_dev;
     const int chunk = (V + DC_PART - 1) / DC_PART;
     const int v0 = min(V, (int)blockIdx.x * chunk), v1 = min(V, v0 + chunk);
+    const int n = v1 - v0;
+    // bucket offsets from the totals k_depth_colscan left in boff[1 ..] (every workgroup scans the 4 KB itself;
+    // workgroup 0 publishes the result as boff2 for the count and emit passes)
+    const int total = cs.boff[tid + 1];
+    int vis;
+    const int base = block_scan_1024(total, s_wave, &vis);
+    if (blockIdx.x == 0) {
+        cs.boff2[tid] = base;
+        if (tid == 0) cs.boff2[NBK] = vis;
+    }
+    const int before = cs.phist[(size_t)blockIdx.x * NBK + tid];
+    const int gb = base + before;
+    // this workgroup's count of bucket tid = the distance to the next workgroup's offset (or the bucket's total)
+    const int nxt = (int)blockIdx.x + 1 < DC_PART ? cs.phist[(size_t)(blockIdx.x + 1) * NBK + tid] : total;
+    const int cnt = nxt - before;
+    int sum;
+    const int lb = block_scan_1024(cnt, s_wave, &sum);
+    s_lbase[tid] = lb;
+    if (tid == 0) s_lbase[NBK] = sum;
+    s_cur[tid] = lb;
+    s_gbase[tid] = gb;
+    __syncthreads();
+    const bool staged = n <= DC_STAGE;   // (workgroup-uniform; larger chunks fall back to direct scattered stores)
     for (int b0 = v0; b0 < v1; b0 += 4 * DC_BLOCK) {
         int b[4];
 #pragma unroll
@@ -600,8 +645,29 @@ __global__ __launch_bounds__(DC_BLOCK) void k_depth_scatter(const int* __restric
             b[k] = v < v1 ? (int)cs.bucket_of[v] : -1;
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (b[k] >= 0) cs.list[atomicAdd(&s_cur[b[k]], 1)] = b0 + k * DC_BLOCK + tid;
+        for (int k = 0; k < 4; k++) {
+            if (b[k] < 0) continue;
+            const int slot = atomicAdd(&s_cur[b[k]], 1);
+            const int v = b0 + k * DC_BLOCK + tid;
+            if (staged) s_list[slot] = v;
+            else cs.list[s_gbase[b[k]] + slot - s_lbase[b[k]]] = v;
+        }
+    }
+    if (!staged) return;
+    __syncthreads();
+    for (int i = tid; i < n; i += DC_BLOCK) {
+        // the bucket of LDS slot i: last b with lbase[b] <= i
+        int lo = 0, len = NBK;
+        while (len > 1) {
+            const int half = len >> 1;
+            if (s_lbase[lo + half] <= i) {
+                lo += half;
+                len -= half;
+            } else {
+                len = half;
+            }
+        }
+        cs.list[s_gbase[lo] + i - s_lbase[lo]] = s_list[i];
     }
 }
 
@@ -614,19 +680,16 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_count_buckets(const float* _
     for (int t = threadIdx.x; t < Tb; t += PRIV_BLOCK) s_hist[t] = 0;
     __syncthreads();
     const int sl = blockIdx.x;
-    const int g0 = cs.boff[sl], g1 = cs.boff[sl + 1];
-    // the next iteration's record (list entry -> 32-byte gather) is in flight while this one's tiles are walked
-    BinRec nxt;
-    bool nxt_active = g0 + (int)threadIdx.x < g1;
-    if (nxt_active) nxt = load_bin_record(rec, cs.list[g0 + threadIdx.x]);
+    const int g0 = cs.boff2[sl], g1 = cs.boff2[sl + 1];
+    // (requesting the NEXT trip's record -- list entry, then a 32-byte gather -- before this trip's tiles are walked
+    // makes the kernel slower, 77 -> 87 us at workload D; reading the records in list order instead of gathering
+    // them: 73 us; the rest of the distance to k_bin_count's 61 us is the buckets' unequal populations (max / mean
+    // 1.4 with 64 samples per bucket).  profiles/r04/kbench_cut_count_variants.txt)
     for (int base = g0; base < g1; base += PRIV_BLOCK) {   // wave-uniform trip count
-        const BinRec cur = nxt;
-        const bool active = nxt_active;
-        const int i2 = base + PRIV_BLOCK + threadIdx.x;
-        nxt_active = i2 < g1;
-        if (nxt_active) nxt = load_bin_record(rec, cs.list[i2]);
+        const int i = base + threadIdx.x;
+        const bool active = i < g1;
         TileWalk tw;
-        if (active) tw = tile_walk_setup(cur, ntx, nty, mh, row0, row1);
+        if (active) tw = tile_walk_setup(load_bin_record(rec, cs.list[i]), ntx, nty, mh, row0, row1);
         wave_for_each_tile(active, tw, ntx, 0, [&](int tile, uint64_t) { atomicAdd(&s_hist[tile - t0], 1); });
     }
     __syncthreads();
@@ -786,7 +849,9 @@ __global__ __launch_bounds__(BLOCK) void k_bin_emit_buckets(const float* __restr
         const bool want = MODE == 1 ? sl <= cs.bstar[t0 + t] : flags[t0 + t] != 0;
         s_cursor[t] = want ? ranges[t0 + t] + row[t] : -1;
     }
-    const int g0 = cs.boff[sl], g1 = cs.boff[sl + 1];
+    const int g0 = cs.boff2[sl], g1 = cs.boff2[sl + 1];
+    __syncthreads();
+#ifdef GS_CUT_EMIT_PREFETCH   // (A/B build: the next trip's record in flight during this trip's walk)
     BinRec nxt;
     int nxt_g = 0;
     bool nxt_active = g0 + (int)threadIdx.x < g1;
@@ -794,8 +859,9 @@ __global__ __launch_bounds__(BLOCK) void k_bin_emit_buckets(const float* __restr
         nxt_g = cs.list[g0 + threadIdx.x];
         nxt = load_bin_record(rec, nxt_g);
     }
-    __syncthreads();
+#endif
     for (int base = g0; base < g1; base += BLOCK) {   // wave-uniform trip count
+#ifdef GS_CUT_EMIT_PREFETCH
         const BinRec r = nxt;
         const int g = nxt_g;
         const bool active = nxt_active;
@@ -805,6 +871,12 @@ __global__ __launch_bounds__(BLOCK) void k_bin_emit_buckets(const float* __restr
             nxt_g = cs.list[i2];
             nxt = load_bin_record(rec, nxt_g);
         }
+#else
+        const bool active = base + (int)threadIdx.x < g1;
+        const int g = active ? cs.list[base + threadIdx.x] : 0;
+        BinRec r{};
+        if (active) r = load_bin_record(rec, g);
+#endif
         TileWalk tw;
         uint64_t key = 0;
         if (active) {
@@ -838,124 +910,6 @@ __global__ __launch_bounds__(BLOCK) void k_bin_emit_buckets(const float* __restr
 // Size classes (separate launches, a workgroup whose tile is in another class exits at once) keep
 // LDS per workgroup -- and with it the number of resident workgroups per CU -- matched to the tile:
 //   n <= 1024: 8.5 KiB    n <= 4096: 34 KiB    n <= 8192: 68 KiB    larger: pair-wise on global memory.
-constexpr int SORT_BLOCK = 256;
-constexpr int SORT_R = 16;
-static_assert(SORT_BLOCK == 256, "the radix-select histogram has one bin per thread");
-
-__device__ inline int slot(int i) { return i + (i >> 4); }
-
-#define GS_CE(x, y)                                                                                \
-    do {                                                                                           \
-        const uint64_t _a = (x), _b = (y);                                                         \
-        const bool _sw = _a > _b;                                                                  \
-        (x) = _sw ? _b : _a;                                                                       \
-        (y) = _sw ? _a : _b;                                                                       \
-    } while (0)
-
-// half-cleaners of stride J, J/2, ..., 1 on 16 registers
-template <int J>
-__device__ inline void reg_half_cleaners(uint64_t (&v)[SORT_R]) {
-#pragma unroll
-    for (int j = J; j > 0; j >>= 1) {
-#pragma unroll
-        for (int p = 0; p < SORT_R / 2; p++) {
-            const int lo = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-            GS_CE(v[lo], v[lo + j]);
-        }
-    }
-}
-
-// all phases k = 2 .. 16 on 16 registers
-__device__ inline void reg_sort16(uint64_t (&v)[SORT_R]) {
-#pragma unroll
-    for (int k = 2; k <= SORT_R; k <<= 1) {
-        const int h = k >> 1;
-#pragma unroll
-        for (int p = 0; p < SORT_R / 2; p++) {   // flip
-            const int blk = p / h, off = p & (h - 1);
-            GS_CE(v[blk * k + off], v[blk * k + (k - 1 - off)]);
-        }
-#pragma unroll
-        for (int j = k >> 2; j > 0; j >>= 1) {
-#pragma unroll
-            for (int p = 0; p < SORT_R / 2; p++) {
-                const int lo = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-                GS_CE(v[lo], v[lo + j]);
-            }
-        }
-    }
-}
-
-template <bool FULL_SORT>
-__device__ __forceinline__ void register_pass(uint64_t* s, int n, int n_pad, int tid) {
-    for (int blk = tid; blk < (n_pad >> 4); blk += SORT_BLOCK) {
-        const int base = blk << 4;
-        if (base >= n) continue;   // an all-padding block is already in order
-        uint64_t v[SORT_R];
-        const int sb = slot(base);
-#pragma unroll
-        for (int e = 0; e < SORT_R; e++) v[e] = (base + e < n) ? s[sb + e] : ~0ull;
-        if (FULL_SORT) reg_sort16(v);
-        else reg_half_cleaners<SORT_R / 2>(v);
-#pragma unroll
-        for (int e = 0; e < SORT_R; e++)
-            if (base + e < n) s[sb + e] = v[e];
-    }
-}
-
-// one pair-wise step on LDS (flip when j == 0), four pairs in flight per thread
-__device__ __forceinline__ void pair_step_lds(uint64_t* s, int n, int n_pad, int k, int j, int tid) {
-    const int pairs = n_pad >> 1;
-    for (int p0 = tid; p0 < pairs; p0 += 4 * SORT_BLOCK) {
-        int lo[4], hi[4];
-        uint64_t a[4], b[4];
-        bool ok[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int p = p0 + u * SORT_BLOCK;
-            if (j == 0) {
-                const int h = k >> 1;
-                const int blk = p / h, off = p & (h - 1);
-                lo[u] = blk * k + off;
-                hi[u] = blk * k + (k - 1 - off);
-            } else {
-                lo[u] = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-                hi[u] = lo[u] + j;
-            }
-            ok[u] = p < pairs && hi[u] < n;
-            if (ok[u]) {
-                a[u] = s[slot(lo[u])];
-                b[u] = s[slot(hi[u])];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (ok[u] && a[u] > b[u]) {
-                s[slot(lo[u])] = b[u];
-                s[slot(hi[u])] = a[u];
-            }
-        }
-    }
-}
-
-// sorts s[slot(0..n)) ascending; every thread of the workgroup calls it, keys already in LDS
-__device__ __forceinline__ void lds_bitonic_sort(uint64_t* s_keys, int n, int tid) {
-    int n_pad = SORT_R;
-    while (n_pad < n) n_pad <<= 1;
-    register_pass<true>(s_keys, n, n_pad, tid);
-    __syncthreads();
-    for (int k = 2 * SORT_R; k <= n_pad; k <<= 1) {
-        pair_step_lds(s_keys, n, n_pad, k, 0, tid);
-        __syncthreads();
-        for (int j = k >> 2; j >= SORT_R; j >>= 1) {
-            pair_step_lds(s_keys, n, n_pad, k, j, tid);
-            __syncthreads();
-        }
-        register_pass<false>(s_keys, n, n_pad, tid);
-        __syncthreads();
-    }
-}
-
 template <int CAP_LO, int CAP_HI>
 __global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_lds(const int* __restrict__ ranges,
                                                               const uint64_t* __restrict__ keys,
@@ -1190,38 +1144,6 @@ __device__ __forceinline__ void prefix_sort_tile(const uint64_t* __restrict__ ke
     for (int i = tid; i < K; i += SORT_BLOCK) sorted[i] = L.out[i];
 }
 
-// pair-wise bitonic network on global memory, in place (lists beyond the LDS classes)
-__device__ __forceinline__ void global_sort_tile(uint64_t* gk, int* __restrict__ sorted, int n, int tid) {
-    int n_pad = 2;
-    while (n_pad < n) n_pad <<= 1;
-    for (int k = 2; k <= n_pad; k <<= 1) {
-        for (int j = 0, first = 1; first || j > 0; first = 0) {
-            for (int p = tid; p < (n_pad >> 1); p += SORT_BLOCK) {
-                int lo, hi;
-                if (j == 0) {
-                    const int h = k >> 1;
-                    const int blk = p / h, off = p & (h - 1);
-                    lo = blk * k + off;
-                    hi = blk * k + (k - 1 - off);
-                } else {
-                    lo = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-                    hi = lo + j;
-                }
-                if (hi >= n) continue;
-                const uint64_t a = gk[lo], b = gk[hi];
-                if (a > b) {
-                    gk[lo] = b;
-                    gk[hi] = a;
-                }
-            }
-            __threadfence_block();
-            __syncthreads();
-            j = (j == 0) ? (k >> 2) : (j >> 1);
-        }
-    }
-    for (int i = tid; i < n; i += SORT_BLOCK) sorted[i] = (int)(uint32_t)gk[i];
-}
-
 // One workgroup per tile of the band.  By list length n:
 //   n <= 64, <= 256   wave 0 alone (wave_sort<1>, <4>)
 //   n <= 1024         sort1024_4waves on the padded list
@@ -1256,6 +1178,77 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort(
     } else if (PREFIX) {
         prefix_sort_tile<4096 / SORT_BLOCK>(keys + s0, sorted + s0, n, tid, L);
     }
+}
+
+// Sort of a depth-cut tile list (<= 1024 entries).  The emit lays a tile's kept entries out bucket by bucket, and
+// buckets are depth intervals in ascending order: the list is a concatenation of short unordered runs (2.7 entries on
+// average at workload D) whose runs are already in order -- every key is at most (its run's length - 1) places from
+// its final position.  An odd-even transposition network sorts exactly that in as many passes as the longest run is
+// long: four consecutive keys per thread in registers, the pair across two threads through LDS, until a pass swaps
+// nothing (then every adjacent pair is in order).  Correct for any input (n passes sort anything); a list that has
+// not settled after RUN_PASSES passes goes through the general 1024-key sort instead.
+#ifndef GS_CUT_RUN_PASSES
+#define GS_CUT_RUN_PASSES 24
+#endif
+__global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_runs(const int* __restrict__ ranges,
+                                                               const uint64_t* __restrict__ keys,
+                                                               int* __restrict__ sorted, int tile0, int64_t cap) {
+    __shared__ SortLds L;   // first / last key of every thread in L.sel[0 .. 512); the fallback's buffers
+    const int tile = tile0 + blockIdx.x;
+    const int s0 = ranges[tile];
+    const int n = ranges[tile + 1] - s0;
+    if (n <= 0 || n > GS_SORT_PREFIX || (int64_t)s0 + n > cap) return;
+    const int tid = threadIdx.x;
+    uint64_t k[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) k[r] = 4 * tid + r < n ? keys[s0 + 4 * tid + r] : ~0ull;
+    uint64_t* s_first = L.sel;
+    uint64_t* s_last = L.sel + SORT_BLOCK;
+    bool settled = false;
+    for (int pass = 0; pass < GS_CUT_RUN_PASSES; pass++) {
+        bool sw = false;
+#define GS_CE_SW(x, y)                                                                             \
+    do {                                                                                           \
+        const uint64_t _a = (x), _b = (y);                                                         \
+        const bool _s = _a > _b;                                                                   \
+        (x) = _s ? _b : _a;                                                                        \
+        (y) = _s ? _a : _b;                                                                        \
+        sw |= _s;                                                                                  \
+    } while (0)
+        GS_CE_SW(k[0], k[1]);
+        GS_CE_SW(k[2], k[3]);
+        GS_CE_SW(k[1], k[2]);
+        s_first[tid] = k[0];
+        s_last[tid] = k[3];
+        __syncthreads();
+        const uint64_t right = tid + 1 < SORT_BLOCK ? s_first[tid + 1] : ~0ull;
+        const uint64_t left = tid > 0 ? s_last[tid - 1] : 0ull;
+        if (right < k[3]) {   // (k[3] of this thread, k[0] of the next): the smaller stays here
+            k[3] = right;
+            sw = true;
+        }
+        if (left > k[0]) {    // ... the larger goes there
+            k[0] = left;
+            sw = true;
+        }
+        if (!__syncthreads_or(sw)) {
+            settled = true;
+            break;
+        }
+    }
+#undef GS_CE_SW
+    if (settled) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (4 * tid + r < n) sorted[s0 + 4 * tid + r] = (int)(uint32_t)k[r];
+        return;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) L.sel[4 * tid + r] = k[r];   // (any permutation of the list, padded with ~0)
+    __syncthreads();
+    sort1024_4waves(L.sel, L.out, tid);
+    for (int i = tid; i < n; i += SORT_BLOCK) sorted[s0 + i] = L.out[i];
 }
 
 // The rare long lists: a small grid walks the tiles.  4096 < n <= 8192: prefix mode only (full mode:
@@ -1304,7 +1297,6 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_flagged(const int* __r
     }
 }
 
-static size_t sort_lds_bytes(int cap) { return (size_t)(cap + cap / SORT_R) * sizeof(uint64_t); }
 
 static void sort_attr_once() {
     static bool attr_set = false;
@@ -1567,6 +1559,7 @@ int gs_tile_count_cut(const void* bin_records, int N, const int32_t* visible_cou
     int32_t* counts = workspace;
     int32_t* hist = workspace + T;
     k_depth_hist<<<DC_PART, DC_BLOCK, 0, s>>>(visible_count, cs);
+    k_depth_colscan<<<NBK / 64, 1024, 0, s>>>(cs);
     k_depth_scatter<<<DC_PART, DC_BLOCK, 0, s>>>(visible_count, cs);
     k_bin_count_buckets<<<NBK, PRIV_BLOCK, sizeof(int) * (size_t)Tb, s>>>((const float*)bin_records, n_tiles_x, n_tiles_y,
                                                                           mh_dist, tile_row0, tile_row1, hist, cs);
@@ -1593,8 +1586,12 @@ int gs_tile_emit_sort_cut(const void* bin_records, int N, int n_tiles_x, int n_t
     k_bin_emit_buckets<1, GS_CUT_EMIT_BLOCK><<<NBK, GS_CUT_EMIT_BLOCK, sizeof(int) * (size_t)Tb, s>>>(
         (const float*)bin_records, n_tiles_x, n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, workspace + T, keys,
         S, nullptr, cs);
-    // every kept list has at most GS_SORT_PREFIX entries: the wave-level sorts order it completely
+    // every kept list has at most GS_SORT_PREFIX entries, laid out as short runs in depth order
+#ifdef GS_CUT_GENERAL_SORT   // (A/B build: the general <= 1024 sorts)
     k_tile_sort<false><<<Tb, SORT_BLOCK, 0, s>>>(tile_ranges, keys, sorted_gaussians, t0, S);
+#else
+    k_tile_sort_runs<<<Tb, SORT_BLOCK, 0, s>>>(tile_ranges, keys, sorted_gaussians, t0, S);
+#endif
     return check_launch("tile_emit_sort_cut");
 }
 
@@ -1605,7 +1602,7 @@ int gs_cut_debug_views(int32_t* cut_workspace, int N, int n_tiles, int32_t** bst
     if (bstar) *bstar = cs.bstar;
     if (totals) *totals = cs.totals;
     if (bounds) *bounds = cs.bounds;
-    if (bucket_offsets) *bucket_offsets = cs.boff;
+    if (bucket_offsets) *bucket_offsets = cs.boff2;
     if (ctrl) *ctrl = cs.ctrl;
     return GS_OK;
 }

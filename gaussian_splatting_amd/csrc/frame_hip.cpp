@@ -602,6 +602,10 @@ struct ShardSpec {
     c10::intrusive_ptr<c10d::ProcessGroup> pg;          // null with the test hook
     py::object a2a_hook;                                // tests: stands in for all_to_all_single, no image gather
     int64_t band_pixel_rows = 0, padded_height = 0;
+    // band layout: equal bands are all-gathered in place; any other split (cost-balanced bands) as chunks of
+    // chunk_rows = 16 x tallest band + 1 pixel rows whose last row carries the band's per-row costs
+    bool equal_bands = true;
+    int64_t chunk_rows = 0;
     ~ShardSpec() {   // the record may die on an autograd thread: Python references are dropped under the GIL
         if (!a2a_hook.ptr()) return;
         if (Py_IsInitialized()) {
@@ -635,6 +639,13 @@ Tensor make_guard(const FramePtr& fr) {
     return torch::from_blob(holder, {1}, [](void* p) { delete reinterpret_cast<FramePtr*>(p); }, torch::kUInt8);
 }
 FrameRec& frame_of(const Tensor& guard) { return **reinterpret_cast<FramePtr*>(guard.data_ptr()); }
+
+// cost-balanced bands: the latest frame's gathered per-row costs (pinned host memory) and the event behind the kernel
+// that wrote them
+struct RowCosts {
+    Tensor host;
+    hipEvent_t event = nullptr;
+} g_row_costs;
 
 struct PlanInfo {
     int64_t v_lo = 0, v_hi = 0, V = 0, S = 0;
@@ -755,7 +766,8 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
         // the other rows' splat counts / weights: no zero fill (5 us per frame); a stand-in exchange (tests, the
         // one-GPU measurement of a rank's frame) returns the band image with zeros outside it
         const bool whole = sp.a2a_hook.is_none();
-        const int64_t image_rows = sp.a2a_hook.is_none() ? sp.padded_height : 0;
+        const int64_t image_rows =
+            !sp.a2a_hook.is_none() ? 0 : (sp.equal_bands ? sp.padded_height : 16 * (int64_t)nty + sp.chunk_rows);
         bool rendered = false;
         int64_t capacity = 0;
         if (speculative) {
@@ -885,13 +897,40 @@ struct OwnerRender : public torch::autograd::Function<OwnerRender> {
         ctx->saved_data["fr"] = guard;
         ctx->set_materialize_grads(false);
         Tensor image = fr.out.image;
-        if (sp.a2a_hook.is_none()) {
+        if (sp.a2a_hook.is_none() && sp.equal_bands) {
             // in-place all-gather of the equal bands: every rank's band sits at its own rows of the padded buffer
             const int64_t chunk = sp.band_pixel_rows * fr.W * 3;
             Tensor flat = image.view({-1}).narrow(0, 0, sp.G * chunk);
             Tensor mine = flat.narrow(0, sp.rank * chunk, chunk).clone();
             void* stream = cur_stream();
             timed_region("rccl_all_gather_image", stream, [&] { sp.pg->_allgather_base(flat, mine)->wait(); });
+        } else if (sp.a2a_hook.is_none()) {
+            // cost-balanced bands: chunks of chunk_rows pixel rows, the last one carrying this band's per-row costs;
+            // the gathered chunks are assembled into the frame and the summed costs land in pinned host memory
+            // (ShardedRasterizer reads them before the next frame: take_row_costs)
+            void* stream = cur_stream();
+            const int nty = (fr.H + 15) / 16, ntx = (fr.W + 15) / 16;
+            const int64_t row_floats = 3 * (int64_t)fr.W, crows = sp.chunk_rows;
+            float* base = image.data_ptr<float>();
+            ok(gs_band_row_costs(fr.ranges.data_ptr<int32_t>(), ntx, nty, fr.row0, fr.row1, 64, GS_SORT_PREFIX,
+                                 base + (16 * (int64_t)fr.row0 + crows - 1) * row_floats, stream));
+            Tensor mine = image.view({-1}).narrow(0, 16 * (int64_t)fr.row0 * row_floats, crows * row_floats);
+            Tensor gathered = torch::empty({sp.G * crows * row_floats}, image.options());
+            timed_region("rccl_all_gather_image", stream, [&] { sp.pg->_allgather_base(gathered, mine)->wait(); });
+            Tensor full = torch::empty({fr.H, fr.W, 3}, image.options());
+            Tensor host_costs = torch::empty({nty}, torch::TensorOptions().dtype(torch::kFloat32).pinned_memory(true));
+            ok(gs_band_assemble(gathered.data_ptr(), sp.bounds.data(), sp.G, (int)crows, fr.W, fr.H, nty, full.data_ptr(),
+                                host_costs.data_ptr(), stream));
+            hipEvent_t ev;
+            hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            hip_ok(hipEventRecord(ev, (hipStream_t)stream));
+            {
+                std::lock_guard<std::mutex> lock(g_mutex);
+                if (g_row_costs.event) (void)hipEventDestroy(g_row_costs.event);
+                g_row_costs.host = host_costs;
+                g_row_costs.event = ev;
+            }
+            return full;
         }
         return image.narrow(0, 0, fr.H);
     }
@@ -966,7 +1005,7 @@ std::tuple<Tensor, Tensor, Tensor> sharded_rasterize(
     Tensor quaternion, Tensor scale, Tensor opacity, Tensor rgb, c10::optional<Tensor> sh, Tensor camera_T_world, Tensor K,
     int64_t width, int64_t height, double near_thresh, double far_thresh, double cull_mask_padding, double mh_dist,
     Tensor background_rgb, int64_t world_size, int64_t rank, std::vector<int64_t> bounds, std::vector<int64_t> owner_blocks,
-    py::object process_group, py::object all_to_all_hook) {
+    py::object process_group, py::object all_to_all_hook, bool cost_bands) {
     const auto dev = xyz.device();
     const int64_t N = xyz.size(0);
     TORCH_CHECK(xyz.is_cuda(), "xyz is not a CUDA tensor");
@@ -1004,14 +1043,23 @@ std::tuple<Tensor, Tensor, Tensor> sharded_rasterize(
     }
     sp.band_pixel_rows = 16 * ((nty + G - 1) / G);
     sp.padded_height = sp.band_pixel_rows * G;
-    if (all_to_all_hook.is_none()) {
-        // the band images are all-gathered IN PLACE: rank r's band must start at row r * band_pixel_rows of the padded
-        // buffer, i.e. the bands must be the equal-band layout (sharded.band_of); cost-balanced bands gather otherwise
+    {
         const int64_t rows_per = (nty + G - 1) / G;
-        for (int r = 0; r <= G; r++)
-            TORCH_CHECK(sp.bounds[r] == std::min<int64_t>(nty, r * rows_per),
-                        "sharded_rasterize gathers equal bands in place: bounds[", r, "] = ", sp.bounds[r], ", expected ",
-                        std::min<int64_t>(nty, r * rows_per));
+        int64_t tallest = 0;
+        for (int r = 0; r < G; r++) {
+            TORCH_CHECK(sp.bounds[r] <= sp.bounds[r + 1], "bounds must be ascending");
+            tallest = std::max<int64_t>(tallest, sp.bounds[r + 1] - sp.bounds[r]);
+            sp.equal_bands = sp.equal_bands && sp.bounds[r] == std::min<int64_t>(nty, r * rows_per);
+        }
+        sp.equal_bands = sp.equal_bands && sp.bounds[G] == nty;
+        TORCH_CHECK(sp.bounds[0] == 0 && sp.bounds[G] == nty, "bounds must cover the tile rows [0, ", nty, ")");
+        // equal bands are gathered in place; the cost policy always gathers chunks (their last row is how the costs
+        // travel), whatever this frame's split happens to be
+        TORCH_CHECK(cost_bands || sp.equal_bands || !all_to_all_hook.is_none(),
+                    "sharded_rasterize: unequal bands need cost_bands = true (the chunked image gather)");
+        if (cost_bands) sp.equal_bands = false;
+        sp.chunk_rows = 16 * tallest + 1;
+        TORCH_CHECK(sp.equal_bands || nty <= 3 * width, "image too narrow for the cost row");
     }
     fr->row0 = sp.bounds[me];
     fr->row1 = sp.bounds[me + 1];
@@ -1127,6 +1175,37 @@ py::dict collect_timing() {
     return d;
 }
 
+// cost-balanced bands: the per-row costs the latest frame's image gather left behind (None if there are none); waits
+// for the kernel that wrote them, which has long finished when the next frame asks
+py::object take_row_costs() {
+    Tensor host;
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        host = g_row_costs.host;
+        ev = g_row_costs.event;
+        g_row_costs.host = Tensor();
+        g_row_costs.event = nullptr;
+    }
+    if (!host.defined()) return py::none();
+    if (ev) {
+        hip_ok(hipEventSynchronize(ev));
+        (void)hipEventDestroy(ev);
+    }
+    py::list out;
+    const float* p = host.data_ptr<float>();
+    for (int64_t i = 0; i < host.numel(); i++) out.append(p[i]);
+    return out;
+}
+
+// tests: shrink / grow every stored capacity guess (a too small one must be detected and the frame's emit, sort and
+// render repeated with the exact sizes)
+void debug_scale_capacity_hints(double factor) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    for (auto& kv : g_capacity) kv.second = (int64_t)(kv.second * factor);
+    for (auto& kv : g_overflow_capacity) kv.second = (int64_t)(kv.second * factor);
+}
+
 void set_segments(int mode) { g_segments = mode; }
 void set_depth_cut(int mode, int64_t min_mean_list) {
     g_depth_cut = mode;
@@ -1148,12 +1227,14 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("width"), py::arg("height"), py::arg("near_thresh"), py::arg("far_thresh"), py::arg("cull_mask_padding"),
           py::arg("mh_dist"), py::arg("background_rgb"), py::arg("row0") = 0, py::arg("row1") = -1);
     m.def("sharded_rasterize", &sharded_rasterize,
-          "one rank of the tile-row sharded frame, owner-sliced gradients, equal bands: -> (image, culling_mask, uv)");
+          "one rank of the tile-row sharded frame, owner-sliced gradients, equal or cost-balanced bands: -> (image, culling_mask, uv)");
     m.def("last_plan", &last_plan);
+    m.def("take_row_costs", &take_row_costs);
     m.def("counters", &counters);
     m.def("reset_counters", &reset_counters);
     m.def("set_modes", &set_modes, py::arg("sort_prefix"), py::arg("early_render"));
     m.def("set_segments", &set_segments, py::arg("mode"));
+    m.def("debug_scale_capacity_hints", &debug_scale_capacity_hints, py::arg("factor"));
     m.def("set_depth_cut", &set_depth_cut, py::arg("mode"), py::arg("min_mean_list") = 0);
     m.def("set_band_compact", &set_band_compact, py::arg("on"));
     m.def("last_tile_flags", &last_tile_flags, py::arg("clear") = false);

@@ -204,7 +204,8 @@ struct CutState {                       // views into the caller's cut workspace
     int* ctrl;                          // [0] deepest bucket any tile wants, [1] flagged tiles of this frame
     int* totals;                        // [T]  n(t)
     int* bstar;                         // [T]  b*(t), -1: nothing kept
-    int* boff;                          // [BUCKETS + 1]
+    int* boff;                          // [BUCKETS + 1] scratch: bucket totals at [1 ..]
+    int* boff2;                         // [BUCKETS + 1] first list position of each bucket, [BUCKETS] = V
     uint32_t* bounds;                   // [BUCKETS] inclusive upper depth bound (sortable bits) of each bucket
     int* phist;                         // [DC_PART][BUCKETS]
     int* list;                          // [N]
@@ -212,7 +213,7 @@ struct CutState {                       // views into the caller's cut workspace
 };
 __host__ __device__ inline size_t cut_ws_ints(int N, int T) {
     const size_t n = (size_t)(N > 0 ? N : 1), t = (size_t)(T > 0 ? T : 1);
-    return 8 + 2 * t + (GS_CUT_BUCKETS + 8) + GS_CUT_BUCKETS + (size_t)DC_PART * GS_CUT_BUCKETS + n + (n + 1) / 2 + 16;
+    return 8 + 2 * t + 2 * (GS_CUT_BUCKETS + 8) + GS_CUT_BUCKETS + (size_t)DC_PART * GS_CUT_BUCKETS + n + (n + 1) / 2 + 16;
 }
 __host__ __device__ inline CutState cut_state_of(int32_t* ws, int N, int T) {
     const size_t n = (size_t)(N > 0 ? N : 1), t = (size_t)(T > 0 ? T : 1);
@@ -222,6 +223,7 @@ __host__ __device__ inline CutState cut_state_of(int32_t* ws, int N, int T) {
     c.totals = p; p += t;
     c.bstar = p; p += t;
     c.boff = p; p += GS_CUT_BUCKETS + 8;
+    c.boff2 = p; p += GS_CUT_BUCKETS + 8;
     c.bounds = (uint32_t*)p; p += GS_CUT_BUCKETS;
     c.phist = p; p += (size_t)DC_PART * GS_CUT_BUCKETS;
     c.list = p; p += n;

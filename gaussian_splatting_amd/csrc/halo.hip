@@ -288,6 +288,47 @@ __global__ __launch_bounds__(HB) void k_halo_gather_sum(
     for (int j = 0; j < 9; j++) o[j] = acc[j];
 }
 
+// ---- cost-balanced bands (sharded.py band_policy "cost") -----------------------------------
+// Bands of unequal height cannot be all-gathered in place: rank r contributes a chunk of chunk_rows pixel rows
+// (16 x the tallest band + 1) that starts at its band; the chunk's LAST row carries, as floats, the cost of every
+// tile row of the rank's band (0 elsewhere) -- what the next frame's bands are balanced on.
+//   k_band_row_costs   cost[r] = sum over the row's tiles of min(list length, cap) + tile_cost per tile
+//   k_band_assemble    gathered chunks -> the frame (pixel row y comes from the band that owns tile row y / 16);
+//                      its last workgroup sums the cost rows straight into the caller's pinned host buffer
+__global__ __launch_bounds__(GS_WAVE) void k_band_row_costs(const int* __restrict__ ranges, int ntx, int row0, int row1,
+                                                            int tile_cost, int cap, float* __restrict__ cost_row) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    int sum = 0;
+    if (r >= row0 && r < row1) {
+        for (int t = lane; t < ntx; t += GS_WAVE) sum += min(ranges[r * ntx + t + 1] - ranges[r * ntx + t], cap);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) sum += __shfl_xor(sum, d);
+        sum += tile_cost * ntx;
+    }
+    if (lane == 0) cost_row[r] = (float)sum;
+}
+
+__global__ __launch_bounds__(HB) void k_band_assemble(const float* __restrict__ gathered, RankInts bounds, int G,
+                                                      int chunk_rows, int row_floats, int H, int R,
+                                                      float* __restrict__ image, float* __restrict__ host_costs) {
+    const int y = blockIdx.x;
+    if (y == H) {   // the extra workgroup: next frame's row costs
+        for (int q = threadIdx.x; q < R; q += HB) {
+            float c = 0;
+            for (int r = 0; r < G; r++) c += gathered[((size_t)r * chunk_rows + chunk_rows - 1) * row_floats + q];
+            host_costs[q] = c;
+        }
+        __threadfence_system();
+        return;
+    }
+    const int ty = y >> 4;
+    int r = 0;
+    while (r + 1 < G && ty >= bounds.v[r + 1]) r++;
+    const float* src = gathered + ((size_t)r * chunk_rows + (y - 16 * bounds.v[r])) * row_floats;
+    float* dst = image + (size_t)y * row_floats;
+    for (int i = threadIdx.x; i < row_floats; i += HB) dst[i] = src[i];
+}
+
 static RankInts rank_ints(const int32_t* a, int n) {
     RankInts r;
     for (int i = 0; i <= GS_MAX_RANKS; i++) r.v[i] = i < n ? a[i] : 0;
@@ -350,6 +391,25 @@ int gs_halo_plan_masked(const uint32_t* mask, int N, const int32_t* visible_coun
     k_halo_send_index_bounds<<<nblk + 1, HB, 0, s>>>(mask, offsets, nblk, visible_count, pre_offsets,
                                                      rank_ints(owner_blocks, G + 1), G, rank, send_index, vb, Pb, plan);
     return check_launch("halo_plan_masked");
+}
+
+int gs_band_row_costs(const int32_t* tile_ranges, int n_tiles_x, int n_tile_rows, int tile_row0, int tile_row1,
+                      int tile_cost, int cap, void* cost_row, void* stream) {
+    GS_REQUIRE(n_tiles_x > 0 && n_tile_rows > 0 && tile_row0 >= 0 && tile_row0 <= tile_row1 && tile_row1 <= n_tile_rows,
+               "band_row_costs: bad tile rows");
+    k_band_row_costs<<<n_tile_rows, GS_WAVE, 0, (hipStream_t)stream>>>(tile_ranges, n_tiles_x, tile_row0, tile_row1, tile_cost,
+                                                                       cap, (float*)cost_row);
+    return check_launch("band_row_costs");
+}
+
+int gs_band_assemble(const void* gathered, const int32_t* band_rows, int G, int chunk_rows, int W, int H, int n_tile_rows,
+                     void* image, void* host_costs, void* stream) {
+    GS_REQUIRE(G >= 1 && G <= GS_MAX_RANKS, "band_assemble: 1 <= G <= %d", GS_MAX_RANKS);
+    GS_REQUIRE(W > 0 && H > 0 && chunk_rows > 0 && n_tile_rows <= 3 * W, "band_assemble: bad sizes");
+    GS_REQUIRE(host_costs != nullptr, "band_assemble: host_costs must not be null");
+    k_band_assemble<<<H + 1, HB, 0, (hipStream_t)stream>>>((const float*)gathered, rank_ints(band_rows, G + 1), G, chunk_rows,
+                                                           3 * W, H, n_tile_rows, (float*)image, (float*)host_costs);
+    return check_launch("band_assemble");
 }
 
 int gs_halo_gather_sum(const uint32_t* mask, const int32_t* workspace, int N, int G, int rank,

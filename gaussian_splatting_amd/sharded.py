@@ -652,7 +652,12 @@ class ShardedRasterizer:
                 raise ValueError("grad_mode 'owner' needs owned= (the parameter slices of this rank)")
             o = (owned.xyz, owned.quaternion, owned.scale, owned.opacity, owned.rgb, owned.sh)
             use_native = NATIVE if self.native is None else self.native
-            nat = fused.native() if (use_fused and use_native and self.band_policy == "equal") else None
+            nat = fused.native() if (use_fused and use_native) else None
+            if nat is not None and self.band_policy == "cost":
+                # the costs the previous frame's image gather left in pinned memory (csrc/frame_hip.cpp) -> this frame's bands
+                costs = nat.take_row_costs()
+                if costs is not None:
+                    self.set_row_costs(costs)
             if nat is not None:
                 g = gaussians
                 nat.set_modes(bool(fused.SORT_PREFIX), bool(fused.EARLY_RENDER))
@@ -665,7 +670,7 @@ class ShardedRasterizer:
                     *o, g.xyz, g.quaternion, g.scale, g.opacity, g.rgb, g.sh, camera_T_world, camera.K, int(camera.width),
                     int(camera.height), near_thresh, far_thresh, cull_mask_padding, mh_dist, background_rgb,
                     self.world_size, self.rank, list(self.bounds), owner_blocks(g.xyz.shape[0], self.world_size), group,
-                    self.all_to_all)
+                    self.all_to_all, self.band_policy == "cost")
                 p = nat.last_plan()
                 self.last_plan = SimpleNamespace(send_splits=p["send_splits"], recv_splits=p["recv_splits"],
                                                  v_lo=p["v_lo"], v_hi=p["v_hi"])

@@ -366,6 +366,19 @@ int gs_render_depth(const void* packed, const void* xyz_camera_frame, const int3
                     const int32_t* sorted_gaussians, int W, int H, float alpha_threshold,
                     void* depth_image, void* stream);
 
+/* Cost-balanced bands (multi-GPU; no reference counterpart): the band images of unequal bands are all-gathered as
+ * equal chunks of chunk_rows = 16 x (tallest band) + 1 pixel rows, each starting at its rank's band; the last row of
+ * a chunk carries the per-tile-row costs of that band (floats; 0 outside the band).
+ *   gs_band_row_costs   cost_row[r] = sum over the tiles of row r of min(list length, cap) + tile_cost per tile, for
+ *                       r in [tile_row0, tile_row1), 0 elsewhere (n_tile_rows floats)
+ *   gs_band_assemble    gathered float[G][chunk_rows][3 W] -> image float[H][3 W] (pixel row y from the chunk of the
+ *                       band that holds tile row y / 16, band_rows = the G + 1 boundaries, HOST array) and
+ *                       host_costs float[n_tile_rows] (device-accessible PINNED host memory: the summed cost rows,
+ *                       what balances the next frame's bands; record an event behind the call and wait for it) */
+int gs_band_row_costs(const int32_t* tile_ranges, int n_tiles_x, int n_tile_rows, int tile_row0, int tile_row1,
+                      int tile_cost, int cap, void* cost_row, void* stream);
+int gs_band_assemble(const void* gathered, const int32_t* band_rows, int G, int chunk_rows, int W, int H, int n_tile_rows,
+                     void* image, void* host_costs, void* stream);
 /* ---- multi-GPU: tile-row bands with owner-sliced gradients ------------------------------------
  * (no reference counterpart: the reference is single-GPU; BASELINE.json north_star asks for frames
  * sharded by tile rows over up to 8 GPUs.)  Rank b renders tile rows [band_rows[b], band_rows[b+1]);

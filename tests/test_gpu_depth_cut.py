@@ -192,3 +192,26 @@ def test_auto_policy_takes_the_cut_only_for_long_lists():
             assert fused.counters().get("depth_cut_frames", 0) - before == expect, (N, W, H)
     finally:
         fused.DEPTH_CUT = prev
+
+
+def test_cut_frame_with_too_small_capacity_guesses_is_repeated():
+    """native orchestration: emit, sort and render (with its repair chain) are enqueued on capacities guessed from
+    earlier frames before the host has the frame's counts; guesses that turn out too small (kept entries, or the
+    complete count the overflow buffers are sized by) must be detected and the three steps repeated"""
+    nat = fused.native()
+    if nat is None:
+        pytest.skip("native frame module not built")
+    W, H = 256, 192
+    g, cam, T = make_scene(300_000, W, H, 0, seed=5, device=DEV)
+    left = g.xyz[:, 0] < 0
+    g.opacity[left] = -5.5            # flagged and unflagged tiles in one frame: the overflow buffers are used
+    gi = make_grad_image(W, H, seed=2, device=DEV)
+    ref = run_frame(g, cam, T, gi, False, True)
+    first = run_frame(g, cam, T, gi, True, True)
+    same_frame(first, ref)
+    fused.reset_counters()
+    for factor in (0.02, 1.0, 0.5, 50.0):
+        nat.debug_scale_capacity_hints(factor)
+        same_frame(run_frame(g, cam, T, gi, True, True), ref)
+    c = fused.counters()
+    assert c["depth_cut_frames"] == 4 and c["capacity_misses"] >= 2, c

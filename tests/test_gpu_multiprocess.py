@@ -79,7 +79,7 @@ def _worker(rank, world, port, mode, native, deg, out, band_policy="equal"):
     (2, "owner", True, "equal"), (3, "owner", True, "equal"), (8, "owner", True, "equal"),
     (2, "owner", False, "equal"), (2, "replicated", None, "equal"),
     # cost-balanced bands: the per-row costs ride on the image gather and the next frame's bands follow them
-    (3, "owner", False, "cost")])
+    (3, "owner", False, "cost"), (3, "owner", True, "cost"), (2, "owner", True, "cost")])
 def test_sharded_frame_on_several_ranks_of_one_gpu(world, mode, native, policy):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")

@@ -304,11 +304,13 @@ def run_both_sort_modes(make, grad_image):
             if getattr(g, k) is not None:
                 getattr(g, k).requires_grad_(True)
         fused.SORT_PREFIX = mode
+        prev_cut, fused.DEPTH_CUT = fused.DEPTH_CUT, False   # the prefix SORT is what these tests are about
         try:
             img, mask, uv = fused.rasterize(g, T, cam, use_sh_precompute=True,
                                             background_rgb=torch.full((3,), 0.5, device=DEV), **kw)
         finally:
             fused.SORT_PREFIX = True
+            fused.DEPTH_CUT = prev_cut
         uv.retain_grad()
         img.backward(grad_image)
         out[mode] = (img.detach(), {k: getattr(g, k).grad for k in PARAMS if getattr(g, k) is not None}, uv.grad)

@@ -80,11 +80,9 @@ def test_halo_plan_matches_reference_and_oracle(G):
                                                       (2, 3, 20000, 640, 472, 2.0, "equal-uvloss")])
 @pytest.mark.parametrize("native", ["native+compact", "native", "python"])
 def test_owner_mode_with_simulated_ranks(G, deg, N, W, H, near, policy, native):
-    """native: the frame's orchestration in C++ (csrc/frame_hip.cpp sharded_rasterize; equal bands) -- with the
-    band-compact per-Gaussian stage or with the replicated one -- or in Python"""
+    """native: the frame's orchestration in C++ (csrc/frame_hip.cpp sharded_rasterize; equal and cost-balanced bands)
+    -- with the band-compact per-Gaussian stage or with the replicated one -- or in Python"""
     from gaussian_splatting_amd import sharded
-    if native != "python" and not policy.startswith("equal"):
-        pytest.skip("the native orchestration covers the equal-band policy")
     prev = sharded.NATIVE, sharded.BAND_COMPACT
     sharded.NATIVE, sharded.BAND_COMPACT = native != "python", native == "native+compact"
     try:
@@ -221,10 +219,17 @@ def test_cost_band_policy_single_rank_rccl(grad_mode):
             for k, ref in ref_grads.items():
                 assert scaled_err(getattr(holder, k).grad, ref) < 1e-5, (frame, k)
             if frame == 0:
-                assert rast._pending_costs is not None
-                costs = rast._pending_costs[0]
-                torch.cuda.synchronize()
-                assert costs.shape[0] == (H + 15) // 16 and float(costs.min()) >= rast.TILE_COST * ((W + 15) // 16)
+                if grad_mode == "owner":   # the native orchestration: the costs wait in pinned memory for the next frame
+                    from gaussian_splatting_amd import fused
+                    costs = fused.native().take_row_costs()
+                    assert costs is not None and len(costs) == (H + 15) // 16
+                    assert min(costs) >= rast.TILE_COST * ((W + 15) // 16)
+                    rast.set_row_costs(costs)
+                else:
+                    assert rast._pending_costs is not None
+                    costs = rast._pending_costs[0]
+                    torch.cuda.synchronize()
+                    assert costs.shape[0] == (H + 15) // 16 and float(costs.min()) >= rast.TILE_COST * ((W + 15) // 16)
         assert rast.bounds == [0, (H + 15) // 16]
     finally:
         if created:
