@@ -158,7 +158,7 @@ std::pair<int32_t*, hipEvent_t> pinned_slot(int dev) {
     PinnedRing& ring = g_pinned[dev];
     if (ring.bufs.empty()) {
         for (int i = 0; i < 4; i++) {
-            ring.bufs.push_back(torch::empty({32}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true)));
+            ring.bufs.push_back(torch::empty({96}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true)));
             hipEvent_t ev;
             hip_ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             ring.events.push_back(ev);
@@ -696,6 +696,15 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
         // what the binning walks: the first *items_n rows of (bin_uv, bin_conic, bin_xyz) or an index list into them
         const float *bin_uv = uv, *bin_conic = conic, *bin_xyz = xyz_cam;
         const int32_t *items_n = count, *subset = nullptr, *subset_n = nullptr;
+        // the frame's host read: (S, V, -) from the tile scan and the plan record behind it.  Band-compact path: both
+        // kernels write straight into the pinned slot (no copy kernel in the stream); otherwise one copy of the record
+        int32_t* host;
+        hipEvent_t ready;
+        {
+            std::lock_guard<std::mutex> lock(g_mutex);
+            std::tie(host, ready) = pinned_slot((int)dev.index());
+        }
+        const int rec_at = compact ? 3 : 2;   // where the plan record starts in the host buffer
         if (compact) {
             timed("gs_band_project", stream, [&] {
                 return gs_band_project(fr.xyz.data_ptr(), fr.scale.data_ptr(), fr.opacity.data_ptr(), fr.camera_T_world.data_ptr(),
@@ -705,7 +714,7 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
             });
             timed("gs_halo_plan", stream, [&] {
                 return gs_halo_plan_masked((const uint32_t*)h, N, count, ws, sp.owner_blocks.data(), G, me, h + 2 * (int64_t)N,
-                                           h + N, record, stream);
+                                           h + N, record, host + rec_at, stream);
             });
             timed("gs_preprocess_forward", stream, [&] {
                 return gs_preprocess_forward_list(fr.xyz.data_ptr(), fr.quaternion.data_ptr(), fr.scale.data_ptr(),
@@ -734,7 +743,7 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
         }
         timed("gs_tile_count", stream, [&] {
             return gs_tile_count(bin_uv, bin_conic, N, items_n, subset, subset_n, ntx, nty, (float)fr.mh_dist, row0, row1,
-                                 tile_counts, ranges_buf, nullptr, stream);
+                                 tile_counts, ranges_buf, compact ? host : nullptr, stream);
         });
         auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(dev);
         Tensor sorted, keys;
@@ -751,15 +760,14 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
         };
         const HintKey key{(int)dev.index(), N, T, row0, row1};
         int64_t guess = -1;
-        int32_t* host;
-        hipEvent_t ready;
         {
             std::lock_guard<std::mutex> lock(g_mutex);
             auto it = g_capacity.find(key);
             if (it != g_capacity.end()) guess = it->second;
-            std::tie(host, ready) = pinned_slot((int)dev.index());
         }
-        hip_ok(hipMemcpyAsync(host, ranges_buf + T, (2 + plan_ints) * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        if (!compact)
+            hip_ok(hipMemcpyAsync(host, ranges_buf + T, (2 + plan_ints) * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                  (hipStream_t)stream));
         hip_ok(hipEventRecord(ready, (hipStream_t)stream));
         const bool speculative = guess >= 0;
         // a band.  With the real exchange the other bands' rows are overwritten by the all-gather and nothing reads
@@ -781,7 +789,7 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
         }
         hip_ok(hipEventSynchronize(ready));
         // the plan's host half: rows to send, V, v_lo, v_hi, send[G], recv[G]
-        const int32_t* rec = host + 2;
+        const int32_t* rec = host + rec_at;
         const int64_t S = host[0], V = rec[1], L = compact ? rec[0] : rec[1];
         {
             std::lock_guard<std::mutex> lock(g_mutex);

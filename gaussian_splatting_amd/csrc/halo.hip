@@ -138,7 +138,7 @@ __device__ inline void halo_bounds_block(
     const int* __restrict__ visible_count, const int* __restrict__ pre_offsets, const RankInts& owner_blk,
     int G, int me, int* __restrict__ vb /*[G+1]*/,
     int* __restrict__ Pb /*[G][G+1]*/, int* __restrict__ plan /*[4+2G]*/, int n_waves,
-    int* s_vb /*[GS_MAX_RANKS + 1]*/, int (*s_P)[GS_MAX_RANKS + 1]) {
+    int* s_vb /*[GS_MAX_RANKS + 1]*/, int (*s_P)[GS_MAX_RANKS + 1], int* __restrict__ plan_host = nullptr) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int V = *visible_count;
     // Two rounds of loads for the whole workgroup: (1) every boundary's visible index, (2) per boundary the block of
@@ -198,6 +198,21 @@ __device__ inline void halo_bounds_block(
         plan[4 + t] = s_P[me][t + 1] - s_P[me][t];       // rows I send to owner t
         plan[4 + G + t] = s_P[t][me + 1] - s_P[t][me];   // rows I receive from sender t
     }
+    // the same record straight into the caller's pinned host buffer (the frame's host read without a copy kernel
+    // in the stream; the caller waits for an event behind a LATER kernel of the stream)
+    if (plan_host != nullptr) {
+        if (t == 0) {
+            plan_host[0] = s_P[me][G];
+            plan_host[1] = V;
+            plan_host[2] = s_vb[me];
+            plan_host[3] = s_vb[me + 1];
+        }
+        if (t < G) {
+            plan_host[4 + t] = s_P[me][t + 1] - s_P[me][t];
+            plan_host[4 + G + t] = s_P[t][me + 1] - s_P[t][me];
+        }
+        __threadfence_system();
+    }
 }
 
 __global__ __launch_bounds__(GS_WAVE*(GS_MAX_RANKS + 1)) void k_halo_bounds(
@@ -215,13 +230,14 @@ __global__ __launch_bounds__(GS_WAVE*(GS_MAX_RANKS + 1)) void k_halo_bounds(
 __global__ __launch_bounds__(HB) void k_halo_send_index_bounds(
     const uint32_t* __restrict__ mask, const int* __restrict__ offsets, int nblk,
     const int* __restrict__ visible_count, const int* __restrict__ pre_offsets, RankInts owner_blk, int G, int me,
-    int* __restrict__ send_index, int* __restrict__ vb, int* __restrict__ Pb, int* __restrict__ plan) {
+    int* __restrict__ send_index, int* __restrict__ vb, int* __restrict__ Pb, int* __restrict__ plan,
+    int* __restrict__ plan_host) {
     __shared__ int s_cnt[HB / GS_WAVE];
     __shared__ int s_vb[GS_MAX_RANKS + 1];
     __shared__ int s_P[GS_MAX_RANKS][GS_MAX_RANKS + 1];
     if ((int)blockIdx.x == nblk) {
         halo_bounds_block(mask, offsets, nblk, visible_count, pre_offsets, owner_blk, G, me, vb, Pb, plan,
-                          HB / GS_WAVE, s_vb, s_P);
+                          HB / GS_WAVE, s_vb, s_P, plan_host);
         return;
     }
     const int v = blockIdx.x * HB + threadIdx.x;
@@ -376,7 +392,7 @@ int gs_halo_plan(const void* uvs, const void* conic, int N, const int32_t* visib
 
 int gs_halo_plan_masked(const uint32_t* mask, int N, const int32_t* visible_count,
                         const int32_t* preprocess_workspace, const int32_t* owner_blocks, int G, int rank,
-                        int32_t* workspace, int32_t* send_index, int32_t* plan, void* stream) {
+                        int32_t* workspace, int32_t* send_index, int32_t* plan, int32_t* plan_host, void* stream) {
     GS_REQUIRE(G >= 1 && G <= GS_MAX_RANKS, "halo_plan: 1 <= G <= %d", GS_MAX_RANKS);
     GS_REQUIRE(rank >= 0 && rank < G, "halo_plan: bad rank");
     GS_REQUIRE(N > 0, "halo_plan: N must be positive");
@@ -389,7 +405,8 @@ int gs_halo_plan_masked(const uint32_t* mask, int N, const int32_t* visible_coun
     const int32_t* pre_offsets = preprocess_workspace + nblk;
     k_halo_scan<<<G, 1024, 0, s>>>(blk_counts, nblk, offsets);
     k_halo_send_index_bounds<<<nblk + 1, HB, 0, s>>>(mask, offsets, nblk, visible_count, pre_offsets,
-                                                     rank_ints(owner_blocks, G + 1), G, rank, send_index, vb, Pb, plan);
+                                                     rank_ints(owner_blocks, G + 1), G, rank, send_index, vb, Pb, plan,
+                                                     plan_host);
     return check_launch("halo_plan_masked");
 }
 

@@ -433,7 +433,10 @@ int gs_band_project(const void* xyz, const void* scale, const void* opacity, con
                     int32_t* halo_workspace, void* stream);
 int gs_halo_plan_masked(const uint32_t* mask, int N, const int32_t* visible_count,
                         const int32_t* preprocess_workspace, const int32_t* owner_blocks, int G, int rank,
-                        int32_t* workspace, int32_t* send_index, int32_t* plan, void* stream);
+                        int32_t* workspace, int32_t* send_index, int32_t* plan,
+                        int32_t* plan_host /* NULL, or 4 + 2 G ints of device-accessible pinned host memory: a copy of
+                                              plan, written by the same kernel (the host read without a copy) */,
+                        void* stream);
 int gs_preprocess_forward_list(const void* xyz, const void* quaternion, const void* scale, const void* rgb, const void* sh,
                                int n_sh, const void* camera_T_world, const void* K, const void* camera_center,
                                const int32_t* list, const int32_t* list_count, int capacity, const int32_t* vis_idx,
