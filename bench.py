@@ -522,7 +522,8 @@ def main():
     # runs and corrected for gfx950: scripts/pmc_passes.sh, scripts/make_traffic_json.py) -- a committed
     # profile of this workload, NOT measured by this run: tagged with its source
     traffic, traffic_source = {}, None
-    for rel in (f"profiles/r03/hbm_traffic_{args.workload}.json", f"profiles/r02/hbm_traffic_{args.workload}.json",
+    for rel in (f"profiles/r04/hbm_traffic_{args.workload}.json", f"profiles/r03/hbm_traffic_{args.workload}.json",
+                f"profiles/r02/hbm_traffic_{args.workload}.json",
                 f"profiles/r01_hbm_traffic_{args.workload}.json"):
         tpath = os.path.join(ROOT, rel)
         if world == 1 and path == "fused" and os.path.exists(tpath):
@@ -610,6 +611,14 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "other_workloads": other,
             "frame_counters": run["counters"],
         }
+        if fused_mod is not None and not sharded:
+            cnt = run["counters"] or {}
+            line["config"]["depth_cut"] = {
+                "policy": str(fused_mod.DEPTH_CUT), "frames_with_cut": cnt.get("depth_cut_frames", 0),
+                "frames": cnt.get("frames", 0), "backoffs": cnt.get("depth_cut_backoffs", 0),
+                "note": "depth-bucketed binning (csrc/binning.hip): only each tile's <= 1024 nearest instances are "
+                        "emitted and sorted, tiles that need more are repaired on the device; S above is the COMPLETE "
+                        "instance count (what the SURVEY 8(d) byte formula prices); results identical"}
         if sharded:
             line["multi_gpu"] = {
                 "world_size_seen_by_rccl": dist.get_world_size(), "backend": dist.get_backend(),
@@ -679,7 +688,7 @@ def valu_roofline(entry, launch_ms, workload):
     """VALU issue view of the dominant kernel: wave-instructions from the committed PMC pass (source tagged)
     over the launch time measured by THIS run, against the plain-fp32 issue peak of the chip
     (256 CUs x 4 SIMDs x one wave-instruction per 2 cycles at 2.4 GHz; profiles/r02/ubench_valu_rate.txt)."""
-    rnd = next((r for r in ("r03", "r02") if os.path.exists(os.path.join(ROOT, "profiles", r, f"valu_insts_{workload}.json"))),
+    rnd = next((r for r in ("r04", "r03", "r02") if os.path.exists(os.path.join(ROOT, "profiles", r, f"valu_insts_{workload}.json"))),
                None)
     if rnd is None:
         return None

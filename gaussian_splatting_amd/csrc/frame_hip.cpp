@@ -57,7 +57,7 @@ struct PinnedRing {
 };
 std::map<int, PinnedRing> g_pinned;   // per device
 struct Counters {
-    int64_t frames = 0, speculative = 0, misses = 0, s_min = -1, s_max = -1, slab_copies = 0, cut_frames = 0;
+    int64_t frames = 0, speculative = 0, misses = 0, s_min = -1, s_max = -1, slab_copies = 0, cut_frames = 0, cut_backoffs = 0;
 } g_counters;
 std::vector<Tensor> g_flag_log;
 Tensor g_last_flags;   // tile_flags of the latest prefix-mode render (tests / tools)
@@ -69,7 +69,7 @@ bool g_band_compact = true;   // multi-GPU: band-compact per-Gaussian stage (Own
 // depth cut: 0 = auto (whole frames in the LDS-histogram regime whose lists averaged g_cut_min_mean_list entries or
 // more in an earlier frame of the same shape), 1 = always (where supported), -1 = never
 int g_depth_cut = 0;
-int64_t g_cut_min_mean_list = 2048;
+int64_t g_cut_min_mean_list = 1280;   // workload C (1477 per tile): 1.227 -> 1.193 ms with the cut (profiles/r04)
 // the histogram gs_preprocess_forward_cut fills and returns to zero: one per (device, stream), zeroed once
 int32_t* depth_hist_of(const torch::Device& dev, void* stream) {
     static std::map<std::pair<int, void*>, Tensor> hists;
@@ -80,13 +80,47 @@ int32_t* depth_hist_of(const torch::Device& dev, void* stream) {
         it = hists.emplace(key, torch::zeros({GS_CUT_HIST_BINS}, torch::TensorOptions().dtype(torch::kInt32).device(dev))).first;
     return it->second.data_ptr<int32_t>();
 }
+// "auto" also backs off when the cut does not pay: a frame in which more than an eighth of the tiles had to be
+// repaired from their complete lists (faint scenes, e.g. right after an opacity reset: every pixel composites deep)
+// emitted most lists twice.  The render's repair kernel leaves the flagged-tile count of every cut frame in a pinned
+// word; it is looked at -- never waited for -- when a later frame of the shape decides, and switches the cut off
+// for the next CUT_COOLDOWN frames of that shape (then it is tried again).
+constexpr int CUT_COOLDOWN = 32;
+struct CutFeedback {
+    Tensor flagged;   // pinned int32[1]
+    int cooldown = 0;
+};
+std::map<HintKey, CutFeedback> g_cut_feedback;
+int32_t* cut_feedback_word(const HintKey& shape) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    CutFeedback& fb = g_cut_feedback[shape];
+    if (!fb.flagged.defined())
+        fb.flagged = torch::zeros({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
+    return fb.flagged.data_ptr<int32_t>();
+}
 bool want_depth_cut(const HintKey& shape, int N, int ntx, int row0, int row1, bool whole, int sort_prefix) {
     if (g_depth_cut < 0 || !whole || !sort_prefix) return false;
     if (!gs_cut_supported(ntx, row0, row1, N)) return false;
     if (g_depth_cut > 0) return true;
     std::lock_guard<std::mutex> lock(g_mutex);
     auto it = g_complete_count.find(shape);
-    return it != g_complete_count.end() && it->second >= g_cut_min_mean_list * (int64_t)(row1 - row0) * ntx;
+    if (it == g_complete_count.end() || it->second < g_cut_min_mean_list * (int64_t)(row1 - row0) * ntx) return false;
+    auto fb = g_cut_feedback.find(shape);
+    if (fb != g_cut_feedback.end()) {
+        if (fb->second.flagged.defined()) {
+            volatile int32_t* w = fb->second.flagged.data_ptr<int32_t>();
+            if ((int64_t)*w * 8 > (int64_t)(row1 - row0) * ntx) {
+                fb->second.cooldown = CUT_COOLDOWN;
+                *w = 0;
+                g_counters.cut_backoffs++;
+            }
+        }
+        if (fb->second.cooldown > 0) {
+            fb->second.cooldown--;
+            return false;
+        }
+    }
+    return true;
 }
 bool want_segments(int64_t n_instances, int64_t n_tiles) {
     if (g_segments == 0) return n_tiles > 0 && n_tiles < 1500 && n_instances >= 192 * n_tiles;
@@ -204,6 +238,7 @@ struct CutRef {
     int N;
     float mh;
     int64_t overflow_capacity;
+    int32_t* host_flagged;
 };
 
 RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* ranges, Tensor& sorted, Tensor& keys,
@@ -239,7 +274,7 @@ RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* 
                                        (uint64_t*)okeys.data_ptr<int64_t>(), r.overflow_sorted.data_ptr<int32_t>(),
                                        cut->overflow_capacity, bg.data_ptr(), W, H, row0, row1,
                                        r.cut_flags.data_ptr<int32_t>(), r.nsp.data_ptr<int32_t>(), r.fw.data_ptr(),
-                                       r.image.data_ptr(), tile_cost, stream);
+                                       r.image.data_ptr(), tile_cost, cut->host_flagged, stream);
         });
         std::lock_guard<std::mutex> lock(g_mutex);
         if (g_flag_log.size() < 512) g_flag_log.push_back(r.cut_flags);
@@ -361,7 +396,7 @@ struct Preprocess : public torch::autograd::Function<Preprocess> {
         // outputs.  With capacities guessed from earlier frames of this shape, emit + sort + render are enqueued before
         // the host waits.
         const bool speculative = guess >= 0 && (!cut || guess_overflow >= 0);
-        CutRef cref{bin_rec, tile_counts, cut_ws, full_ranges, N, (float)mh_dist, 0};
+        CutRef cref{bin_rec, tile_counts, cut_ws, full_ranges, N, (float)mh_dist, 0, cut ? cut_feedback_word(shape) : nullptr};
         RenderOut out;
         bool rendered = false;
         int64_t capacity = 0;
@@ -1130,6 +1165,7 @@ py::dict counters() {
     d["S_max"] = c.s_max < 0 ? py::object(py::none()) : py::object(py::int_(c.s_max));
     d["slab_copies"] = c.slab_copies;   // backward calls that could not read the render node's slab in place
     d["depth_cut_frames"] = c.cut_frames;
+    d["depth_cut_backoffs"] = c.cut_backoffs;
     d["prefix_repaired_tiles"] = repaired;
     d["prefix_frames_logged"] = (int64_t)log.size();
     return d;

@@ -895,7 +895,10 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(GS_FWD_CK_WA
     const int* __restrict__ sorted, const float* __restrict__ bg, int W, int H, int ntx, int tile0,
     int nt, int* __restrict__ nsp_out, float* __restrict__ fw_out, float* __restrict__ image,
     int* __restrict__ tile_flags, int64_t cap, int* __restrict__ tile_cost, const SegState seg,
-    const int* __restrict__ flag_counter) {
+    const int* __restrict__ flag_counter, int* __restrict__ host_flagged) {
+    // (depth cut) how many tiles of the frame had to be repaired, into the caller's pinned host word: what the
+    // orchestration's policy looks at before later frames (never waited for)
+    if (host_flagged != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *host_flagged = *flag_counter;
     if (flag_counter != nullptr && *flag_counter == 0) return;   // (depth cut: no tile of the frame is flagged)
     for (int t = blockIdx.x; t < nt; t += gridDim.x) {
         if (tile_flags[tile0 + t] == 0) continue;
@@ -1834,7 +1837,7 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
         again<<<nt < 512 ? nt : 512, RB, 0, s>>>(
             (const float*)packed, (const float*)rgb, tile_ranges, sorted_gaussians,
             (const float*)background_rgb, W, H, ntx, t0, nt, num_splats_per_pixel,
-            (float*)final_weight_per_pixel, (float*)image, tile_flags, S, tile_cost, seg, nullptr);
+            (float*)final_weight_per_pixel, (float*)image, tile_flags, S, tile_cost, seg, nullptr, nullptr);
     }
     return check_launch("render_tiles_prefix");
 }
@@ -1845,7 +1848,7 @@ int gs_render_tiles_cut(const void* packed, const void* rgb, const int32_t* tile
                         int32_t* workspace, int32_t* cut_workspace, uint64_t* overflow_keys, int32_t* overflow_sorted,
                         int64_t overflow_capacity, const void* background_rgb, int W, int H, int tile_row0, int tile_row1,
                         int32_t* tile_flags, int32_t* num_splats_per_pixel, void* final_weight_per_pixel, void* image,
-                        int32_t* tile_cost, void* stream) {
+                        int32_t* tile_cost, int32_t* host_flagged, void* stream) {
     GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
     GS_REQUIRE(tile_flags != nullptr && full_ranges != nullptr, "tile_flags and full_ranges must not be null");
     if (int e = check_rows(H, tile_row0, tile_row1)) return e;
@@ -1869,7 +1872,7 @@ int gs_render_tiles_cut(const void* packed, const void* rgb, const int32_t* tile
     k_render_fwd_flagged<false><<<nt < 512 ? nt : 512, RB, 0, s>>>(
         (const float*)packed, (const float*)rgb, full_ranges, overflow_sorted, (const float*)background_rgb, W, H, ntx, t0,
         nt, num_splats_per_pixel, (float*)final_weight_per_pixel, (float*)image, tile_flags, overflow_capacity, tile_cost,
-        SEG_NONE, flag_counter);
+        SEG_NONE, flag_counter, host_flagged);
     return check_launch("render_tiles_cut");
 }
 

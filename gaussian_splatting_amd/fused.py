@@ -59,7 +59,7 @@ EARLY_RENDER = True
 # an earlier frame of the same shape (the partition of the Gaussians by depth costs ~0.03 ms: it must buy more than
 # that); True / False force it.  Callers that want the complete lists back (return_aux) never get it.
 DEPTH_CUT = {"0": False, "1": True}.get(os.environ.get("GSPLAT_DEPTH_CUT", "auto"), "auto")   # (env: A/B runs of bench.py)
-DEPTH_CUT_MIN_MEAN_LIST = 2048
+DEPTH_CUT_MIN_MEAN_LIST = 1280
 _mean_list_hint = {}   # frame shape -> complete instance count of the latest frame
 
 last_tile_flags = None   # int32[T] of the latest prefix-mode frame of the Python path (see last_flags())
@@ -147,6 +147,7 @@ def counters():
     if _native_mod is not None:
         nat = _native_mod.counters()
         if nat["frames"]:
+            out["depth_cut_backoffs"] = nat.get("depth_cut_backoffs", 0)
             for k in ("frames", "speculative_frames", "capacity_misses", "prefix_repaired_tiles", "prefix_frames_logged",
                       "depth_cut_frames"):
                 out[k] += nat[k]
@@ -473,7 +474,7 @@ def render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, 
         _hip.call("gs_render_tiles_cut", _p(packed), _p(rgb), _p(ranges), _p(sorted_g), ctypes.c_int64(sorted_g.shape[0]),
                   _p(cut.full_ranges), _p(cut.bin_rec), cut.N, _cf(cut.mh_dist), _p(cut.tile_counts), _p(cut.cut_ws),
                   _p(okeys), _p(osorted), ctypes.c_int64(cut.S_full), _p(background_rgb), width, height, row0, row1,
-                  _p(flags), _p(nsp), _p(fw), _p(image), _p(cost), stream)
+                  _p(flags), _p(nsp), _p(fw), _p(image), _p(cost), None, stream)
         cut.flags, cut.overflow_sorted = flags, osorted
         global last_tile_flags
         last_tile_flags = flags

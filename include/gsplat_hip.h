@@ -336,13 +336,15 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
  * emitted into overflow_keys / overflow_sorted (capacity overflow_capacity >= full_ranges[T], the frame's complete
  * instance count; only flagged tiles' segments are written) and they are rendered again -- plain enqueues, no host
  * read; the three repair launches exit at once while nothing is flagged.  bin_records, workspace, cut_workspace: as
- * given to gs_tile_count_cut.  Results are those of gs_render_tiles_packed on the complete sorted lists, bit for bit. */
+ * given to gs_tile_count_cut.  host_flagged (may be NULL): one int of device-accessible pinned host memory that receives
+ * the number of flagged tiles (a policy hint for later frames: a frame whose tiles mostly need their complete lists
+ * is cheaper without the cut).  Results are those of gs_render_tiles_packed on the complete sorted lists, bit for bit. */
 int gs_render_tiles_cut(const void* packed, const void* rgb, const int32_t* tile_ranges, const int32_t* sorted_gaussians,
                         int64_t S, const int32_t* full_ranges, const void* bin_records, int N, float mh_dist,
                         int32_t* workspace, int32_t* cut_workspace, uint64_t* overflow_keys, int32_t* overflow_sorted,
                         int64_t overflow_capacity, const void* background_rgb, int W, int H, int tile_row0, int tile_row1,
                         int32_t* tile_flags, int32_t* num_splats_per_pixel, void* final_weight_per_pixel, void* image,
-                        int32_t* tile_cost, void* stream);
+                        int32_t* tile_cost, int32_t* host_flagged, void* stream);
 /* Gradient mode of the render backward: the `backward_mode` argument of the three entry points above
  * (ABI 5: per call, so that a trainer switching modes cannot race a backward that the autograd engine's
  * own thread has queued).  GS_BACKWARD_DEFAULT takes the process-wide default, which gs_set_backward_mode

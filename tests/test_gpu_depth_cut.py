@@ -215,3 +215,24 @@ def test_cut_frame_with_too_small_capacity_guesses_is_repeated():
         same_frame(run_frame(g, cam, T, gi, True, True), ref)
     c = fused.counters()
     assert c["depth_cut_frames"] == 4 and c["capacity_misses"] >= 2, c
+
+
+def test_auto_policy_backs_off_when_most_tiles_need_their_complete_lists():
+    """"auto" (native orchestration): a faint scene flags every truncated tile, i.e. the cut emits most lists twice;
+    the flagged-tile count of a cut frame reaches the host through a pinned word and switches the cut off for the
+    next frames of that shape.  Results are the same either way."""
+    nat = fused.native()
+    if nat is None:
+        pytest.skip("native frame module not built")
+    W, H = 256, 176
+    g, cam, T = make_scene(280_000, W, H, 0, seed=11, device=DEV)
+    g.opacity.fill_(-5.0)
+    gi = make_grad_image(W, H, seed=2, device=DEV)
+    ref = run_frame(g, cam, T, gi, False, True)
+    fused.reset_counters()
+    for frame in range(5):
+        same_frame(run_frame(g, cam, T, gi, "auto", True), ref)
+        torch.cuda.synchronize()   # (the policy never waits for the word; the test makes its arrival deterministic)
+    c = fused.counters()
+    # frame 0 of the shape ran uncut as `ref`; frame 1 here takes the cut, is flagged all over, and the rest back off
+    assert c["depth_cut_frames"] == 1 and c["depth_cut_backoffs"] == 1, c
