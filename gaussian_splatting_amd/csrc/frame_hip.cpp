@@ -333,24 +333,27 @@ struct Preprocess : public torch::autograd::Function<Preprocess> {
         // With the depth cut, uv / conic / z live in the 32-byte binning records (columns 0-1, 2-4, 5) and the separate
         // arrays are not written: the tensors this node hands on are strided views of the records.
         const int64_t nn = N;
-        Arena iar(torch::kInt32, dev, {n_ws, 1, N, N, n_tc, T + 3, (N + 3) / 4, n_cut, cut ? T + 1 : 0});
-        Arena far(torch::kFloat32, dev, {3, cut ? 0 : 2 * nn, cut ? 0 : 3 * nn, cut ? 0 : 3 * nn, N, 3 * nn, 12 * nn,
+        Arena iar(torch::kInt32, dev, {n_ws, 1, N, 0, n_tc, T + 3, (N + 3) / 4, n_cut, cut ? T + 1 : 0});
+        Arena far(torch::kFloat32, dev, {3, cut ? 0 : 2 * nn, cut ? 0 : 3 * nn, cut ? 0 : 3 * nn, N, 0, 12 * nn,
                                          cut ? 8 * nn : 0});
         int32_t *ws = iar.ptr<int32_t>(0), *count = iar.ptr<int32_t>(1), *rank = iar.ptr<int32_t>(2),
-                *vis_idx = iar.ptr<int32_t>(3), *tile_counts = iar.ptr<int32_t>(4), *ranges_buf = iar.ptr<int32_t>(5);
+                *tile_counts = iar.ptr<int32_t>(4), *ranges_buf = iar.ptr<int32_t>(5);
         uint8_t* mask = (uint8_t*)iar.ptr<int32_t>(6);
         int32_t *cut_ws = iar.ptr<int32_t>(7), *full_ranges = iar.ptr<int32_t>(8);
         float *center = far.ptr<float>(0), *uv = far.ptr<float>(1), *xyz_cam = far.ptr<float>(2), *conic = far.ptr<float>(3),
-              *opa = far.ptr<float>(4), *rgbr = far.ptr<float>(5), *packed = far.ptr<float>(6), *bin_rec = far.ptr<float>(7);
+              *opa = far.ptr<float>(4), *packed = far.ptr<float>(6), *bin_rec = far.ptr<float>(7);
+        // (the one-coefficient render kernels read the colour from the packed record: no separate colour array)
+        const float* rgbr = packed;
         int32_t* depth_hist = cut ? depth_hist_of(dev, stream) : nullptr;
         timed("gs_preprocess_forward", stream, [&] {
             return gs_preprocess_forward_cut(xyz.data_ptr(), quaternion.data_ptr(), scale.data_ptr(), opacity.data_ptr(),
                                              rgb.data_ptr(), has_sh ? sh.data_ptr() : nullptr, n_sh, camera_T_world.data_ptr(),
                                              K.data_ptr(), N, (int)W, (int)H, (float)near_thresh, (float)far_thresh,
                                              (float)padding, (float)mh_dist, (int)row0, (int)row1, ws, center, count, mask, rank,
-                                             vis_idx, cut ? nullptr : uv, cut ? nullptr : xyz_cam, cut ? nullptr : conic, opa,
-                                             rgbr, packed, cut ? bin_rec : nullptr, cut ? cut_ws : nullptr, depth_hist, stride,
-                                             stream);
+                                             nullptr /* vis_idx: nobody reads it on this path */, cut ? nullptr : uv,
+                                             cut ? nullptr : xyz_cam, cut ? nullptr : conic, opa,
+                                             nullptr /* rgb_render: the colour is in the packed record */, packed,
+                                             cut ? bin_rec : nullptr, cut ? cut_ws : nullptr, depth_hist, stride, stream);
         });
         HintKey key = shape;
         key.mode = cut ? 1 : 0;
@@ -449,8 +452,10 @@ struct Preprocess : public torch::autograd::Function<Preprocess> {
             conic_t = far.block(3, 3 * nn).view({N, 3}).narrow(0, 0, V);
         }
         Tensor opa_t = far.block(4, N).view({N, 1}).narrow(0, 0, V);
-        Tensor rgbr_t = far.block(5, 3 * (int64_t)N).view({N, 3}).narrow(0, 0, V);
         Tensor packed_t = far.block(6, 12 * (int64_t)N).view({N, 12});
+        // the colour output of this node only carries the autograd edge of the render gradients' colour columns (the
+        // kernels read the colour from the packed record, nobody reads this tensor's values): a stride-0 placeholder
+        Tensor rgbr_t = zero_scalar(dev).expand({V, 3});
         Tensor ranges_t = iar.block(5, T + 1);
         Tensor mask_t = iar.block(6, (N + 3) / 4).view(torch::kBool).narrow(0, 0, N);
         // depth-cut frames: what the backward needs to read a repaired tile's complete list (empty otherwise)

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(PP_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))
     float c3[3] = {0, 0, 0}, opa = 0;
     bool in_band = true;
     if (act) {
-        o.vis_idx[v] = g;
+        if (o.vis_idx != nullptr) o.vis_idx[v] = g;
         if (o.uv != nullptr) {
             o.uv[v * 2 + 0] = uv[0];
             o.uv[v * 2 + 1] = uv[1];
@@ -388,9 +388,11 @@ __global__ __launch_bounds__(PP_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))
         }
     }
     if (!act) return;
-    o.rgb[v * 3 + 0] = col[0];
-    o.rgb[v * 3 + 1] = col[1];
-    o.rgb[v * 3 + 2] = col[2];
+    if (o.rgb != nullptr) {   // (the renderer reads the colour from the packed record; the array serves callers)
+        o.rgb[v * 3 + 0] = col[0];
+        o.rgb[v * 3 + 1] = col[1];
+        o.rgb[v * 3 + 2] = col[2];
+    }
 
     // packed render record, identical to k_pack
     float pk[GS_PACKED_WIDTH];

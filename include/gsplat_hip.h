@@ -198,7 +198,8 @@ int gs_cut_debug_views(int32_t* cut_workspace, int N, int n_tiles, int32_t** bst
  *   outputs  camera_center[3]; visible_count[1] (= V, on the device); culling_mask uint8[N]
  *            (1 = culled); rank int32[N] (visible index or -1); and, with capacity N rows of which
  *            the first V are written: vis_idx int32, uv[.,2], xyz_camera_frame[.,3], conic[.,3],
- *            opacity_act[.,1] = sigmoid, rgb_render[.,3], packed[.,12] (see gs_pack_splats). */
+ *            opacity_act[.,1] = sigmoid, rgb_render[.,3], packed[.,12] (see gs_pack_splats).  vis_idx and
+ *            rgb_render may be NULL (not written: the renderer reads the colour from the packed record). */
 size_t gs_preprocess_workspace_ints(int N);
 int gs_preprocess_forward(const void* xyz, const void* quaternion, const void* scale,
                           const void* opacity, const void* rgb, const void* sh, int n_sh,

@@ -16,7 +16,7 @@ for name in ("pass3.txt", "pass4.txt"):
         if m:
             k = re.sub(r"\(.*", "", m.group(1).strip()).replace("void ", "")
             vals.setdefault(k, {})[m.group(2)] = float(m.group(3))
-ENTRY = {
+ENTRY_UNCUT = {
     "gs_render_tiles_backward_slab": ["gs::k_render_bwd<float, 1>", "gs::k_tile_order"],
     "gs_render_tiles_prefix": ["gs::k_render_fwd<float, 1>", "gs::k_render_fwd_flagged", "gs::k_render_fwd_flagged<false>",
                                "gs::k_tile_sort_flagged<8192>", "gs::k_tile_sort_flagged<4096>"],
@@ -25,8 +25,25 @@ ENTRY = {
     "gs_tile_count": ["gs::k_bin_count", "gs::k_bin_colscan", "gs::k_bin_colscan<64>", "gs::k_scan_tiles"],
     "gs_tile_emit_sort": ["gs::k_bin_emit", "gs::k_tile_sort<true>", "gs::k_tile_sort_big<true>"],
 }
+# frames binned with the depth cut (csrc/binning.hip "depth cut"; round 4): the same entry points, other kernels
+ENTRY_CUT = {
+    "gs_render_tiles_backward_slab": ["gs::k_render_bwd<float, 1>", "gs::k_tile_order"],
+    "gs_render_tiles_prefix": ["gs::k_render_fwd<float, 1>", "gs::k_bin_emit_buckets<2, 512>", "gs::k_tile_sort_overflow",
+                               "gs::k_render_fwd_flagged<false>"],
+    "gs_preprocess_forward": ["gs::k_preprocess<16, false>", "gs::k_cull_count", "gs::k_scan_counts<true>"],
+    "gs_preprocess_backward": ["gs::k_preprocess_bwd<16>"],
+    "gs_tile_count": ["gs::k_depth_hist", "gs::k_depth_colscan", "gs::k_depth_scatter", "gs::k_bin_count_buckets",
+                      "gs::k_bin_colscan_cut<64>", "gs::k_scan_tiles_cut"],
+    "gs_tile_emit_sort": ["gs::k_bin_emit_buckets<1, 1024>", "gs::k_tile_sort_runs"],
+}
+ENTRY = ENTRY_CUT if "gs::k_bin_count_buckets" in vals else ENTRY_UNCUT
 res = {"workload": workload, "source": pmc_dir, "note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
        "entries": {}}
+if ENTRY is ENTRY_CUT:   # (round 4 on: also every kernel on its own)
+    res["binning"] = "depth cut"
+    res["kernels"] = {k: {"fetch_kib": v.get("FETCH_SIZE", 0.0), "write_kib": v.get("WRITE_SIZE", 0.0),
+                          "hbm_bytes": int((2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024)}
+                      for k, v in sorted(vals.items()) if k.startswith("gs::")}
 for entry, kernels in ENTRY.items():
     f = sum(vals.get(k, {}).get("FETCH_SIZE", 0.0) for k in kernels)
     w = sum(vals.get(k, {}).get("WRITE_SIZE", 0.0) for k in kernels)

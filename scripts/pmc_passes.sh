@@ -7,6 +7,8 @@ OUT=$R/${2:-gpurun_out/pmc_$WL}
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
+# (GSPLAT_DEPTH_CUT: 1 = the depth-cut kernels from the first frame on, so that a kernel name has one meaning in the run)
+export GSPLAT_DEPTH_CUT=${GSPLAT_DEPTH_CUT:-1}
 CMD="python $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --also="
 i=0
 for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \

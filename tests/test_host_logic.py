@@ -226,30 +226,36 @@ def test_bench_helpers():
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
-def test_committed_traffic_and_valu_json_follow_from_the_committed_pmc_passes(tmp_path):
-    """profiles/r02/hbm_traffic_D.json and valu_insts_D.json (what bench.py reports as roofline.traffic /
-    roofline.valu) are exactly what scripts/make_traffic_json.py derives from the committed rocprofv3 passes"""
+@pytest.mark.parametrize("rnd", ["r02", "r04"])
+def test_committed_traffic_and_valu_json_follow_from_the_committed_pmc_passes(tmp_path, rnd):
+    """profiles/<round>/hbm_traffic_D.json and valu_insts_D.json (what bench.py reports as roofline.traffic /
+    roofline.valu) are exactly what scripts/make_traffic_json.py derives from the committed rocprofv3 passes
+    (r04: the frame binned with the depth cut -- other kernels behind the same entry points)"""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out, valu = tmp_path / "t.json", tmp_path / "v.json"
-    subprocess.run([sys.executable, os.path.join(root, "scripts", "make_traffic_json.py"), "profiles/r02/pmc_bench_D",
+    subprocess.run([sys.executable, os.path.join(root, "scripts", "make_traffic_json.py"), f"profiles/{rnd}/pmc_bench_D",
                     str(out), "D", str(valu)], check=True, cwd=root, capture_output=True)
-    assert json.load(open(out)) == json.load(open(os.path.join(root, "profiles", "r02", "hbm_traffic_D.json")))
-    assert json.load(open(valu)) == json.load(open(os.path.join(root, "profiles", "r02", "valu_insts_D.json")))
+    assert json.load(open(out)) == json.load(open(os.path.join(root, "profiles", rnd, "hbm_traffic_D.json")))
+    assert json.load(open(valu)) == json.load(open(os.path.join(root, "profiles", rnd, "valu_insts_D.json")))
+    if rnd == "r04":
+        assert json.load(open(out))["binning"] == "depth cut"
 
 
-@pytest.mark.parametrize("name", ["bench_D.json", "bench_B.json", "bench_C.json", "bench_D_moving_camera.json"])
+@pytest.mark.parametrize("name", ["r02/bench_D.json", "r02/bench_B.json", "r02/bench_C.json",
+                                  "r02/bench_D_moving_camera.json", "r04/bench_D.json"])
 def test_committed_bench_lines_keep_the_contract(name):
-    """the JSON lines under profiles/r02 are what `python bench.py` printed: the contract's fields, BASELINE.json's
+    """the JSON lines under profiles/ are what `python bench.py` printed: the contract's fields, BASELINE.json's
     metric verbatim, a roofline object whose fraction is achieved / peak and whose achieved rate is the algorithmic
     bytes over the measured launch duration, and (workload D, default flags) the CPU baseline"""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, "profiles", "r02", name)))
+    d = json.load(open(os.path.join(root, "profiles", name)))
+    name = os.path.basename(name)
     base = json.load(open(os.path.join(root, "BASELINE.json")))
     assert d["metric"] == base["metric"] and d["unit"] == "Mpixels/s" and d["higher_is_better"] is True
     assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
