@@ -266,8 +266,10 @@ RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* 
         // flagged tiles from the overflow buffers
         r.seg = torch::empty({0}, opt);
         r.cut_flags = torch::empty({T}, opt.dtype(torch::kInt32));
-        r.overflow_sorted = torch::empty({cut->overflow_capacity}, opt.dtype(torch::kInt32));
-        Tensor okeys = torch::empty({cut->overflow_capacity}, opt.dtype(torch::kInt64));
+        // (never empty: a frame without a visible Gaussian still hands the backward a non-null overflow list)
+        const int64_t ocap = std::max<int64_t>(cut->overflow_capacity, 1);
+        r.overflow_sorted = torch::empty({ocap}, opt.dtype(torch::kInt32));
+        Tensor okeys = torch::empty({ocap}, opt.dtype(torch::kInt64));
         timed("gs_render_tiles_prefix", stream, [&] {
             return gs_render_tiles_cut(packed, rgbr, ranges, sorted.data_ptr<int32_t>(), sorted.size(0), cut->full_ranges,
                                        cut->bin_rec, cut->N, cut->mh, cut->tile_counts, cut->cut_ws,

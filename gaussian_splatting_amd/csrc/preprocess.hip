@@ -103,7 +103,7 @@ __global__ __launch_bounds__(PP_BLOCK) void k_cull_count(const float* __restrict
     if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
-// exclusive prefix of counts[n] in place of offsets[n]; total -> total_out[0].  One workgroup.
+// exclusive prefix of counts[n] in place of offsets[n]; total -> total_out[0].  One workgroup (CUT: a second one).
 // depth_hist != nullptr (depth-bucketed binning): also turns k_cull_count's depth histogram into GS_CUT_BUCKETS - 1
 // bucket boundaries of about equal population -- boundary k is where the cumulative sample count reaches
 // (k + 1) / GS_CUT_BUCKETS, interpolated linearly inside its bin -- and returns the histogram to zero for the next
@@ -117,7 +117,9 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ co
     __shared__ int s_carry;
     __shared__ int s_cum[CUT ? GS_CUT_HIST_BINS : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if constexpr (CUT) {
+    // CUT: two workgroups -- 0 scans the counts, 1 makes the boundaries (independent; one after the other in a single
+    // workgroup was 12 us, each alone is 5-7)
+    if constexpr (CUT) if (blockIdx.x == 1) {
         constexpr int PER = GS_CUT_HIST_BINS / 1024;
         static_assert(GS_CUT_HIST_BINS % 1024 == 0 && GS_CUT_BUCKETS == 1024, "one thread per bucket, PER bins per thread");
         int v[PER], sum = 0;
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ co
             bound = (uint32_t)min(b, (uint64_t)hi);
         }
         if (tid < GS_CUT_BUCKETS) bounds[tid] = bound;
-        __syncthreads();   // s_wave is reused below
+        return;
     }
     if (tid == 0) s_carry = 0;
     __syncthreads();
@@ -753,7 +755,7 @@ int gs_preprocess_forward_cut(const void* xyz, const void* quaternion, const voi
     CutState cs{};
     if (cut_workspace != nullptr) {
         cs = cut_state_of(cut_workspace, N, n_tiles);
-        k_scan_counts<true><<<1, 1024, 0, s>>>(block_counts, nb, block_offsets, visible_count, depth_hist, cs.bounds, fr);
+        k_scan_counts<true><<<2, 1024, 0, s>>>(block_counts, nb, block_offsets, visible_count, depth_hist, cs.bounds, fr);
     } else {
         k_scan_counts<false><<<1, 1024, 0, s>>>(block_counts, nb, block_offsets, visible_count, nullptr, nullptr, fr);
     }

@@ -469,8 +469,9 @@ def render_forward(packed, rgb, ranges, sorted_g, keys, background_rgb, height, 
         assert not segments, "depth segments and the depth cut are not combined"
         scratch = torch.empty(2 * ntx * nty, dtype=torch.int32, device=dev)
         flags, cost = scratch[:ntx * nty], scratch[ntx * nty:]
-        okeys = torch.empty(cut.S_full, dtype=torch.int64, device=dev)
-        osorted = torch.empty(cut.S_full, dtype=torch.int32, device=dev)
+        # (never empty: a frame without a visible Gaussian still hands the backward a non-null overflow list)
+        okeys = torch.empty(max(cut.S_full, 1), dtype=torch.int64, device=dev)
+        osorted = torch.empty(max(cut.S_full, 1), dtype=torch.int32, device=dev)
         _hip.call("gs_render_tiles_cut", _p(packed), _p(rgb), _p(ranges), _p(sorted_g), ctypes.c_int64(sorted_g.shape[0]),
                   _p(cut.full_ranges), _p(cut.bin_rec), cut.N, _cf(cut.mh_dist), _p(cut.tile_counts), _p(cut.cut_ws),
                   _p(okeys), _p(osorted), ctypes.c_int64(cut.S_full), _p(background_rgb), width, height, row0, row1,

@@ -236,3 +236,58 @@ def test_auto_policy_backs_off_when_most_tiles_need_their_complete_lists():
     c = fused.counters()
     # frame 0 of the shape ran uncut as `ref`; frame 1 here takes the cut, is flagged all over, and the rest back off
     assert c["depth_cut_frames"] == 1 and c["depth_cut_backoffs"] == 1, c
+
+
+def degenerate_scene(case):
+    """scenes whose depth distribution defeats the bucket boundaries (sample quantiles): correctness may not depend on
+    the boundaries being any good -- only the balance of the workgroups and how many tiles get repaired do"""
+    W, H, N = 256, 192, 300_000
+    if case == "few":
+        W, H, N = 64, 48, 3_000          # most of the 1024 buckets empty, the 256 partition workgroups nearly so
+    if case == "long_partition_chunks":
+        W, H, N = 160, 128, 3_400_000    # > 12 288 visible Gaussians per partition workgroup: the unstaged scatter
+    g, cam, T = make_scene(N, W, H, 0, seed=11, device=DEV)
+    z = g.xyz[:, 2]
+    if case == "one_depth":
+        z.fill_(6.0)                     # one bucket holds everything: no tile can be cut, all are repaired
+    elif case == "two_depths":
+        z.copy_(torch.where(torch.arange(N, device=DEV) % 2 == 0, 4.0, 9.0))
+    elif case == "quantized":
+        z.copy_(torch.round(z * 8) / 8)  # ~230 distinct depths: ties inside and across bucket boundaries
+    elif case == "sampled_outliers":
+        # every Gaussian the depth histogram samples sits at one depth, all the others behind it: the boundaries
+        # collapse onto the samples' depth, bucket 0 = the samples, the last bucket = everything else
+        stride = _hip.lib().gs_cut_sample_stride(N)
+        z.copy_(torch.where(torch.arange(N, device=DEV) % stride == 0, 2.0, 5.0 + 20.0 * torch.rand(N, device=DEV)))
+    elif case == "long_runs":
+        # 1/16 of the Gaussians (none of them sampled ones) crowd into a depth interval the boundaries do not
+        # resolve: a kept list holds unordered runs far longer than the run-aware sort settles in its pass budget
+        stride = _hip.lib().gs_cut_sample_stride(N)
+        idx = torch.arange(N, device=DEV)
+        crowd = (idx % 16 == 1) & (idx % stride != 0)
+        z.copy_(torch.where(crowd, 1.6 + 0.01 * torch.rand(N, device=DEV), 8.0 + 20.0 * torch.rand(N, device=DEV)))
+    elif case == "none_visible":
+        z.fill_(-1.0)
+    return g, cam, T, W, H
+
+
+@pytest.mark.parametrize("native", [False, True], ids=["python", "native"])
+@pytest.mark.parametrize("case", ["one_depth", "two_depths", "quantized", "sampled_outliers", "long_runs", "few",
+                                  "none_visible", "long_partition_chunks"])
+def test_cut_frame_with_degenerate_depth_distributions(case, native):
+    g, cam, T, W, H = degenerate_scene(case)
+    gi = make_grad_image(W, H, seed=4, device=DEV)
+    ref = run_frame(g, cam, T, gi, False, native)
+    fused.last_flags(clear=True)
+    fused.reset_counters()
+    got = run_frame(g, cam, T, gi, True, native)
+    flags = fused.last_flags()
+    errs = same_frame(got, ref)
+    got2 = run_frame(g, cam, T, gi, True, native)   # (native: guessed capacities)
+    same_frame(got2, ref)
+    c = fused.counters()
+    if native and case != "none_visible":
+        assert c.get("depth_cut_frames", 0) >= 1, c
+    report(f"depth_cut_degenerate[{case}, {'native' if native else 'python'}]",
+           flagged_tiles=-1 if flags is None else int(flags.sum()), tiles=((W + 15) // 16) * ((H + 15) // 16),
+           max_grad_scaled_err=max(errs.values()))
