@@ -186,6 +186,48 @@ def test_fused_slab_detection_and_arena():
     assert float(blocks[0].sum()) == 3 and float(blocks[1].sum()) == 20 and float(blocks[3].sum()) == 15
 
 
+def test_depth_cut_policy_and_size_helpers(monkeypatch):
+    """fused.want_depth_cut ("auto": whole frames in the LDS-histogram regime whose lists averaged >= 1 280 entries per
+    tile in an earlier frame of the shape) and the C ABI's size helpers of the depth-bucketed binning (no GPU needed:
+    they only compute)."""
+    import ctypes
+    from gaussian_splatting_amd import _hip, fused
+    lib = _hip.lib()
+    lib.gs_cut_workspace_ints.restype = ctypes.c_size_t
+    # every 44th Gaussian of workload D is sampled (<= 65 536 samples), small scenes sample everything
+    assert lib.gs_cut_sample_stride(2_860_000) == 44 and lib.gs_cut_sample_stride(65_536) == 1
+    assert lib.gs_cut_sample_stride(65_537) == 2 and lib.gs_cut_sample_stride(1) == 1
+    # LDS-histogram regime: at most 16 384 tiles in the row range and more than 128 Gaussians per tile
+    ntx, nty = 82, 53
+    assert lib.gs_cut_supported(ntx, 0, nty, 2_860_000) == 1
+    assert lib.gs_cut_supported(ntx, 0, nty, 128 * ntx * nty) == 0 and lib.gs_cut_supported(ntx, 0, nty, 128 * ntx * nty + 1) == 1
+    assert lib.gs_cut_supported(240, 0, 135, 50_000_000) == 0        # 32 400 tiles (4K): not in one range ...
+    assert lib.gs_cut_supported(240, 0, 64, 50_000_000) == 1         # ... a band of it is
+    assert lib.gs_cut_supported(ntx, 5, 5, 2_860_000) == 0           # empty range
+    # workspace: grows with N and T, holds at least the index list, the bucket ids and the 256 x 1024 count matrix
+    w = lib.gs_cut_workspace_ints(2_860_000, ntx * nty)
+    assert w >= 2_860_000 + 2_860_000 // 2 + 256 * 1024 + 2 * ntx * nty
+    assert lib.gs_cut_workspace_ints(2_860_001, ntx * nty) >= w and lib.gs_cut_workspace_ints(2_860_000, ntx * nty + 1) >= w
+    assert w < 2 * (2_860_000 + 2_860_000 // 2 + 256 * 1024 + 2 * ntx * nty)
+
+    key = ("shape",)
+    T = ntx * nty
+    monkeypatch.setattr(fused, "DEPTH_CUT", "auto")
+    monkeypatch.setattr(fused, "_mean_list_hint", {})
+    assert not fused.want_depth_cut(key, 2_860_000, ntx, 0, nty, True)            # nothing known about the shape yet
+    fused._mean_list_hint[key] = fused.DEPTH_CUT_MIN_MEAN_LIST * T - 1
+    assert not fused.want_depth_cut(key, 2_860_000, ntx, 0, nty, True)
+    fused._mean_list_hint[key] = fused.DEPTH_CUT_MIN_MEAN_LIST * T
+    assert fused.want_depth_cut(key, 2_860_000, ntx, 0, nty, True)
+    assert not fused.want_depth_cut(key, 2_860_000, ntx, 0, nty, False)           # bands keep the complete lists
+    assert not fused.want_depth_cut(key, 100_000, ntx, 0, nty, True)              # outside the regime
+    monkeypatch.setattr(fused, "DEPTH_CUT", True)
+    assert fused.want_depth_cut(("other",), 2_860_000, ntx, 0, nty, True)         # forced: no history needed ...
+    assert not fused.want_depth_cut(("other",), 100_000, ntx, 0, nty, True)       # ... but still only where supported
+    monkeypatch.setattr(fused, "DEPTH_CUT", False)
+    assert not fused.want_depth_cut(key, 2_860_000, ntx, 0, nty, True)
+
+
 def test_bench_helpers():
     """bench.py's host-side pieces: the frame's algorithmic bytes are SURVEY.md 8(d)'s formula, camera poses
     are seeded rigid transforms, the median, and the self-spawn command line"""
