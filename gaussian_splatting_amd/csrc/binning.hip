@@ -358,9 +358,9 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_count(const float* __restric
 }
 
 // hist[b][t] <- sum_{b' < b} hist[b'][t];  counts[t] <- column total.
-// 1024-thread workgroup = 64 tiles x 16 row segments of 32 rows: every thread sums its segment
+// 1024-thread workgroup = 64 tiles x 16 row segments of 64 rows: every thread loads and sums its segment
 // (coalesced: a wave reads 64 consecutive tiles of one row), the 16 segment sums of a tile are
-// prefixed through LDS, then the thread re-walks its segment writing the exclusive offsets.
+// prefixed through LDS, then the thread writes the exclusive offsets of its segment.
 #ifndef GS_CS_TILES
 #define GS_CS_TILES 64   // 68 workgroups at workload D; 32 or 16 tiles per workgroup (more, narrower ones) are no faster
 #endif
@@ -375,10 +375,14 @@ __global__ __launch_bounds__(1024) void k_bin_colscan(int* __restrict__ hist, in
     const int seg = threadIdx.x / CS_TILES;
     const int t = blockIdx.x * CS_TILES + lt;
     int* col = hist + (size_t)seg * CS_ROWS * T + t;
-    int sum = 0;
+    // the segment's values stay in registers between the two walks (CS_ROWS <= 64 of them): the matrix is read once
+    int v[CS_ROWS], sum = 0;
     if (t < T) {
-#pragma unroll 8
-        for (int r = 0; r < CS_ROWS; r++) sum += col[(size_t)r * T];
+#pragma unroll
+        for (int r = 0; r < CS_ROWS; r++) {
+            v[r] = col[(size_t)r * T];
+            sum += v[r];
+        }
     }
     s_seg[seg][lt] = sum;
     __syncthreads();
@@ -386,11 +390,10 @@ __global__ __launch_bounds__(1024) void k_bin_colscan(int* __restrict__ hist, in
     for (int s2 = 0; s2 < seg; s2++) run += s_seg[s2][lt];
     if (t < T) {
         if (seg == CS_SEGS - 1) counts[t] = run + sum;
-#pragma unroll 8
+#pragma unroll
         for (int r = 0; r < CS_ROWS; r++) {
-            const int h = col[(size_t)r * T];
             col[(size_t)r * T] = run;
-            run += h;
+            run += v[r];
         }
     }
 }
@@ -712,10 +715,13 @@ __global__ __launch_bounds__(1024) void k_bin_colscan_cut(int* __restrict__ hist
     const int seg = threadIdx.x / CS_TILES;
     const int t = blockIdx.x * CS_TILES + lt;
     int* col = hist + (size_t)seg * CS_ROWS * T + t;
-    int sum = 0;
+    int v[CS_ROWS], sum = 0;   // (registers between the two walks, as in k_bin_colscan)
     if (t < T) {
-#pragma unroll 8
-        for (int r = 0; r < CS_ROWS; r++) sum += col[(size_t)r * T];
+#pragma unroll
+        for (int r = 0; r < CS_ROWS; r++) {
+            v[r] = col[(size_t)r * T];
+            sum += v[r];
+        }
     }
     s_seg[seg][lt] = sum;
     __syncthreads();
@@ -723,9 +729,9 @@ __global__ __launch_bounds__(1024) void k_bin_colscan_cut(int* __restrict__ hist
     for (int s2 = 0; s2 < seg; s2++) run += s_seg[s2][lt];
     int best = -1, bn = 0;
     if (t < T) {
-#pragma unroll 8
+#pragma unroll
         for (int r = 0; r < CS_ROWS; r++) {
-            const int h = col[(size_t)r * T];
+            const int h = v[r];
             col[(size_t)r * T] = run;
             run += h;
             if (h > 0 && run <= kcut) {

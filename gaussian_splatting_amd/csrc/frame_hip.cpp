@@ -559,7 +559,8 @@ struct Render : public torch::autograd::Function<Render> {
         const int64_t V = ctx->saved_data["V"].toInt();
         const int H = (int)nsp.size(0), W = (int)nsp.size(1);
         Tensor grad_image = g[0].contiguous();
-        Tensor slab = torch::zeros({std::max<int64_t>(V, 1), SLAB_WIDTH}, packed.options());
+        // (cleared by the backward call itself, in the launch that also orders the tiles: zero_slab_rows)
+        Tensor slab = torch::empty({std::max<int64_t>(V, 1), SLAB_WIDTH}, packed.options());
         void* stream = cur_stream();
         const int row0 = (int)ctx->saved_data["row0"].toInt(), row1 = (int)ctx->saved_data["row1"].toInt();
         // the forward's per-tile costs and the order workspace sit behind the splat counts (render_forward)
@@ -569,11 +570,16 @@ struct Render : public torch::autograd::Function<Render> {
         // few hundred entries per tile (workload B, 52 per tile: the order kernel's 6 us are not won back)
         const bool segmented = seg.numel() > 0;
         const bool ordered = !segmented && sorted_g.size(0) >= 256 * T;
+        // one prologue launch (clear the slab + order the tiles), then the render kernel alone in its entry
+        timed("gs_render_backward_prologue", stream, [&] {
+            return gs_render_backward_prologue(slab.data_ptr(), slab.size(0), ordered ? tile_cost : nullptr,
+                                               ordered ? tile_cost + T : nullptr, W, H, row0, row1, stream);
+        });
         timed("gs_render_tiles_backward_slab", stream, [&] {
             return gs_render_tiles_backward_slab(packed.data_ptr(), rgbr.data_ptr(), ranges.data_ptr<int32_t>(),
                                                  sorted_g.data_ptr<int32_t>(), bg.data_ptr(), nsp.data_ptr<int32_t>(),
                                                  fw.data_ptr(), grad_image.data_ptr(), W, H, row0, row1, slab.data_ptr(),
-                                                 ordered ? tile_cost : nullptr, ordered ? tile_cost + T : nullptr,
+                                                 0, nullptr, ordered ? tile_cost + T : nullptr,
                                                  segmented ? seg.data_ptr() : nullptr,
                                                  cut ? cut_flags.data_ptr<int32_t>() : nullptr,
                                                  cut ? full_ranges.data_ptr<int32_t>() : nullptr,
@@ -993,15 +999,19 @@ struct OwnerRender : public torch::autograd::Function<OwnerRender> {
         const int W = fr.W, H = fr.H;
         const int64_t V = fr.V;
         Tensor grad_image = g[0].contiguous();
-        Tensor slab = torch::zeros({std::max<int64_t>(fr.L, 1), SLAB_WIDTH}, fr.packed.options());
+        Tensor slab = torch::empty({std::max<int64_t>(fr.L, 1), SLAB_WIDTH}, fr.packed.options());   // (zero_slab_rows)
         void* stream = cur_stream();
         const bool segmented = fr.out.seg.numel() > 0;
+        timed("gs_render_backward_prologue", stream, [&] {
+            return gs_render_backward_prologue(slab.data_ptr(), slab.size(0), nullptr, nullptr, W, H, fr.row0, fr.row1, stream);
+        });
         timed("gs_render_tiles_backward_slab", stream, [&] {
             return gs_render_tiles_backward_slab(fr.packed.data_ptr(), fr.rgbr.data_ptr(), fr.ranges.data_ptr<int32_t>(),
                                                  fr.sorted_g.data_ptr<int32_t>(), fr.bg.data_ptr(), fr.out.nsp.data_ptr<int32_t>(),
                                                  fr.out.fw.data_ptr(), grad_image.data_ptr(), W, H, fr.row0, fr.row1,
-                                                 slab.data_ptr(), nullptr, nullptr, segmented ? fr.out.seg.data_ptr() : nullptr,
-                                                 nullptr, nullptr, nullptr, fr.bwd_mode, stream);
+                                                 slab.data_ptr(), 0, nullptr, nullptr,
+                                                 segmented ? fr.out.seg.data_ptr() : nullptr, nullptr, nullptr, nullptr,
+                                                 fr.bwd_mode, stream);
         });
         // rows of the send list -> owners; rows of the owned range <- the ranks whose band they reach
         int64_t n_send = 0, n_recv = 0;

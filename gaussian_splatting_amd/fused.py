@@ -508,7 +508,8 @@ def render_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, grad
     backward_mode: _hip.GS_BACKWARD_COMPAT / _EXACT, per call (ABI 5); None = the process default at the call"""
     nty = (height + TILE_EDGE_LENGTH_PX - 1) // TILE_EDGE_LENGTH_PX
     row0, row1 = tile_rows if tile_rows is not None else (0, nty)
-    slab = torch.zeros(max(V, 1), SLAB_WIDTH, dtype=torch.float32, device=packed.device)
+    # (cleared by the call itself, in the launch that also orders the tiles: zero_slab_rows)
+    slab = torch.empty(max(V, 1), SLAB_WIDTH, dtype=torch.float32, device=packed.device)
     cost = order = None
     seg_on = seg_state is not None and seg_state.numel() > 0
     # longest-first only pays where a workgroup lives long enough for the kernel's tail to matter: lists of a
@@ -517,9 +518,12 @@ def render_backward(packed, rgb, ranges, sorted_g, background_rgb, nsp, fw, grad
             and sorted_g.shape[0] >= LPT_MIN_MEAN_LIST * tile_cost.numel()):
         cost = tile_cost
         order = torch.empty(tile_cost.numel() + 8, dtype=torch.int32, device=packed.device)
+    # one prologue launch (clear the slab + order the tiles), then the render kernel alone in its entry
+    _hip.call("gs_render_backward_prologue", _p(slab), ctypes.c_int64(slab.shape[0]), _p(cost) if cost is not None else None,
+              _p(order) if order is not None else None, width, height, row0, row1, _stream())
     _hip.call("gs_render_tiles_backward_slab", _p(packed), _p(rgb), _p(ranges), _p(sorted_g), _p(background_rgb),
-              _p(nsp), _p(fw), _p(grad_image), width, height, row0, row1, _p(slab),
-              _p(cost) if cost is not None else None, _p(order) if order is not None else None,
+              _p(nsp), _p(fw), _p(grad_image), width, height, row0, row1, _p(slab), ctypes.c_int64(0),
+              None, _p(order) if order is not None else None,
               _p(seg_state) if seg_on else None,
               _p(cut.flags) if cut is not None else None, _p(cut.full_ranges) if cut is not None else None,
               _p(cut.overflow_sorted) if cut is not None else None,

@@ -314,20 +314,30 @@ int gs_render_tiles_backward_packed(const void* packed, const void* rgb, const v
                                     void* grad_opacity, void* grad_uv, void* grad_conic, int dtype,
                                     int backward_mode, void* stream);
 /* The fused renderer's form of the above (fp32, n_sh == 1): the four gradients of a Gaussian are
- * accumulated into one row of grad_slab[V, 9] = (rgb 3 | opacity 1 | uv 2 | conic 3), which must be
- * zero-initialised (or hold values to accumulate onto).
- * tile_cost / tile_order (both NULL, or both given): with the costs gs_render_tiles_prefix measured and an
- * int32[n_tiles + 8] workspace, the tiles' workgroups are started longest-first (shorter drain at the end of
- * the kernel; grids below 2048 tiles keep the natural order).  The gradients do not depend on it.
+ * accumulated into one row of grad_slab[V, 9] = (rgb 3 | opacity 1 | uv 2 | conic 3).  zero_slab_rows: 0 = the
+ * slab is zero-initialised (or holds values to accumulate onto); n > 0 = the call clears its first n rows itself
+ * (16-byte aligned slab), in the launch that also makes the tile order -- one prologue kernel instead of a fill
+ * and a single-workgroup kernel one after the other.
+ * tile_cost / tile_order: with the costs gs_render_tiles_prefix measured and an int32[n_tiles + 8] workspace, the
+ * tiles' workgroups are started longest-first (shorter drain at the end of the kernel; grids below 2048 tiles keep
+ * the natural order).  Both NULL: natural order.  tile_order alone: the order gs_render_backward_prologue left in
+ * it (the fused frames call the prologue as its own entry so that this one is the render kernel and nothing else).
+ * The gradients do not depend on the order.
  * segment_state (may be NULL): the workspace the forward filled -> (tile, depth segment) work items, see
  * gs_render_segment_workspace_bytes; tile_cost / tile_order are then not used.
  * cut_flags / full_ranges / overflow_sorted (all NULL, or all given; ABI 6): a frame rendered by gs_render_tiles_cut --
  * a tile with cut_flags[t] != 0 reads its (complete) list from overflow_sorted at full_ranges[t]. */
+/* The backward's prologue as its own call (ABI 6): clears the first zero_slab_rows rows of grad_slab[., 9] (0: none)
+ * and, if tile_order is given, leaves the launch order of the rows' tiles there -- longest-first from tile_cost
+ * (grids of >= 2048 tiles), the natural order otherwise -- in ONE launch; hand tile_order (and tile_cost = NULL,
+ * zero_slab_rows = 0) to gs_render_tiles_backward_slab. */
+int gs_render_backward_prologue(void* grad_slab, int64_t zero_slab_rows, const int32_t* tile_cost, int32_t* tile_order,
+                                int W, int H, int tile_row0, int tile_row1, void* stream);
 int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int32_t* tile_ranges,
                                   const int32_t* sorted_gaussians, const void* background_rgb,
                                   const int32_t* num_splats_per_pixel,
                                   const void* final_weight_per_pixel, const void* grad_image, int W,
-                                  int H, int tile_row0, int tile_row1, void* grad_slab,
+                                  int H, int tile_row0, int tile_row1, void* grad_slab, int64_t zero_slab_rows,
                                   const int32_t* tile_cost, int32_t* tile_order, const void* segment_state,
                                   const int32_t* cut_flags, const int32_t* full_ranges, const int32_t* overflow_sorted,
                                   int backward_mode, void* stream);

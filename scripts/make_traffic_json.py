@@ -36,10 +36,13 @@ ENTRY_CUT = {
                       "gs::k_bin_colscan_cut<64>", "gs::k_scan_tiles_cut"],
     "gs_tile_emit_sort": ["gs::k_bin_emit_buckets<1, 1024>", "gs::k_tile_sort_runs"],
 }
-ENTRY = ENTRY_CUT if "gs::k_bin_count_buckets" in vals else ENTRY_UNCUT
+ENTRY = dict(ENTRY_CUT if "gs::k_bin_count_buckets" in vals else ENTRY_UNCUT)
+if "gs::k_bwd_prologue" in vals:   # (round 4, late: slab clear + tile order as one launch behind its own entry point)
+    ENTRY["gs_render_tiles_backward_slab"] = ["gs::k_render_bwd<float, 1>"]
+    ENTRY["gs_render_backward_prologue"] = ["gs::k_bwd_prologue"]
 res = {"workload": workload, "source": pmc_dir, "note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
        "entries": {}}
-if ENTRY is ENTRY_CUT:   # (round 4 on: also every kernel on its own)
+if "gs::k_bin_count_buckets" in vals:   # (round 4 on: also every kernel on its own)
     res["binning"] = "depth cut"
     res["kernels"] = {k: {"fetch_kib": v.get("FETCH_SIZE", 0.0), "write_kib": v.get("WRITE_SIZE", 0.0),
                           "hbm_bytes": int((2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024)}

@@ -626,33 +626,73 @@ def test_backward_longest_first_tile_order(W, H, monkeypatch):
     # the order itself
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     order = torch.full((nt + 8,), -7, dtype=torch.int32, device=DEV)
-    slab = torch.zeros(V, 9, device=DEV)
+    # zero_slab_rows = V: the call clears the slab itself (in the launch that makes the order) -- rows beyond stay
+    big = torch.full((V + 3, 9), 7.0, device=DEV)
+    slab = big[:V]
     _hip.call("gs_render_tiles_backward_slab", p(f.packed), p(rgb_v), p(f.ranges), p(f.sorted_g), p(bg), p(nsp), p(fw),
-              p(gi), W, H, 0, (H + 15) // 16, p(slab), p(cost), p(order), None, None, None, None, _hip.GS_BACKWARD_DEFAULT,
-              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+              p(gi), W, H, 0, (H + 15) // 16, p(slab), ctypes.c_int64(V), p(cost), p(order), None, None, None, None,
+              _hip.GS_BACKWARD_DEFAULT, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
-    o = order.cpu()
+    assert (big[V:] == 7.0).all()
+    # ... also without an order (fill-only prologue), and zero_slab_rows = 0 accumulates onto what is there
+    again = torch.full((V, 9), 3.0, device=DEV)
+    _hip.call("gs_render_tiles_backward_slab", p(f.packed), p(rgb_v), p(f.ranges), p(f.sorted_g), p(bg), p(nsp), p(fw),
+              p(gi), W, H, 0, (H + 15) // 16, p(again), ctypes.c_int64(V), None, None, None, None, None, None,
+              _hip.GS_BACKWARD_DEFAULT, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert scaled_err(again, natural) < 2e-6
+    _hip.call("gs_render_tiles_backward_slab", p(f.packed), p(rgb_v), p(f.ranges), p(f.sorted_g), p(bg), p(nsp), p(fw),
+              p(gi), W, H, 0, (H + 15) // 16, p(again), ctypes.c_int64(0), None, None, None, None, None, None,
+              _hip.GS_BACKWARD_DEFAULT, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert scaled_err(again, 2 * natural) < 4e-6
     n_grid = (nt + 7) // 8 * 8                       # the launch grid; block 8 j + x is the j-th tile of XCD x
     per = n_grid // 8
-    assert sorted(t for t in o[:n_grid].tolist() if t >= 0) == list(range(nt)) and (o[n_grid:] == -7).all()
-    for x in range(8):
-        mine = o[x:n_grid:8]
-        tiles = mine[mine >= 0]
-        assert (mine[len(tiles):] == -1).all()                      # idle blocks come last
-        assert ((tiles // per) == x).all()                          # the XCD keeps its contiguous eighth
-        c = cost.cpu()[tiles.long()].float()
-        cls = (c * (127.0 / float(cost.max()))).int()               # the kernel's cost classes
-        assert (cls[1:] <= cls[:-1]).all()
+
+    def check_order(order_t):
+        o = order_t.cpu()
+        assert sorted(t for t in o[:n_grid].tolist() if t >= 0) == list(range(nt)) and (o[n_grid:] == -7).all()
+        for x in range(8):
+            mine = o[x:n_grid:8]
+            tiles = mine[mine >= 0]
+            assert (mine[len(tiles):] == -1).all()                      # idle blocks come last
+            assert ((tiles // per) == x).all()                          # the XCD keeps its contiguous eighth
+            c = cost.cpu()[tiles.long()].float()
+            cls = (c * (127.0 / float(cost.max()))).int()               # the kernel's cost classes
+            assert (cls[1:] <= cls[:-1]).all()
+
+    check_order(order)
     assert scaled_err(slab, natural) < 2e-6
-    # cost without order (or the reverse) is refused
+    # the prologue as its own call (what the fused frames do): the same order, the slab cleared; the backward then
+    # takes the order as given
+    order2 = torch.full((nt + 8,), -7, dtype=torch.int32, device=DEV)
+    slab2 = torch.full((V, 9), 5.0, device=DEV)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _hip.call("gs_render_backward_prologue", p(slab2), ctypes.c_int64(V), p(cost), p(order2), W, H, 0, (H + 15) // 16, stream)
+    check_order(order2)   # (tiles of one cost class come in the order the LDS atomics hand out: not repeatable)
+    assert not slab2.any()
+    _hip.call("gs_render_tiles_backward_slab", p(f.packed), p(rgb_v), p(f.ranges), p(f.sorted_g), p(bg), p(nsp), p(fw),
+              p(gi), W, H, 0, (H + 15) // 16, p(slab2), ctypes.c_int64(0), None, p(order2), None, None, None, None,
+              _hip.GS_BACKWARD_DEFAULT, stream)
+    assert scaled_err(slab2, natural) < 2e-6
+    # a row range below 2048 tiles: the prologue spells out the natural order (block 8 j + x = j-th tile of eighth x)
+    rows = 8
+    nt_b = rows * ((W + 15) // 16)
+    ng_b = (nt_b + 7) // 8 * 8
+    order3 = torch.full((nt + 8,), -7, dtype=torch.int32, device=DEV)
+    _hip.call("gs_render_backward_prologue", None, ctypes.c_int64(0), p(cost), p(order3), W, H, 2, 2 + rows, stream)
+    o3 = order3.cpu()
+    per_b = ng_b // 8
+    want = torch.tensor([(b % 8) * per_b + b // 8 for b in range(ng_b)], dtype=torch.int32)
+    assert torch.equal(o3[:ng_b], torch.where(want < nt_b, want, torch.full_like(want, -1))) and (o3[ng_b:] == -7).all()
+    # cost without order is refused
     with pytest.raises(RuntimeError, match="go together"):
         _hip.call("gs_render_tiles_backward_slab", p(f.packed), p(rgb_v), p(f.ranges), p(f.sorted_g), p(bg), p(nsp),
-                  p(fw), p(gi), W, H, 0, (H + 15) // 16, p(slab), p(cost), None, None, None, None, None, _hip.GS_BACKWARD_DEFAULT,
+                  p(fw), p(gi), W, H, 0, (H + 15) // 16, p(slab), ctypes.c_int64(0), p(cost), None, None, None, None, None,
+                  _hip.GS_BACKWARD_DEFAULT,
                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     # the gradient mode is an argument of the call (ABI 5): anything but DEFAULT / COMPAT / EXACT is refused
     with pytest.raises(RuntimeError, match="backward mode"):
         _hip.call("gs_render_tiles_backward_slab", p(f.packed), p(rgb_v), p(f.ranges), p(f.sorted_g), p(bg), p(nsp),
-                  p(fw), p(gi), W, H, 0, (H + 15) // 16, p(slab), None, None, None, None, None, None, 7,
+                  p(fw), p(gi), W, H, 0, (H + 15) // 16, p(slab), ctypes.c_int64(0), None, None, None, None, None, None, 7,
                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
 
 
