@@ -1621,231 +1621,6 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     GS_STAT_FLUSH(16);
 }
 
-// ---- the fused frame's backward with TWO pixels per lane ("wide") ---------------------------------------
-// k_render_bwd<float, 1> spends ~135 of the ~305 SIMD cycles of a (wave, splat) visit on work that does not depend
-// on the pixel: the record's LDS fetch, the walk over the touch mask, the nine-value cross-lane reduction (20 DPP
-// adds + 3 lane swaps at 4-8 cycles each) and the slot store.  A splat that touches one 8x8 patch of a tile mostly
-// touches its horizontal neighbour too, so here a wave owns a 16x8 STRIP -- lane (x, y) the pixels (x, y) and
-// (x + 8, y) of it -- and pays that part once for both patches: the two pixels' nine terms are added in the lane
-// and reduced together.  Same arithmetic per pixel as k_render_bwd (visit_pixel_bwd is its per-lane body: the
-// alpha and the skip decisions bit for bit, render_backward.cu:141-234), the per-(splat, tile) sums differ by the
-// order of fp32 additions only.  A patch the splat does not touch is skipped wave-wide from its own mask bit, so
-// a visit never costs more than before.  Workgroup = one tile = two waves; whole frames of the fused renderer
-// only (no depth segments, one colour coefficient per channel, slab output).
-struct BwdPixel {
-    float weight, ca0, ca1, ca2, gi0, gi1, gi2;
-    int nsp;
-    bool bg_init;
-};
-struct BwdTerms {
-    float aw, w, q0, q1, q2;
-};
-__device__ __forceinline__ void visit_pixel_bwd(BwdPixel& px, BwdTerms& t, bool reach, float du, float dv, float du2,
-                                                float dv2, const Vec4<float>& g0, const Vec4<float>& g1,
-                                                const Vec4<float>& g2, int k_q1, float bg0, float bg1, float bg2) {
-    using T = float;
-    t.aw = 0; t.w = 0; t.q0 = 0; t.q1 = 0; t.q2 = 0;
-    if (reach && !(du2 + dv2 > g0.z)) {   // inside the cutoff radius
-        const T duv = du * dv;
-        const T mh = (g1.z * du * du - (g1.y + g1.y) * du * dv + g1.x * dv * dv) * g2.x;
-        const T e = exp_neg_half(mh);
-        const T norm_prob = (mh > T(0)) ? e : T(0);
-        T alpha = g0.w * norm_prob;
-        if (alpha > Thr<T>::sat_gt()) alpha = Thr<T>::alpha_cap();
-        if (alpha >= Thr<T>::alpha_min()) {
-            if (!px.bg_init) {   // render_backward.cu:172-181
-                const T bw = 1.0 - (alpha * px.weight + 1.0 - px.weight);
-                if (bw > Thr<T>::bgw_gt()) {
-                    px.ca0 += bg0 * bw;
-                    px.ca1 += bg1 * bw;
-                    px.ca2 += bg2 * bw;
-                }
-                px.bg_init = true;
-            }
-            {
-#pragma clang fp contract(fast)
-                const T r1ma = fast_rcp(T(1) - alpha);
-                if (k_q1 < px.nsp - 1) px.weight = px.weight * r1ma;   // Q1 (chunk-local index) unless exact
-                t.aw = alpha * px.weight;
-                const T c0 = g2.y, c1 = g2.z, c2 = g2.w;
-                const T ga = (c0 * px.weight - px.ca0 * r1ma) * px.gi0 + (c1 * px.weight - px.ca1 * r1ma) * px.gi1 +
-                             (c2 * px.weight - px.ca2 * r1ma) * px.gi2;
-                px.ca0 += c0 * t.aw;
-                px.ca1 += c1 * t.aw;
-                px.ca2 += c2 * t.aw;
-                t.w = norm_prob * ga;
-                t.q0 = (dv2 - g1.z * mh) * t.w;
-                t.q1 = (g1.y * mh - duv) * t.w;
-                t.q2 = (du2 - g1.x * mh) * t.w;
-            }
-        }
-    }
-}
-
-#ifndef GS_BWD_WIDE
-#define GS_BWD_WIDE 0
-#endif
-#ifdef GS_BWDW_WAVES
-#define GS_BWDW_OCC __attribute__((amdgpu_waves_per_eu(GS_BWDW_WAVES, GS_BWDW_WAVES)))
-#else
-#define GS_BWDW_OCC
-#endif
-constexpr int WB = 128;   // threads of a wide workgroup: two waves = two 16x8 strips of the tile
-__global__ __launch_bounds__(WB) GS_BWDW_OCC void k_render_bwd_wide(
-    const float* __restrict__ packed, const int* __restrict__ ranges, const int* __restrict__ sorted,
-    const float* __restrict__ bg, const int* __restrict__ nsp_in, const float* __restrict__ fw_in,
-    const float* __restrict__ grad_image, int W, int H, int ntx, int tile0, int nt, float* __restrict__ g_slab,
-    int exact, const int* __restrict__ tile_order, const int* __restrict__ cut_flags,
-    const int* __restrict__ full_ranges, const int* __restrict__ overflow_sorted) {
-    using T = float;
-    constexpr int SV = 9;
-    constexpr int RCHUNK = GS_BWD_CHUNK;
-    constexpr int NWORD = RCHUNK / 64;
-    constexpr int REF_CH = ref_chunk<float>(1);
-    static_assert(RCHUNK <= WB && RCHUNK % 64 == 0, "a chunk is staged and flushed one splat per thread");
-    __shared__ alignas(16) T s_geom[RCHUNK * GS_PACKED_WIDTH];
-    __shared__ int s_idx[RCHUNK];
-    __shared__ T s_acc[2 * RCHUNK * SV];   // [strip][splat][9]
-    __shared__ int s_max[2];
-    __shared__ unsigned long long s_mask[4][NWORD];
-    __shared__ unsigned long long s_hit[2][NWORD];
-
-    const int t_local = tile_order ? tile_order[blockIdx.x] : tile_of_block(blockIdx.x, nt);
-    if (t_local < 0 || t_local >= nt) return;
-    const int tile = tile0 + t_local;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile_x = tile % ntx, tile_y = tile / ntx;
-    const int ua = tile_x * 16 + (lane & 7), ub = ua + 8, vy = tile_y * 16 + wave * 8 + (lane >> 3);
-    int s0 = ranges[tile];
-    int n_tile = ranges[tile + 1] - s0;
-    if (cut_flags != nullptr && cut_flags[tile] != 0) {   // depth cut: a repaired tile reads its complete list
-        s0 = full_ranges[tile];
-        n_tile = full_ranges[tile + 1] - s0;
-        sorted = overflow_sorted;
-    }
-    if (n_tile <= 0) return;
-
-    BwdPixel A{0, 0, 0, 0, 0, 0, 0, 0, false}, B{0, 0, 0, 0, 0, 0, 0, 0, false};
-    if (ua < W && vy < H) {
-        const size_t p = (size_t)vy * W + ua;
-        A.nsp = nsp_in[p];
-        A.weight = fw_in[p];
-        A.gi0 = grad_image[p * 3 + 0]; A.gi1 = grad_image[p * 3 + 1]; A.gi2 = grad_image[p * 3 + 2];
-    }
-    if (ub < W && vy < H) {
-        const size_t p = (size_t)vy * W + ub;
-        B.nsp = nsp_in[p];
-        B.weight = fw_in[p];
-        B.gi0 = grad_image[p * 3 + 0]; B.gi1 = grad_image[p * 3 + 1]; B.gi2 = grad_image[p * 3 + 2];
-    }
-    // the tile's deepest used splat (render_backward.cu:131 makes everything beyond it a no-op)
-    int m = max(A.nsp, B.nsp);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d));
-    if (lane == 0) s_max[wave] = m;
-    __syncthreads();
-    const int n_used = min(n_tile, max(s_max[0], s_max[1]));
-    if (n_used <= 0) return;
-
-    const T pua = T(ua), pub = T(ub), pv = T(vy);
-    const T Y0 = T(GS_SH_0);
-    const int slot_off = slot_lane_offset(lane);
-    const T bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    const int pa = 2 * wave, pb = 2 * wave + 1;   // the strip's patches in build_touch_masks' numbering
-
-    const int last_chunk = (n_used - 1) / RCHUNK;
-    for (int chunk = last_chunk; chunk >= 0; chunk--) {
-        const int base = chunk * RCHUNK;
-        const int cnt = min(RCHUNK, n_used - base);
-        __syncthreads();   // previous chunk fully flushed
-        stage_chunk<T, 1>(packed, nullptr, sorted, s0 + base, cnt, tid, s_geom, nullptr, s_idx);
-        // (no barrier in between: thread t tests the record thread t staged)
-        build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile_x, tile_y, s_mask);
-        __syncthreads();
-
-        for (int word = (cnt - 1) >> 6; word >= 0; word--) {
-            const unsigned long long ma = wave_uniform(s_mask[pa][word]), mb = wave_uniform(s_mask[pb][word]);
-            unsigned long long mm = ma | mb;
-            unsigned long long hit = 0;
-            while (mm) {
-                const int bit = 63 - __builtin_clzll(mm);
-                mm &= ~(1ull << bit);
-                const int i = (word << 6) + bit;
-                const int k = base + i;
-                const bool ta = (ma >> bit) & 1ull, tb = (mb >> bit) & 1ull;   // wave-uniform
-                const bool reach_a = ta && k < A.nsp, reach_b = tb && k < B.nsp;
-                const unsigned long long ra = ballot(reach_a), rb = ballot(reach_b);
-                if ((ra | rb) == 0) continue;   // no lane reaches this splat
-                const T* rec = s_geom + i * GS_PACKED_WIDTH;
-                const Vec4<T> g0 = *reinterpret_cast<const Vec4<T>*>(rec);       // u v r2 opacity
-                const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(rec + 4);   // a b c det
-                const Vec4<T> g2 = *reinterpret_cast<const Vec4<T>*>(rec + 8);   // 1/det, colour
-                asm volatile("" ::"v"(g1.x), "v"(g1.y), "v"(g1.z), "v"(g2.x), "v"(g2.y), "v"(g2.z), "v"(g2.w));
-                const int k_q1 = exact ? k : k % REF_CH;
-                const T dv = pv - g0.y, dv2 = dv * dv;
-                const T dua = pua - g0.x, dub = pub - g0.x;
-                BwdTerms ta_{0, 0, 0, 0, 0}, tb_{0, 0, 0, 0, 0};
-                if (ra != 0) visit_pixel_bwd(A, ta_, reach_a, dua, dv, dua * dua, dv2, g0, g1, g2, k_q1, bg0, bg1, bg2);
-                if (rb != 0) visit_pixel_bwd(B, tb_, reach_b, dub, dv, dub * dub, dv2, g0, g1, g2, k_q1, bg0, bg1, bg2);
-                // a lane contributes iff a pixel of it passed the alpha test; aw > 0 there
-                if (ballot(ta_.aw != T(0) || tb_.aw != T(0)) == 0) continue;
-                T val[9];
-                const T awya = ta_.aw * Y0, awyb = tb_.aw * Y0;
-                val[0] = awya * A.gi0 + awyb * B.gi0;
-                val[1] = awya * A.gi1 + awyb * B.gi1;
-                val[2] = awya * A.gi2 + awyb * B.gi2;
-                val[3] = ta_.w + tb_.w;
-                val[4] = ta_.w * dua + tb_.w * dub;
-                val[5] = ta_.w * dv + tb_.w * dv;
-                val[6] = ta_.q0 + tb_.q0;
-                val[7] = ta_.q1 + tb_.q1;
-                val[8] = ta_.q2 + tb_.q2;
-                reduce9_to_slot(val, lane, slot_off, &s_acc[(wave * RCHUNK + i) * SV]);
-                hit |= 1ull << bit;
-            }
-            if (lane == 0) s_hit[wave][word] = hit;
-        }
-        __syncthreads();
-        // Phase 1, thread = splat: add the strips' slots, apply the per-splat factors, park the row in strip 0's slot
-        if (tid < cnt) {
-            T a[SV];
-#pragma unroll
-            for (int j = 0; j < SV; j++) a[j] = 0;
-#pragma unroll
-            for (int w2 = 0; w2 < 2; w2++) {
-                if ((s_hit[w2][tid >> 6] >> (tid & 63)) & 1ull) {
-                    const T* sl = s_acc + (w2 * RCHUNK + tid) * SV;
-#pragma unroll
-                    for (int j = 0; j < SV; j++) a[j] += sl[j];
-                }
-            }
-            const T* rec = s_geom + tid * GS_PACKED_WIDTH;
-            const T ca = rec[4], cb = rec[5], cc = rec[6];
-            const T kf = T(-0.5) * rec[3] * rec[8];
-            const T Mu = a[4], Mv = a[5];
-            a[4] = T(-2) * kf * (cc * Mu - cb * Mv);
-            a[5] = T(-2) * kf * (ca * Mv - cb * Mu);
-            a[6] *= kf;
-            a[7] *= kf;
-            a[8] *= kf;
-            T* row = s_acc + tid * SV;
-#pragma unroll
-            for (int j = 0; j < SV; j++) row[j] = a[j];
-        }
-        __syncthreads();
-        // Phase 2, nine lanes = one row of the slab (see k_render_bwd)
-        const int sub = lane / SV, col = lane - sub * SV;   // lane 63: idle
-        for (int r0 = wave * 7; r0 < cnt; r0 += 14) {
-            const int r = r0 + sub;
-            const bool in = lane < 63 && r < cnt;
-            const T v = in ? s_acc[r * SV + col] : T(0);
-            const unsigned long long nz = ballot(v != T(0));
-            const bool any = in && ((nz >> (sub * SV)) & 0x1ffull) != 0;   // rows of zeros stay untouched
-            if (any) global_add(g_slab + (size_t)s_idx[r] * SV + col, v);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
 // depth (depth.cu:7-115), fp32 only
 // ---------------------------------------------------------------------------------------------------
@@ -2259,20 +2034,12 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
             cut_flags, full_ranges, overflow_sorted);
         return check_launch("render_tiles_backward_slab");
     }
-#if GS_BWD_WIDE && !defined(GS_STATS)
-    // two pixels per lane (k_render_bwd_wide); the instrumented builds keep the kernel their counters live in
-    k_render_bwd_wide<<<grid, WB, 0, s>>>((const float*)packed, tile_ranges, sorted_gaussians, (const float*)background_rgb,
-                                          num_splats_per_pixel, (const float*)final_weight_per_pixel,
-                                          (const float*)grad_image, W, H, ntx, tile_row0 * ntx, nt, (float*)grad_slab, exact,
-                                          use_order ? tile_order : nullptr, cut_flags, full_ranges, overflow_sorted);
-#else
     k_render_bwd<float, 1><<<grid, RB, 0, s>>>(
         (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
         (const float*)background_rgb, num_splats_per_pixel, (const float*)final_weight_per_pixel,
         (const float*)grad_image, W, H, ntx, tile_row0 * ntx, nt, (float*)grad_slab, nullptr,
         nullptr, nullptr, 1, exact, use_order ? tile_order : nullptr, nullptr, nullptr,
         SEG_NONE, cut_flags, full_ranges, overflow_sorted);
-#endif
     return check_launch("render_tiles_backward_slab");
 }
 
