@@ -135,6 +135,14 @@ __device__ unsigned long long g_timeline[2 * GS_TIMELINE_CAP * GS_TIMELINE_W];
 #define GS_BWD_CHUNK 64
 #endif
 constexpr int RB = 256;      // workgroup size = pixels per tile
+// (experiment builds: bytes of unused dynamic LDS per workgroup of the fused frame's render kernels -- caps the
+// workgroups a CU holds, i.e. trades waves in flight for shorter-lived ones; profiles/r04/kbench_lds_pad.txt)
+#ifndef GS_FWD_LDS_PAD
+#define GS_FWD_LDS_PAD 0
+#endif
+#ifndef GS_BWD_LDS_PAD
+#define GS_BWD_LDS_PAD 0
+#endif
 
 // splats staged in LDS per step (at most one per thread); smaller for the wide test-only
 // instantiations so that every kernel stays below 64 KiB of static LDS
@@ -1855,7 +1863,7 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
             ntx, t0, nt, num_splats_per_pixel, (float*)final_weight_per_pixel, (float*)image, GS_SORT_PREFIX,
             tile_flags, S, tile_cost, seg);
     else
-        k_render_fwd<float, 1><<<grid, RB, 0, s>>>(
+        k_render_fwd<float, 1><<<grid, RB, GS_FWD_LDS_PAD, s>>>(
             (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
             (const float*)background_rgb, W, H, ntx, t0, nt, num_splats_per_pixel,
             (float*)final_weight_per_pixel, (float*)image, GS_SORT_PREFIX, tile_flags, S, tile_cost, nullptr, nullptr,
@@ -1890,7 +1898,7 @@ int gs_render_tiles_cut(const void* packed, const void* rgb, const int32_t* tile
     const int t0 = tile_row0 * ntx;
     int* flag_counter = depth_cut_flag_counter(cut_workspace, N, ntx * nty);
     // 1. every tile from its kept (completely sorted) depth prefix; raises the flags
-    k_render_fwd<float, 1><<<grid, RB, 0, s>>>(
+    k_render_fwd<float, 1><<<grid, RB, GS_FWD_LDS_PAD, s>>>(
         (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians, (const float*)background_rgb, W, H,
         ntx, t0, nt, num_splats_per_pixel, (float*)final_weight_per_pixel, (float*)image, 0, tile_flags, S, tile_cost,
         nullptr, nullptr, full_ranges, flag_counter);
@@ -2034,7 +2042,7 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
             cut_flags, full_ranges, overflow_sorted);
         return check_launch("render_tiles_backward_slab");
     }
-    k_render_bwd<float, 1><<<grid, RB, 0, s>>>(
+    k_render_bwd<float, 1><<<grid, RB, GS_BWD_LDS_PAD, s>>>(
         (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
         (const float*)background_rgb, num_splats_per_pixel, (const float*)final_weight_per_pixel,
         (const float*)grad_image, W, H, ntx, tile_row0 * ntx, nt, (float*)grad_slab, nullptr,
