@@ -41,9 +41,10 @@ EXPORTS = [
     "gs_compute_projection_jacobian", "gs_compute_projection_jacobian_backward",
     "gs_compute_conic", "gs_compute_conic_backward",
     "gs_precompute_rgb_from_sh", "gs_precompute_rgb_from_sh_backward",
-    "gs_tile_workspace_ints", "gs_tile_count", "gs_tile_emit_sort", "gs_tile_sort_flagged",
+    "gs_tile_workspace_ints", "gs_tile_count", "gs_tile_emit_sort", "gs_tile_emit_sort_bounded", "gs_tile_sort_flagged",
     "gs_preprocess_workspace_ints", "gs_preprocess_forward", "gs_preprocess_backward",
-    "gs_pack_splats", "gs_render_tiles", "gs_render_tiles_packed", "gs_render_tiles_prefix", "gs_render_tiles_backward",
+    "gs_pack_splats", "gs_render_tiles", "gs_render_tiles_packed", "gs_render_tiles_prefix", "gs_render_tiles_prefix_phased",
+    "gs_render_tiles_backward",
     "gs_render_tiles_backward_packed", "gs_render_tiles_backward_slab", "gs_render_backward_prologue",
     "gs_render_segment_workspace_bytes",
     "gs_set_backward_mode", "gs_get_backward_mode", "gs_render_depth", "gs_halo_workspace_ints", "gs_halo_plan", "gs_halo_gather_sum",

@@ -251,9 +251,14 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int* __restrict__ counts, i
                                                      int* __restrict__ host_mirror) {
     __shared__ int s_wave[16];
     __shared__ int s_carry;
+    __shared__ int s_longest;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_carry = 0;
+    if (tid == 0) {
+        s_carry = 0;
+        s_longest = 0;
+    }
     __syncthreads();
+    int longest = 0;
     for (int base = 0; base < T; base += 1024 * 4) {
         int v[4], sum = 0;
 #pragma unroll
@@ -262,6 +267,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int* __restrict__ counts, i
             v[k] = (i >= t0 && i < t0 + Tb) ? counts[i] : 0;
             if (clear && i >= t0 && i < t0 + Tb) counts[i] = 0;
             sum += v[k];
+            longest = max(longest, v[k]);
         }
         int incl = sum;   // inclusive wave scan
 #pragma unroll
@@ -284,16 +290,22 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int* __restrict__ counts, i
         if (tid == 1023) s_carry = run;
         __syncthreads();
     }
+    if (host_mirror != nullptr) {   // (workgroup-uniform)
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) longest = max(longest, __shfl_xor(longest, d));
+        if (lane == 0) atomicMax(&s_longest, longest);
+        __syncthreads();
+    }
     if (tid == 0) {
         ranges[T] = s_carry;
         const int V = v_dev ? *v_dev : 0;
         if (v_dev) ranges[T + 1] = V;
-        // the frame's host read without a copy in the stream: (S, V) straight into the caller's pinned buffer (a
-        // device -> host hipMemcpyAsync of 8 bytes is a ~10 us blit kernel the next launch queues behind)
+        // the frame's host read without a copy in the stream: (S, V, longest list) straight into the caller's pinned
+        // buffer (a device -> host hipMemcpyAsync of 8 bytes is a ~10 us blit kernel the next launch queues behind)
         if (host_mirror != nullptr) {
             host_mirror[0] = s_carry;
             host_mirror[1] = V;
-            host_mirror[2] = s_carry;
+            host_mirror[2] = s_longest;
             __threadfence_system();
         }
     }
@@ -1161,13 +1173,24 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort(
     const int* __restrict__ ranges,
                                                           const uint64_t* __restrict__ keys,
                                                           int* __restrict__ sorted, int tile0,
-                                                          int64_t cap) {
+                                                          int64_t cap, int64_t lim) {
     __shared__ SortLds L;
     const int tile = tile0 + blockIdx.x;
     const int s0 = ranges[tile];
     const int n = ranges[tile + 1] - s0;
-    if (n <= 0 || n > 4096 || (int64_t)s0 + n > cap) return;
+    if (n <= 0 || (int64_t)s0 + n > cap) return;
     const int tid = threadIdx.x;
+    if (n > (PREFIX ? 4096 : 1024)) {
+        // a longer list belongs to one of the kernels launch_tile_sort enqueues behind this one -- IF the caller's
+        // bound on the list lengths (lim) let it enqueue that kernel.  A bound that was only a guess, and too small,
+        // leaves the list to nobody: the caller will find out and repeat the call, but a render it enqueued in
+        // between must at least read valid indices -- the list's entries in emit order.
+        const int lower = n <= 4096 ? 1024 : (n <= SORT_MAX_LDS_KEYS ? 4096 : SORT_MAX_LDS_KEYS);
+        const bool covered = PREFIX ? lim > 4096 : lim > lower;
+        if (!covered)
+            for (int i = tid; i < n; i += SORT_BLOCK) sorted[s0 + i] = (int)(uint32_t)keys[s0 + i];
+        return;
+    }
     if (n <= 256) {
         if (tid >= 64) return;
         if (n <= 64) wave_sort_tile<1>(keys + s0, sorted + s0, n, tid);
@@ -1320,24 +1343,26 @@ static void sort_attr_once() {
 constexpr int WALK_GRID = 512;   // kernels whose work is rare walk the tiles with this many workgroups
 
 static int launch_tile_sort(const int* ranges, uint64_t* keys, int* sorted, int tile0, int nt,
-                            int64_t S, int sort_prefix, hipStream_t s) {
+                            int64_t S, int sort_prefix, hipStream_t s, int64_t longest = -1) {
     if (nt <= 0) return GS_OK;
     const int walk = nt < WALK_GRID ? nt : WALK_GRID;
-    // larger classes can only be populated if the instance count allows it
+    // larger classes can only be populated if the instance count -- or the caller's bound on the longest list (< 0:
+    // none) -- allows it (S itself stays the capacity the kernels check their writes against)
+    const int64_t lim = longest >= 0 && longest < S ? longest : S;
     if (sort_prefix > 0) {
-        k_tile_sort<true><<<nt, SORT_BLOCK, 0, s>>>(ranges, keys, sorted, tile0, S);
-        if (S > 4096) k_tile_sort_big<true><<<walk, SORT_BLOCK, 0, s>>>(ranges, keys, sorted, tile0, nt, S);
+        k_tile_sort<true><<<nt, SORT_BLOCK, 0, s>>>(ranges, keys, sorted, tile0, S, lim);
+        if (lim > 4096) k_tile_sort_big<true><<<walk, SORT_BLOCK, 0, s>>>(ranges, keys, sorted, tile0, nt, S);
         return GS_OK;
     }
     sort_attr_once();
-    k_tile_sort<false><<<nt, SORT_BLOCK, 0, s>>>(ranges, keys, sorted, tile0, S);
-    if (S > 1024)
+    k_tile_sort<false><<<nt, SORT_BLOCK, 0, s>>>(ranges, keys, sorted, tile0, S, lim);
+    if (lim > 1024)
         k_tile_sort_lds<1024, 4096><<<nt, SORT_BLOCK, sort_lds_bytes(4096), s>>>(ranges, keys, sorted,
                                                                              tile0, S);
-    if (S > 4096)
+    if (lim > 4096)
         k_tile_sort_lds<4096, 8192><<<nt, SORT_BLOCK, sort_lds_bytes(8192), s>>>(ranges, keys, sorted,
                                                                              tile0, S);
-    if (S > SORT_MAX_LDS_KEYS)
+    if (lim > SORT_MAX_LDS_KEYS)
         k_tile_sort_big<false><<<walk, SORT_BLOCK, 0, s>>>(ranges, keys, sorted, tile0, nt, S);
     return GS_OK;
 }
@@ -1493,6 +1518,16 @@ int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void*
                       int tile_row0, int tile_row1, const int32_t* tile_ranges, int32_t* workspace,
                       uint64_t* keys, int64_t S, int32_t* sorted_gaussians, int sort_prefix,
                       void* stream) {
+    return gs_tile_emit_sort_bounded(uvs, xyz_camera_frame, conic, V, visible_count, subset, subset_count, n_tiles_x,
+                                     n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, workspace, keys, S,
+                                     sorted_gaussians, sort_prefix, -1, stream);
+}
+
+int gs_tile_emit_sort_bounded(const void* uvs, const void* xyz_camera_frame, const void* conic, int V,
+                              const int32_t* visible_count, const int32_t* subset, const int32_t* subset_count,
+                              int n_tiles_x, int n_tiles_y, float mh_dist, int tile_row0, int tile_row1,
+                              const int32_t* tile_ranges, int32_t* workspace, uint64_t* keys, int64_t S,
+                              int32_t* sorted_gaussians, int sort_prefix, int64_t longest_list, void* stream) {
     GS_REQUIRE(tile_row0 >= 0 && tile_row1 <= n_tiles_y && tile_row0 <= tile_row1,
                "bad tile row range");
     GS_REQUIRE((subset == nullptr) == (subset_count == nullptr),
@@ -1526,7 +1561,7 @@ int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void*
     }
     const int t0 = tile_row0 * n_tiles_x;
     const int nt = (tile_row1 - tile_row0) * n_tiles_x;
-    launch_tile_sort(tile_ranges, keys, sorted_gaussians, t0, nt, S, sort_prefix, s);
+    launch_tile_sort(tile_ranges, keys, sorted_gaussians, t0, nt, S, sort_prefix, s, longest_list);
     return check_launch("tile_emit_sort");
 }
 
@@ -1594,7 +1629,7 @@ int gs_tile_emit_sort_cut(const void* bin_records, int N, int n_tiles_x, int n_t
         S, nullptr, cs);
     // every kept list has at most GS_SORT_PREFIX entries, laid out as short runs in depth order
 #ifdef GS_CUT_GENERAL_SORT   // (A/B build: the general <= 1024 sorts)
-    k_tile_sort<false><<<Tb, SORT_BLOCK, 0, s>>>(tile_ranges, keys, sorted_gaussians, t0, S);
+    k_tile_sort<false><<<Tb, SORT_BLOCK, 0, s>>>(tile_ranges, keys, sorted_gaussians, t0, S, S);
 #else
     k_tile_sort_runs<<<Tb, SORT_BLOCK, 0, s>>>(tile_ranges, keys, sorted_gaussians, t0, S);
 #endif

@@ -50,6 +50,7 @@ std::map<HintKey, int64_t> g_capacity;
 // depth cut (include/gsplat_hip.h "depth-bucketed binning"): capacity of the overflow buffers (the frame's complete
 // instance count) and the complete instance count of the latest frame of a shape (what "auto" decides on)
 std::map<HintKey, int64_t> g_overflow_capacity, g_complete_count;
+std::map<HintKey, int64_t> g_longest_list;   // longest tile list of the shape's last complete-list frame (a guess for the next)
 struct PinnedRing {
     std::vector<Tensor> bufs;
     std::vector<hipEvent_t> events;
@@ -58,6 +59,7 @@ struct PinnedRing {
 std::map<int, PinnedRing> g_pinned;   // per device
 struct Counters {
     int64_t frames = 0, speculative = 0, misses = 0, s_min = -1, s_max = -1, slab_copies = 0, cut_frames = 0, cut_backoffs = 0;
+    int64_t render_only = 0, late_repairs = 0, long_list_misses = 0;   // the longest-list guess of complete-list frames
 } g_counters;
 std::vector<Tensor> g_flag_log;
 Tensor g_last_flags;   // tile_flags of the latest prefix-mode render (tests / tools)
@@ -230,6 +232,7 @@ void require_f32_cuda(const Tensor& t, const char* name, c10::Device dev, std::i
 struct RenderOut {
     Tensor buf, image, fw, nsp, seg;   // seg: state for the depth-segmented backward (empty: not segmented)
     Tensor cut_flags, overflow_sorted;   // depth-cut frames: flagged tiles and their complete lists (else undefined)
+    Tensor prefix_flags;                 // prefix-sorted frames: the provisional render's tile flags (else undefined)
 };
 // what gs_render_tiles_cut needs from the frame's binning
 struct CutRef {
@@ -243,7 +246,8 @@ struct CutRef {
 
 RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* ranges, Tensor& sorted, Tensor& keys,
                          const Tensor& bg, int W, int H, int row0, int row1, bool whole, int sort_prefix, void* stream,
-                         const HintKey& key, bool exact_count, int64_t image_rows = 0, const CutRef* cut = nullptr) {
+                         const HintKey& key, bool exact_count, int64_t image_rows = 0, const CutRef* cut = nullptr,
+                         int prefix_phases = GS_PREFIX_RENDER | GS_PREFIX_REPAIR) {
     const int64_t P = (int64_t)W * H;
     // image_rows > H (multi-GPU, equal bands): the image block holds world_size full bands so that the band
     // images can be all-gathered in place; the kernels only see the first H rows
@@ -289,11 +293,12 @@ RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* 
     if (sort_prefix && sorted.size(0) > sort_prefix) {
         Tensor flags = torch::empty({(int64_t)ntx * nty}, opt.dtype(torch::kInt32));
         timed("gs_render_tiles_prefix", stream, [&] {
-            return gs_render_tiles_prefix(packed, rgbr, ranges, sorted.data_ptr<int32_t>(),
-                                          (const uint64_t*)keys.data_ptr<int64_t>(), sorted.size(0), bg.data_ptr(), W, H, row0,
-                                          row1, flags.data_ptr<int32_t>(), r.nsp.data_ptr<int32_t>(), r.fw.data_ptr(),
-                                          r.image.data_ptr(), tile_cost, seg_p, stream);
+            return gs_render_tiles_prefix_phased(packed, rgbr, ranges, sorted.data_ptr<int32_t>(),
+                                                 (const uint64_t*)keys.data_ptr<int64_t>(), sorted.size(0), bg.data_ptr(), W, H,
+                                                 row0, row1, flags.data_ptr<int32_t>(), r.nsp.data_ptr<int32_t>(),
+                                                 r.fw.data_ptr(), r.image.data_ptr(), tile_cost, seg_p, prefix_phases, stream);
         });
+        r.prefix_flags = flags;
         std::lock_guard<std::mutex> lock(g_mutex);
         if (g_flag_log.size() < 512) g_flag_log.push_back(flags);
         g_last_flags = flags;
@@ -307,6 +312,22 @@ RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* 
         });
     }
     return r;
+}
+
+// the repair phase of a prefix-sorted frame whose render was enqueued without it (the guess "no list exceeds the
+// prefix" turned out wrong): full sort + second render of the flagged tiles, on the buffers of that render
+void render_prefix_repair(RenderOut& r, const float* packed, const float* rgbr, const int32_t* ranges, Tensor& sorted,
+                          Tensor& keys, const Tensor& bg, int W, int H, int row0, int row1, void* stream) {
+    const int64_t P = (int64_t)W * H;
+    const int64_t PI = r.image.size(0) * (int64_t)W;
+    int32_t* tile_cost = reinterpret_cast<int32_t*>(r.buf.data_ptr<float>()) + 3 * PI + 2 * P;
+    timed("gs_render_tiles_prefix", stream, [&] {
+        return gs_render_tiles_prefix_phased(packed, rgbr, ranges, sorted.data_ptr<int32_t>(),
+                                             (const uint64_t*)keys.data_ptr<int64_t>(), sorted.size(0), bg.data_ptr(), W, H, row0,
+                                             row1, r.prefix_flags.data_ptr<int32_t>(), r.nsp.data_ptr<int32_t>(),
+                                             r.fw.data_ptr(), r.image.data_ptr(), tile_cost,
+                                             r.seg.numel() > 0 ? r.seg.data_ptr() : nullptr, GS_PREFIX_REPAIR, stream);
+    });
 }
 
 // ---- node 1: parameters -> uv, conic, opacity, colour (+ the frame's lists and, early, its image) --------
@@ -382,7 +403,7 @@ struct Preprocess : public torch::autograd::Function<Preprocess> {
 
         auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(dev);
         Tensor sorted, keys;
-        auto emit_sort = [&](int64_t capacity) {
+        auto emit_sort = [&](int64_t capacity, int64_t longest = -1) {
             sorted = torch::empty({capacity}, i32);
             keys = torch::empty({capacity}, i32.dtype(torch::kInt64));
             if (capacity > 0)
@@ -391,9 +412,10 @@ struct Preprocess : public torch::autograd::Function<Preprocess> {
                         return gs_tile_emit_sort_cut(bin_rec, N, ntx, nty, (float)mh_dist, (int)row0, (int)row1, ranges_buf,
                                                      tile_counts, cut_ws, (uint64_t*)keys.data_ptr<int64_t>(), capacity,
                                                      sorted.data_ptr<int32_t>(), stream);
-                    return gs_tile_emit_sort(uv, xyz_cam, conic, N, count, nullptr, nullptr, ntx, nty, (float)mh_dist, (int)row0,
-                                             (int)row1, ranges_buf, tile_counts, (uint64_t*)keys.data_ptr<int64_t>(), capacity,
-                                             sorted.data_ptr<int32_t>(), sort_prefix, stream);
+                    return gs_tile_emit_sort_bounded(uv, xyz_cam, conic, N, count, nullptr, nullptr, ntx, nty, (float)mh_dist,
+                                                     (int)row0, (int)row1, ranges_buf, tile_counts,
+                                                     (uint64_t*)keys.data_ptr<int64_t>(), capacity,
+                                                     sorted.data_ptr<int32_t>(), sort_prefix, longest, stream);
                 });
         };
 
@@ -405,19 +427,35 @@ struct Preprocess : public torch::autograd::Function<Preprocess> {
         RenderOut out;
         bool rendered = false;
         int64_t capacity = 0;
+        // Complete-list frames also guess the LONGEST list (from the shape's last frame): none beyond 4096 entries ->
+        // the sort's walk-grid kernel for those is not enqueued, none beyond the prefix -> neither is the render's
+        // repair phase (a sparse frame -- workload B -- otherwise pays ~5 us each for three kernels that find nothing
+        // to do).  The count pass's scan reports the true value with the frame's counts; a guess that was too small
+        // is made good below: the repair enqueued late, or emit + sort + render repeated.
+        int64_t longest_guess = -1;
+        int phases = GS_PREFIX_RENDER | GS_PREFIX_REPAIR;
         if (speculative) {
             capacity = guess;
             cref.overflow_capacity = guess_overflow;
-            emit_sort(capacity);
+            if (!cut && sort_prefix) {
+                std::lock_guard<std::mutex> lock(g_mutex);
+                auto il = g_longest_list.find(key);
+                if (il != g_longest_list.end()) longest_guess = il->second;
+            }
+            emit_sort(capacity, longest_guess);
             if (g_early_render && sort_prefix && (cut || capacity > sort_prefix)) {
+                if (longest_guess >= 0 && longest_guess <= sort_prefix) phases = GS_PREFIX_RENDER;
                 out = render_forward(packed, rgbr, ranges_buf, sorted, keys, bg, (int)W, (int)H, (int)row0, (int)row1, whole,
-                                     sort_prefix, stream, shape, false, 0, cut ? &cref : nullptr);
+                                     sort_prefix, stream, shape, false, 0, cut ? &cref : nullptr, phases);
                 rendered = true;
             }
         }
         hip_ok(hipEventSynchronize(ready));
         const int64_t S = host[0], V = host[1], S_complete = cut ? host[2] : host[0];
-        const bool miss = speculative && (S > capacity || (cut && S_complete > cref.overflow_capacity));
+        const int64_t longest = cut ? -1 : host[2];
+        // (a list beyond 4096 entries whose sort kernel was not enqueued: the lists are not what the render needs)
+        const bool unsorted_long = speculative && longest_guess >= 0 && longest_guess <= 4096 && longest > 4096;
+        const bool miss = speculative && (S > capacity || (cut && S_complete > cref.overflow_capacity) || unsorted_long);
         {
             std::lock_guard<std::mutex> lock(g_mutex);
             g_counters.frames++;
@@ -426,6 +464,7 @@ struct Preprocess : public torch::autograd::Function<Preprocess> {
             g_counters.s_min = g_counters.s_min < 0 ? S_complete : std::min(g_counters.s_min, S_complete);
             g_counters.s_max = std::max(g_counters.s_max, S_complete);
             g_counters.misses += miss;
+            g_counters.long_list_misses += unsorted_long;
             int64_t& hint = g_capacity[key];
             hint = std::max(hint, S + S / 4 + 4096);
             if (cut) {
@@ -433,16 +472,30 @@ struct Preprocess : public torch::autograd::Function<Preprocess> {
                 ho = std::max(ho, S_complete + S_complete / 4 + 4096);
             }
             g_complete_count[shape] = S_complete;
+            if (!cut && sort_prefix) g_longest_list[key] = longest;
         }
         if (!speculative || miss) {
             cref.overflow_capacity = S_complete;
-            emit_sort(S);
+            emit_sort(S, longest);
             rendered = false;
         }
         Tensor sorted_g = sorted.narrow(0, 0, S), keys_g = keys.narrow(0, 0, S);
-        if (!rendered)
+        if (!rendered) {
+            phases = (!cut && sort_prefix && longest >= 0 && longest <= sort_prefix) ? GS_PREFIX_RENDER
+                                                                                    : (GS_PREFIX_RENDER | GS_PREFIX_REPAIR);
             out = render_forward(packed, rgbr, ranges_buf, sorted_g, keys_g, bg, (int)W, (int)H, (int)row0, (int)row1, whole,
-                                 sort_prefix, stream, shape, true, 0, cut ? &cref : nullptr);
+                                 sort_prefix, stream, shape, true, 0, cut ? &cref : nullptr, phases);
+        } else if (!cut && phases == GS_PREFIX_RENDER && longest > sort_prefix && out.prefix_flags.defined()) {
+            // the early render went without its repair phase and a list IS longer than the prefix: repair now
+            render_prefix_repair(out, packed, rgbr, ranges_buf, sorted, keys, bg, (int)W, (int)H, (int)row0, (int)row1, stream);
+            phases = GS_PREFIX_RENDER | GS_PREFIX_REPAIR;
+            std::lock_guard<std::mutex> lock(g_mutex);
+            g_counters.late_repairs++;
+        }
+        if (phases == GS_PREFIX_RENDER && out.prefix_flags.defined()) {
+            std::lock_guard<std::mutex> lock(g_mutex);
+            g_counters.render_only++;
+        }
 
         Tensor uv_t, conic_t;
         if (cut) {
@@ -1183,6 +1236,9 @@ py::dict counters() {
     d["slab_copies"] = c.slab_copies;   // backward calls that could not read the render node's slab in place
     d["depth_cut_frames"] = c.cut_frames;
     d["depth_cut_backoffs"] = c.cut_backoffs;
+    d["prefix_frames_without_repair_launches"] = c.render_only;   // no list beyond the prefix: render phase alone
+    d["prefix_late_repairs"] = c.late_repairs;                    // guessed so, wrongly: repair enqueued after the host read
+    d["long_list_misses"] = c.long_list_misses;                   // guessed "no list beyond 4096", wrongly: frame repeated
     d["prefix_repaired_tiles"] = repaired;
     d["prefix_frames_logged"] = (int64_t)log.size();
     return d;
@@ -1267,6 +1323,12 @@ void debug_scale_capacity_hints(double factor) {
     for (auto& kv : g_overflow_capacity) kv.second = (int64_t)(kv.second * factor);
 }
 
+// (tests) overwrite the longest-list guesses of every shape seen so far
+void debug_set_longest_list_hints(int64_t value) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    for (auto& kv : g_longest_list) kv.second = value;
+}
+
 void set_segments(int mode) { g_segments = mode; }
 void set_depth_cut(int mode, int64_t min_mean_list) {
     g_depth_cut = mode;
@@ -1296,6 +1358,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("set_modes", &set_modes, py::arg("sort_prefix"), py::arg("early_render"));
     m.def("set_segments", &set_segments, py::arg("mode"));
     m.def("debug_scale_capacity_hints", &debug_scale_capacity_hints, py::arg("factor"));
+    m.def("debug_set_longest_list_hints", &debug_set_longest_list_hints, py::arg("value"));
     m.def("set_depth_cut", &set_depth_cut, py::arg("mode"), py::arg("min_mean_list") = 0);
     m.def("set_band_compact", &set_band_compact, py::arg("on"));
     m.def("last_tile_flags", &last_tile_flags, py::arg("clear") = false);

@@ -1845,7 +1845,18 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
                            int32_t* tile_flags, int32_t* num_splats_per_pixel,
                            void* final_weight_per_pixel, void* image, int32_t* tile_cost, void* segment_state,
                            void* stream) {
+    return gs_render_tiles_prefix_phased(packed, rgb, tile_ranges, sorted_gaussians, keys, S, background_rgb, W, H, tile_row0,
+                                         tile_row1, tile_flags, num_splats_per_pixel, final_weight_per_pixel, image,
+                                         tile_cost, segment_state, GS_PREFIX_RENDER | GS_PREFIX_REPAIR, stream);
+}
+
+int gs_render_tiles_prefix_phased(const void* packed, const void* rgb, const int32_t* tile_ranges,
+                                  int32_t* sorted_gaussians, const uint64_t* keys, int64_t S,
+                                  const void* background_rgb, int W, int H, int tile_row0, int tile_row1,
+                                  int32_t* tile_flags, int32_t* num_splats_per_pixel, void* final_weight_per_pixel,
+                                  void* image, int32_t* tile_cost, void* segment_state, int phases, void* stream) {
     GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
+    GS_REQUIRE(phases >= 1 && phases <= 3, "phases: GS_PREFIX_RENDER, GS_PREFIX_REPAIR or both");
     GS_REQUIRE(tile_flags != nullptr, "tile_flags must not be null");
     GS_REQUIRE(segment_state == nullptr || ((uintptr_t)segment_state & 15) == 0, "segment_state must be 16-byte aligned");
     if (int e = check_rows(H, tile_row0, tile_row1)) return e;
@@ -1857,18 +1868,20 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
     const int t0 = tile_row0 * ntx;
     const SegState seg = seg_state_of(segment_state, W, H, tile_row0, tile_row1);
     // 1. provisional pass over the ordered prefixes; raises the flags
-    if (segment_state)
-        k_render_fwd_ck<<<grid, RB, 0, s>>>(
-            (const float*)packed, (const float*)rgb, tile_ranges, sorted_gaussians, (const float*)background_rgb, W, H,
-            ntx, t0, nt, num_splats_per_pixel, (float*)final_weight_per_pixel, (float*)image, GS_SORT_PREFIX,
-            tile_flags, S, tile_cost, seg);
-    else
-        k_render_fwd<float, 1><<<grid, RB, GS_FWD_LDS_PAD, s>>>(
-            (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
-            (const float*)background_rgb, W, H, ntx, t0, nt, num_splats_per_pixel,
-            (float*)final_weight_per_pixel, (float*)image, GS_SORT_PREFIX, tile_flags, S, tile_cost, nullptr, nullptr,
-            nullptr, nullptr);
-    if (S > GS_SORT_PREFIX) {
+    if (phases & GS_PREFIX_RENDER) {
+        if (segment_state)
+            k_render_fwd_ck<<<grid, RB, 0, s>>>(
+                (const float*)packed, (const float*)rgb, tile_ranges, sorted_gaussians, (const float*)background_rgb, W, H,
+                ntx, t0, nt, num_splats_per_pixel, (float*)final_weight_per_pixel, (float*)image, GS_SORT_PREFIX,
+                tile_flags, S, tile_cost, seg);
+        else
+            k_render_fwd<float, 1><<<grid, RB, GS_FWD_LDS_PAD, s>>>(
+                (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
+                (const float*)background_rgb, W, H, ntx, t0, nt, num_splats_per_pixel,
+                (float*)final_weight_per_pixel, (float*)image, GS_SORT_PREFIX, tile_flags, S, tile_cost, nullptr, nullptr,
+                nullptr, nullptr);
+    }
+    if ((phases & GS_PREFIX_REPAIR) && S > GS_SORT_PREFIX) {
         // 2. + 3. flagged tiles: full sort, render again (no-ops on a dense scene)
         sort_flagged_tiles(tile_ranges, keys, sorted_gaussians, t0, nt, S, tile_flags, s);
         auto again = segment_state ? k_render_fwd_flagged<true> : k_render_fwd_flagged<false>;

@@ -148,6 +148,8 @@ def counters():
         nat = _native_mod.counters()
         if nat["frames"]:
             out["depth_cut_backoffs"] = nat.get("depth_cut_backoffs", 0)
+            for k in ("prefix_frames_without_repair_launches", "prefix_late_repairs", "long_list_misses"):
+                out[k] = nat.get(k, 0)
             for k in ("frames", "speculative_frames", "capacity_misses", "prefix_repaired_tiles", "prefix_frames_logged",
                       "depth_cut_frames"):
                 out[k] += nat[k]

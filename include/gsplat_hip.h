@@ -99,8 +99,11 @@ int gs_precompute_rgb_from_sh_backward(const void* xyz, const void* matrix, cons
  *
  * uvs[V,2], xyz_camera_frame[V,3], conic[V,3]; n_tiles = n_tiles_x*n_tiles_y.
  * host_mirror (gs_tile_count, gs_tile_count_cut; may be NULL): a device-accessible pointer to 3 ints of PINNED HOST
- *   memory that receives (instance count, visible count, complete instance count) when the scan finishes -- the
- *   frame's host read without a copy kernel in the stream (record an event behind the call and wait for it).
+ *   memory that receives, when the scan finishes, (instance count, visible count, x) with x = the length of the
+ *   LONGEST tile list of the rows (gs_tile_count) / the complete instance count (gs_tile_count_cut) -- the frame's
+ *   host read without a copy kernel in the stream (record an event behind the call and wait for it).  A caller that
+ *   knows the longest list can tell gs_tile_emit_sort_bounded and gs_render_tiles_prefix_phased what they need
+ *   not launch.
  * visible_count: NULL, or a device pointer to the number of valid rows when the inputs are
  *   capacity-V buffers whose fill level only the device knows (gs_preprocess_forward); rows
  *   beyond it are ignored and tile_ranges then has T+2 entries, [T+1] = *visible_count, so that
@@ -135,6 +138,15 @@ int gs_tile_emit_sort(const void* uvs, const void* xyz_camera_frame, const void*
                       int tile_row0, int tile_row1, const int32_t* tile_ranges, int32_t* workspace,
                       uint64_t* keys, int64_t S, int32_t* sorted_gaussians /*[S]*/, int sort_prefix,
                       void* stream);
+/* gs_tile_emit_sort with a bound on the list lengths (ABI 6): longest_list >= 0 promises that no tile of the rows has
+ * more entries, and the sort launches that only serve longer lists are not enqueued (a sparse frame otherwise pays
+ * ~5 us for a kernel that finds nothing to do); < 0 = no promise.  The bound may be a GUESS only if the caller checks
+ * it against the count pass's result afterwards and repeats the call when it was too small. */
+int gs_tile_emit_sort_bounded(const void* uvs, const void* xyz_camera_frame, const void* conic, int V,
+                              const int32_t* visible_count, const int32_t* subset, const int32_t* subset_count,
+                              int n_tiles_x, int n_tiles_y, float mh_dist, int tile_row0, int tile_row1,
+                              const int32_t* tile_ranges, int32_t* workspace, uint64_t* keys, int64_t S,
+                              int32_t* sorted_gaussians /*[S]*/, int sort_prefix, int64_t longest_list, void* stream);
 /* Full sort of the tiles t in the row band with tile_flags[t] != 0 (keys as left by
  * gs_tile_emit_sort(..., GS_SORT_PREFIX, ...), same S). */
 int gs_tile_sort_flagged(const int32_t* tile_ranges, const uint64_t* keys, int64_t S,
@@ -284,6 +296,17 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
                            int32_t* tile_flags, int32_t* num_splats_per_pixel,
                            void* final_weight_per_pixel, void* image, int32_t* tile_cost, void* segment_state,
                            void* stream);
+/* The same in two separately callable phases (ABI 6): GS_PREFIX_RENDER = step (1), GS_PREFIX_REPAIR = steps (2) + (3)
+ * on the flags step (1) left, both = gs_render_tiles_prefix.  A frame none of whose lists exceeds GS_SORT_PREFIX
+ * cannot raise a flag: a caller that knows (the count pass's longest list) enqueues the render alone, one that only
+ * guessed enqueues the repair when the count says otherwise -- later in the stream, the same result. */
+#define GS_PREFIX_RENDER 1
+#define GS_PREFIX_REPAIR 2
+int gs_render_tiles_prefix_phased(const void* packed, const void* rgb, const int32_t* tile_ranges,
+                                  int32_t* sorted_gaussians, const uint64_t* keys, int64_t S,
+                                  const void* background_rgb, int W, int H, int tile_row0, int tile_row1,
+                                  int32_t* tile_flags, int32_t* num_splats_per_pixel, void* final_weight_per_pixel,
+                                  void* image, int32_t* tile_cost, void* segment_state, int phases, void* stream);
 /* Depth segments of the fused backward (fp32, n_sh == 1; ABI 5).  segment_state (may be NULL): a 16-byte aligned
  * device workspace of gs_render_segment_workspace_bytes(W, H, tile_row0, tile_row1) bytes (ABI 6: sized for the
  * tile rows the three calls are given -- 32 KB per tile of the band, not of the grid) that gs_render_tiles_packed /

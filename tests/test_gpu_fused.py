@@ -477,6 +477,71 @@ def test_native_orchestration_equals_python_orchestration(deg, bgval):
             assert scaled_err(p1[k], p0[k]) < 1e-5, k
 
 
+@pytest.mark.parametrize("case,N", [("short", 20_000), ("medium", 90_000), ("long", 400_000)])
+def test_native_frame_guesses_the_longest_list(case, N):
+    """Complete-list frames of the native orchestration guess the frame's LONGEST tile list from the shape's last
+    frame: "none beyond the prefix" leaves the render's repair phase out, "none beyond 4096" the sort's walk-grid
+    kernel (workload B otherwise pays for three launches that find nothing to do).  The count pass reports the true
+    value with the frame's counts; every wrong guess must be made good -- the repair enqueued late, or the frame's
+    emit + sort + render repeated -- and the results stay those of the Python orchestration, which guesses nothing."""
+    nat = fused.native()
+    if nat is None:
+        pytest.skip("native frame module not built")
+    W, H = 256, 192
+    g, cam, T = make_scene(N, W, H, 0, seed=9, device=DEV)
+    if case != "short":
+        g.opacity.fill_(-5.0)   # faint: pixels composite thousands of entries, prefix-sorted tiles ARE flagged
+    bg = torch.full((3,), 0.25, device=DEV)
+    gi = make_grad_image(W, H, seed=3, device=DEV)
+    for k in PARAMS:
+        if getattr(g, k) is not None:
+            getattr(g, k).requires_grad_(True)
+
+    def frame(native):
+        prev = fused.NATIVE, fused.DEPTH_CUT
+        fused.NATIVE, fused.DEPTH_CUT = native, False
+        try:
+            for k in PARAMS:
+                if getattr(g, k) is not None:
+                    getattr(g, k).grad = None
+            img, mask, uv = fused.rasterize(g, T, cam, 0.3, 500.0, 100, 3.0, True, bg)
+            img.backward(gi)
+            return img.detach().clone(), {k: getattr(g, k).grad.clone() for k in PARAMS if getattr(g, k) is not None}
+        finally:
+            fused.NATIVE, fused.DEPTH_CUT = prev
+
+    def same(a, b):
+        assert torch.equal(a[0], b[0])
+        for k in b[1]:
+            assert scaled_err(a[1][k], b[1][k]) < 1e-5, k
+
+    # the longest list of this scene, from the Python stages
+    f = fused.preprocess_forward(g.xyz.detach(), g.quaternion.detach(), g.scale.detach(), g.opacity.detach(), g.rgb.detach(),
+                                 None, T, cam.K, W, H, 0.3, 500.0, 100, 3.0, None, 0)
+    longest = int((f.ranges[1:] - f.ranges[:-1]).max())
+    lo, hi = {"short": (1, 1024), "medium": (1025, 4096), "long": (4097, 10 ** 9)}[case]
+    assert lo <= longest <= hi, (case, longest)
+    ref = frame(False)
+    fused.reset_counters()
+    same(frame(True), ref)                 # first frame of the shape: nothing guessed
+    same(frame(True), ref)                 # guess = the truth
+    c0 = fused.counters()
+    for hint in (100, 2000, 10 ** 6, 100):
+        nat.debug_set_longest_list_hints(hint)
+        same(frame(True), ref)
+    c = fused.counters()
+    report(f"longest_list_guess[{case}]", longest=longest,
+           **{k: c.get(k, -1) for k in ("prefix_frames_without_repair_launches", "prefix_late_repairs", "long_list_misses",
+                                        "capacity_misses", "speculative_frames")})
+    if case == "short":
+        assert c0["prefix_frames_without_repair_launches"] >= 1 and c["prefix_late_repairs"] == 0 and c["long_list_misses"] == 0, c
+    elif case == "medium":
+        assert c0["prefix_frames_without_repair_launches"] == 0, c0
+        assert c["prefix_late_repairs"] >= 2 and c["long_list_misses"] == 0, c   # the two frames that guessed 100
+    else:
+        assert c["long_list_misses"] >= 3, c   # guesses 100, 2000, 100 of a frame with a list beyond 4096
+
+
 def test_fused_rasterize_rejects_bad_inputs():
     """the fused path hands raw pointers to the C ABI: wrong dtype / device / shape must raise like the
     reference's TORCH_CHECKs (src/checks.cuh:5-14) instead of reading garbage"""
