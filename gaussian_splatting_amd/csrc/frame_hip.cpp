@@ -233,6 +233,7 @@ struct RenderOut {
     Tensor buf, image, fw, nsp, seg;   // seg: state for the depth-segmented backward (empty: not segmented)
     Tensor cut_flags, overflow_sorted;   // depth-cut frames: flagged tiles and their complete lists (else undefined)
     Tensor prefix_flags;                 // prefix-sorted frames: the provisional render's tile flags (else undefined)
+    int32_t* tile_cost = nullptr;        // per-tile render cost int32[T] inside buf (the backward's launch-order key)
 };
 // what gs_render_tiles_cut needs from the frame's binning
 struct CutRef {
@@ -265,6 +266,7 @@ RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* 
     r.fw = r.buf.narrow(0, 3 * PI, P).view({H, W});
     r.nsp = r.buf.narrow(0, 3 * PI + P, P).view(torch::kInt32).view({H, W});
     int32_t* tile_cost = reinterpret_cast<int32_t*>(r.buf.data_ptr<float>()) + 3 * PI + 2 * P;
+    r.tile_cost = tile_cost;
     if (cut != nullptr) {
         // depth-cut lists: kept prefixes, then (on the device, only if a tile was flagged) the complete lists of the
         // flagged tiles from the overflow buffers
@@ -318,14 +320,11 @@ RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* 
 // prefix" turned out wrong): full sort + second render of the flagged tiles, on the buffers of that render
 void render_prefix_repair(RenderOut& r, const float* packed, const float* rgbr, const int32_t* ranges, Tensor& sorted,
                           Tensor& keys, const Tensor& bg, int W, int H, int row0, int row1, void* stream) {
-    const int64_t P = (int64_t)W * H;
-    const int64_t PI = r.image.size(0) * (int64_t)W;
-    int32_t* tile_cost = reinterpret_cast<int32_t*>(r.buf.data_ptr<float>()) + 3 * PI + 2 * P;
     timed("gs_render_tiles_prefix", stream, [&] {
         return gs_render_tiles_prefix_phased(packed, rgbr, ranges, sorted.data_ptr<int32_t>(),
                                              (const uint64_t*)keys.data_ptr<int64_t>(), sorted.size(0), bg.data_ptr(), W, H, row0,
                                              row1, r.prefix_flags.data_ptr<int32_t>(), r.nsp.data_ptr<int32_t>(),
-                                             r.fw.data_ptr(), r.image.data_ptr(), tile_cost,
+                                             r.fw.data_ptr(), r.image.data_ptr(), r.tile_cost,
                                              r.seg.numel() > 0 ? r.seg.data_ptr() : nullptr, GS_PREFIX_REPAIR, stream);
     });
 }
