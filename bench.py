@@ -256,24 +256,39 @@ def camera_poses(n, seed, device, moving):
     return out
 
 
+HBM_ACHIEVABLE_GBS = 6290.0   # MI355X_MICROARCH.md: float4 grid-stride copy, read + write
+
+
 def measure_copy_bandwidth(dev, mib=1024, reps=5):
-    """device-to-device copy of a buffer far beyond the 256 MiB Infinity Cache: bytes read + written per
-    second, the practical HBM roof next to the 8 TB/s nominal"""
+    """A hand-written float4 stream copy (csrc/train_ops.hip: gs_stream_copy, non-temporal) of a buffer far beyond
+    the 256 MiB Infinity Cache: bytes read + written per second on THIS box -- the practical HBM roof next to the
+    8 TB/s nominal and the guide's 6.29 TB/s achievable.  (Until round 4 this timed torch's copy_(), which measures the
+    library's copy kernel: 4.7-5.2 TB/s.)  Best of a few grid sizes."""
+    import ctypes
+    from gaussian_splatting_amd import _hip
     n = mib * (1 << 20) // 4
     a = torch.empty(n, dtype=torch.float32, device=dev).fill_(1.0)
     b = torch.empty_like(a)
-    b.copy_(a)
-    torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    ev[0].record()
-    for _ in range(reps):
-        b.copy_(a)
-    ev[1].record()
-    torch.cuda.synchronize()
-    ms = ev[0].elapsed_time(ev[1]) / reps
+    stream = _hip.current_stream()
+    best = 0.0
+    for blocks in (2048, 4096, 8192, 16384):
+        def copy():
+            _hip.call("gs_stream_copy", ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(a.data_ptr()),
+                      ctypes.c_size_t(n * 4), blocks, stream)
+        copy()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(reps):
+            copy()
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms = ev[0].elapsed_time(ev[1]) / reps
+        best = max(best, 2 * n * 4 / (ms * 1e-3) / 1e9)
+    assert bool((b[:1024] == 1.0).all())
     del a, b
     torch.cuda.empty_cache()
-    return 2 * n * 4 / (ms * 1e-3) / 1e9
+    return best
 
 
 def median(xs):
@@ -548,6 +563,9 @@ def main():
             "frame_algorithmic_bytes": int(alg["frame"]),
             "frame_frac": round(alg["frame"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             "hbm_copy_gbs_measured": round(copy_gbs, 1) if copy_gbs else None,
+            "hbm_copy_kernel": "float4 grid-stride stream copy, non-temporal (gs_stream_copy), 1 GiB, read + written bytes",
+            "hbm_achievable_gbs_guide": HBM_ACHIEVABLE_GBS,
+            "frame_frac_of_achievable": round(alg["frame"] / (ms_per_step * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS, 5),
             "frame_frac_of_measured_copy": (round(alg["frame"] / (ms_per_step * 1e-3) / 1e9 / copy_gbs, 5)
                                             if copy_gbs else None),
             "pixel_splat_evaluations_per_frame": int(E),
@@ -777,7 +795,16 @@ def parity_check(workload, fused_mod, dev, n_rows=None):
     ntx = (W + 15) // 16
     n_tiles = ntx * (nty if rows is None else rows[1] - rows[0])
     segmented = bool(fused_mod.want_segments(int(sorted_g.numel()), n_tiles))
-    return {"grad_max_rel_err_floor_1e-6": worst["floor_1e-6"],
+    return {"headline": {"grad_max_rel_err_floor_1e-6": worst["floor_1e-6"],
+                         "fp32_reorder_spread_floor_1e-6": worst["reorder_1e-6"],
+                         "ratio_kernel_to_pure_fp32_reorder_spread": (worst["floor_1e-6"] / worst["reorder_1e-6"]
+                                                                      if worst["reorder_1e-6"] > 0 else None),
+                         "grad_max_rel_err_floor_1e-2": worst["floor_1e-2"], "target": 1e-4,
+                         "read_as": "the 1e-6-floor figure is never to be read alone: the second number is what the "
+                                    "oracle's OWN bit-identical fp32 terms give when summed in two fixed orders, i.e. the "
+                                    "floor of that criterion for any fp32 implementation; the 1 %-floor figure is the "
+                                    "one asserted against the 1e-4 target"},
+            "grad_max_rel_err_floor_1e-6": worst["floor_1e-6"],
             "fp32_reorder_spread_floor_1e-6": worst["reorder_1e-6"],
             "grad_max_rel_err": worst["floor_1e-2"], "fp32_reorder_spread_floor_1e-2": worst["reorder_1e-2"],
             "grad_max_err_over_leaf_term_magnitudes": worst["noise_normalised"],
@@ -944,8 +971,28 @@ def time_train_loop(iters, dev, n_start=140_000, n_cameras=24, W=1297, H=840):
     with torch.no_grad():
         targets = [fused.rasterize(truth, T, cam, use_sh_precompute=True, background_rgb=bg0, **DEFAULTS)[0].clamp(0, 1)
                    for T in poses]
+    # Initialisation as the reference's DataLoader.create_gaussians does it from the SfM point cloud
+    # (dataloader.py:43-67, utils.py:19-37): points ON the scene with their colours -- here a subsample of the hidden
+    # scene's centres, perturbed by ~1 px of reprojection noise, colours perturbed --, opacity inverse_sigmoid(0.2),
+    # identity rotation, isotropic scale = log(0.8 x min(mean distance to the 3 nearest points (itself included),
+    # 0.1)).  (A first version started from an unrelated random scene: the training views were fitted -- 14 -> 33 dB
+    # -- and the held-out views were not, 14.5 -> 16.6 dB: what the reference would do without SfM points.)
+    import numpy as np
+    from scipy.spatial import cKDTree
+    from gaussian_splatting_amd.splat_py.structs import Gaussians
+    gen = torch.Generator().manual_seed(5)
+    pick_idx = torch.randperm(truth.xyz.shape[0], generator=gen)[:n_start]
+    pts = truth.xyz[pick_idx.to(dev)].cpu().double()
+    pts = pts + 1e-3 * pts[:, 2:3] * torch.randn(n_start, 3, generator=gen, dtype=torch.float64)
+    cols = truth.rgb[pick_idx.to(dev)].cpu() + 0.1 * torch.randn(n_start, 3, generator=gen)
+    dist, _ = cKDTree(pts.numpy()).query(pts.numpy(), k=3, workers=-1)
+    scale0 = torch.from_numpy(np.log(0.8 * np.minimum(dist.mean(axis=1), 0.1))).float()[:, None].expand(n_start, 3)
+    quat0 = torch.zeros(n_start, 4)
+    quat0[:, 0] = 1.0
+    opa0 = torch.full((n_start, 1), float(np.log(0.2 / 0.8)))
+    g = Gaussians(pts.float().to(dev).contiguous(), cols.to(dev).contiguous(), opa0.to(dev), scale0.contiguous().to(dev),
+                  quat0.to(dev), None)
     del truth
-    g, _, _ = make_scene(n_start, W, H, 0, seed=5, device=dev)
     for k in names:
         getattr(g, k).requires_grad_(True)
     opt = Adam([{"params": getattr(g, k), "lr": lrs[k]} for k in names])
@@ -954,8 +1001,34 @@ def time_train_loop(iters, dev, n_start=140_000, n_cameras=24, W=1297, H=840):
     ctrl = DensityController(g, opt, cfg)
     fused.reset_counters()
     pick = torch.Generator().manual_seed(99)
-    order = torch.randint(0, n_cameras, (iters,), generator=pick).tolist()
+    # held-out views (trainer.py:297-346 evaluates PSNR / SSIM on a test split that is never trained on): every
+    # sixth pose; the loop draws its views from the other 20
+    test_cams = list(range(5, n_cameras, 6))
+    train_cams = [c for c in range(n_cameras) if c not in test_cams]
+    order = [train_cams[j] for j in torch.randint(0, len(train_cams), (iters,), generator=pick).tolist()]
     n_trace, adc_ms, adc_steps, time_trace = [], 0.0, 0, []
+    quality, eval_s = [], 0.0
+
+    def evaluate(i, tag):
+        """compute_test_psnr (trainer.py:297-346): render with a black background, clip to [0, 1], PSNR from the mse
+        and SSIM per view -- on the held-out views and, for comparison, on the training views; the loss is the
+        training loss (trainer.py:363-374) of the same images.  Its wall time is taken out of the loop's."""
+        nonlocal eval_s
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        row = {"iteration": i, "at": tag, "n_gaussians": int(g.xyz.shape[0])}
+        with torch.no_grad():
+            for name, cams in (("train", train_cams), ("held_out", test_cams)):
+                terms = torch.stack([ssim_l1_loss(fused.rasterize(g, poses[c], cam, use_sh_precompute=True,
+                                                                  background_rgb=bg0, **DEFAULTS)[0].clamp(0, 1),
+                                                  targets[c], 0.2, return_terms=True)[1] for c in cams]).double()
+                psnr = -10.0 * torch.log10(terms[:, 3])
+                row[name] = {"psnr_db": round(float(psnr.mean()), 3), "ssim": round(float(terms[:, 2].mean()), 5),
+                             "l1": round(float(terms[:, 1].mean()), 6), "loss": round(float(terms[:, 0].mean()), 6)}
+        quality.append(row)
+        torch.cuda.synchronize()
+        eval_s += time.perf_counter() - te
+
     torch.cuda.synchronize()
     t0 = t_seg = time.perf_counter()
     from gaussian_splatting_amd import _hip
@@ -972,7 +1045,10 @@ def time_train_loop(iters, dev, n_start=140_000, n_cameras=24, W=1297, H=840):
             torch.cuda.synchronize()
             now = time.perf_counter()
             time_trace.append([i, round((now - t_seg) / 500 * 1e3, 3), int(g.xyz.shape[0])])
-            t_seg = now
+        if i % 1000 == 0:
+            evaluate(i, "mark")
+        if i and i % 500 == 0:
+            t_seg = time.perf_counter()
         opt.zero_grad(set_to_none=True)
         bg = bg0
         if i < 6600:   # use_background / use_background_end (config.py:98-100, trainer.py:411-417)
@@ -992,12 +1068,41 @@ def time_train_loop(iters, dev, n_start=140_000, n_cameras=24, W=1297, H=840):
             adc_steps += 1
             n_trace.append([i, info.get("n_after", g.xyz.shape[0])])
         if 1050 < i < 6500 and i % 3001 == 0:
+            evaluate(i, "before opacity reset")
             ctrl.reset_opacity()
+            evaluate(i, "after opacity reset")
         if i > 0 and i % 1000 == 0:
             ctrl.add_sh_band()
     torch.cuda.synchronize()
-    total = time.perf_counter() - t0
+    total = time.perf_counter() - t0 - eval_s
+    evaluate(iters, "end")
+    # convergence: every 1000-iteration mark improves on the mark before it, except across the opacity reset
+    # (iteration 3001 pulls every opacity down to 0.01: trainer.py:419-421), where the marks on either side of it are
+    # compared with the evaluation right after the reset instead
+    marks = [q for q in quality if q["at"] in ("mark", "end")]
+    resets = [q["iteration"] for q in quality if q["at"] == "after opacity reset"]
+    steps = []
+    for a, b in zip(marks[:-1], marks[1:]):
+        crosses = any(a["iteration"] <= r < b["iteration"] for r in resets)
+        if crosses:
+            a = next(q for q in quality if q["at"] == "after opacity reset" and a["iteration"] <= q["iteration"] < b["iteration"])
+        steps.append({"from": a["iteration"], "to": b["iteration"], "from_eval": a["at"],
+                      "train_psnr_gain_db": round(b["train"]["psnr_db"] - a["train"]["psnr_db"], 3),
+                      "held_out_psnr_gain_db": round(b["held_out"]["psnr_db"] - a["held_out"]["psnr_db"], 3),
+                      "train_loss_drop": round(a["train"]["loss"] - b["train"]["loss"], 6)})
+    convergence = {
+        "train_psnr_db_start_end": [quality[0]["train"]["psnr_db"], quality[-1]["train"]["psnr_db"]],
+        "held_out_psnr_db_start_end": [quality[0]["held_out"]["psnr_db"], quality[-1]["held_out"]["psnr_db"]],
+        "steps": steps,
+        "monotone_train_loss": all(st["train_loss_drop"] > 0 for st in steps),
+        "monotone_train_psnr": all(st["train_psnr_gain_db"] > 0 for st in steps),
+        "monotone_held_out_psnr": all(st["held_out_psnr_gain_db"] > 0 for st in steps),
+        "held_out_views": test_cams, "training_views": len(train_cams),
+        "note": "targets are renders of a hidden 400 k-Gaussian scene (no dataset here): the PSNR says that 7 000 "
+                "iterations of this build's forward / backward / Adam / density control CONVERGE on views they never "
+                "saw; it is not comparable with the reference's Garden table"}
     return {"iterations": iters, "wall_s": round(total, 3), "ms_per_iteration": round(total / iters * 1e3, 4),
+            "evaluation_s_excluded": round(eval_s, 3), "quality_trace": quality, "convergence": convergence,
             "n_start": n_start, "n_end": int(g.xyz.shape[0]), "sh_coefficients_end": 0 if g.sh is None else int(g.sh.shape[2]),
             "density_control_steps": adc_steps, "density_control_ms_total": round(adc_ms, 2),
             "density_control_ms_mean": round(adc_ms / max(adc_steps, 1), 3), "n_gaussians_trace": n_trace[::6],
@@ -1005,7 +1110,8 @@ def time_train_loop(iters, dev, n_start=140_000, n_cameras=24, W=1297, H=840):
             "entry_ms_per_iteration_at": entry_probe,
             "image": f"{W}x{H}", "cameras": n_cameras,
             "note": "synthetic targets (the dataset is not available): wall time of the reference's 7k training loop "
-                    "structure, not its PSNR.  Published anchor (other hardware, real data): Garden 1/4x 7k in 3:05 = "
+                    "structure; quality_trace / convergence hold loss, PSNR and SSIM on training and held-out views "
+                    "at every 1000th iteration and around the opacity reset -- of THIS synthetic problem, not the Garden table.  Published anchor (other hardware, real data): Garden 1/4x 7k in 3:05 = "
                     "185 s to 1.52 M Gaussians on an RTX 4090 (BASELINE.md, README.md:26)"}
 
 

@@ -49,7 +49,7 @@ EXPORTS = [
     "gs_render_segment_workspace_bytes",
     "gs_set_backward_mode", "gs_get_backward_mode", "gs_render_depth", "gs_halo_workspace_ints", "gs_halo_plan", "gs_halo_gather_sum",
     "gs_band_project", "gs_halo_plan_masked", "gs_preprocess_forward_list",
-    "gs_adam_step", "gs_accumulate_grad_stats", "gs_ssim_l1_workspace_bytes", "gs_ssim_l1_loss",
+    "gs_adam_step", "gs_accumulate_grad_stats", "gs_stream_copy", "gs_ssim_l1_workspace_bytes", "gs_ssim_l1_loss",
     "gs_densify_move",
     "gs_cut_workspace_ints", "gs_cut_sample_stride", "gs_cut_supported", "gs_preprocess_forward_cut", "gs_tile_count_cut",
     "gs_tile_emit_sort_cut", "gs_cut_debug_views", "gs_render_tiles_cut",

@@ -34,6 +34,8 @@
 #include "tile_math.h"
 #include "tile_sort.h"
 
+#include <atomic>
+
 namespace gs {
 
 constexpr int BIN_BLOCK = 256;
@@ -1327,16 +1329,23 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_flagged(const int* __r
 }
 
 
+// hipFuncSetAttribute applies to the CURRENT device: once per device, not once per process (a second device in the
+// same process otherwise never gets the larger dynamic-LDS limit; round-4 advisor finding)
+static bool first_call_on_this_device(std::atomic<uint64_t>& seen) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    const uint64_t bit = 1ull << dev;
+    return (seen.fetch_or(bit) & bit) == 0;
+}
 static void sort_attr_once() {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> seen{0};
+    if (first_call_on_this_device(seen)) {
         (void)hipFuncSetAttribute((const void*)k_tile_sort_lds<4096, 8192>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)sort_lds_bytes(8192));
         (void)hipFuncSetAttribute((const void*)k_tile_sort_flagged<SORT_MAX_LDS_KEYS>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)sort_lds_bytes(SORT_MAX_LDS_KEYS));
-        attr_set = true;
     }
 }
 
@@ -1423,12 +1432,10 @@ int depth_cut_repair(const float* bin_records, int N, int ntx, int nty, float mh
     const CutState cs = cut_state_of(cut_ws, N, T);
     k_bin_emit_buckets<2, PRIV_BLOCK><<<NBK, PRIV_BLOCK, sizeof(int) * (size_t)Tb, s>>>(
         bin_records, ntx, nty, mh, row0, row1, full_ranges, workspace + T, okeys, ocap, flags, cs);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> seen{0};
+    if (first_call_on_this_device(seen))
         (void)hipFuncSetAttribute((const void*)k_tile_sort_overflow, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)sort_lds_bytes(SORT_MAX_LDS_KEYS));
-        attr_set = true;
-    }
     k_tile_sort_overflow<<<Tb < WALK_GRID ? Tb : WALK_GRID, SORT_BLOCK, sort_lds_bytes(SORT_MAX_LDS_KEYS), s>>>(
         full_ranges, okeys, osorted, t0, Tb, ocap, flags, cs.ctrl);
     return GS_OK;

@@ -100,33 +100,41 @@ int32_t* cut_feedback_word(const HintKey& shape) {
         fb.flagged = torch::zeros({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
     return fb.flagged.data_ptr<int32_t>();
 }
+bool want_segments(int64_t n_instances, int64_t n_tiles) {
+    if (g_segments == 0) return n_tiles > 0 && n_tiles < 1500 && n_instances >= 192 * n_tiles;
+    return g_segments > 0 && n_tiles > 0;
+}
 bool want_depth_cut(const HintKey& shape, int N, int ntx, int row0, int row1, bool whole, int sort_prefix) {
     if (g_depth_cut < 0 || !whole || !sort_prefix) return false;
     if (!gs_cut_supported(ntx, row0, row1, N)) return false;
     if (g_depth_cut > 0) return true;
     std::lock_guard<std::mutex> lock(g_mutex);
     auto it = g_complete_count.find(shape);
-    if (it == g_complete_count.end() || it->second < g_cut_min_mean_list * (int64_t)(row1 - row0) * ntx) return false;
+    const int64_t n_tiles = (int64_t)(row1 - row0) * ntx;
+    if (it == g_complete_count.end() || it->second < g_cut_min_mean_list * n_tiles) return false;
+    // "auto" cut and "auto" segments exclude each other per shape: a cut frame takes the unsegmented backward, so a
+    // small whole frame that qualifies for both (fewer than 1500 tiles, long lists) would otherwise change backward
+    // kernels -- and the last bits of its gradients -- whenever the cut policy switches (first frame of a shape,
+    // every backoff).  Such shapes keep the segments (round-4 advisor finding).
+    if (want_segments(it->second, n_tiles)) return false;
     auto fb = g_cut_feedback.find(shape);
-    if (fb != g_cut_feedback.end()) {
-        if (fb->second.flagged.defined()) {
-            volatile int32_t* w = fb->second.flagged.data_ptr<int32_t>();
-            if ((int64_t)*w * 8 > (int64_t)(row1 - row0) * ntx) {
-                fb->second.cooldown = CUT_COOLDOWN;
-                *w = 0;
-                g_counters.cut_backoffs++;
-            }
-        }
+    if (fb != g_cut_feedback.end() && fb->second.flagged.defined()) {
+        volatile int32_t* w = fb->second.flagged.data_ptr<int32_t>();
+        // During a backoff no cut frame is enqueued, so the word is not looked at; it is cleared when the backoff
+        // ends -- CUT_COOLDOWN uncut frames after the last cut frame was enqueued, whose repair kernel has long
+        // written its count by then -- never while a cut frame may still be in flight (a count landing after a
+        // host-side reset used to start a second backoff; round-4 advisor finding).
         if (fb->second.cooldown > 0) {
-            fb->second.cooldown--;
+            if (--fb->second.cooldown == 0) *w = 0;
+            return false;
+        }
+        if ((int64_t)*w * 8 > n_tiles) {
+            fb->second.cooldown = CUT_COOLDOWN;
+            g_counters.cut_backoffs++;
             return false;
         }
     }
     return true;
-}
-bool want_segments(int64_t n_instances, int64_t n_tiles) {
-    if (g_segments == 0) return n_tiles > 0 && n_tiles < 1500 && n_instances >= 192 * n_tiles;
-    return g_segments > 0 && n_tiles > 0;
 }
 // "auto" is decided ONCE per frame shape, from the exact instance count of the first frame of that shape (which is
 // never speculative), and kept: a speculative frame only knows a capacity (S * 1.25 + 4096), so near the
@@ -745,12 +753,18 @@ FrameRec& frame_of(const Tensor& guard) { return **reinterpret_cast<FramePtr*>(g
 struct RowCosts {
     Tensor host;
     hipEvent_t event = nullptr;
-} g_row_costs;
+};
+std::map<int, RowCosts> g_row_costs;   // per device (one slot per process let a second device's frame overwrite the first's)
 
 struct PlanInfo {
-    int64_t v_lo = 0, v_hi = 0, V = 0, S = 0;
+    int64_t v_lo = 0, v_hi = 0, V = 0, S = 0, L = 0;
     std::vector<int64_t> send_splits, recv_splits;
+    // tests (debug_keep_band_lists): the band's tile ranges and sorted list of the latest sharded frame, and the send
+    // list that maps a band-compact row back to its visible index
+    Tensor ranges, sorted_g, send_list;
+    bool compact = false;
 } g_last_plan;
+bool g_keep_band_lists = false;
 
 template <typename F> void timed_region(const char* name, void* stream, F&& call) {
     timed(name, stream, [&] {
@@ -938,6 +952,15 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
             g_last_plan.S = S;
             g_last_plan.send_splits = fr.send_splits;
             g_last_plan.recv_splits = fr.recv_splits;
+            g_last_plan.L = L;
+            g_last_plan.compact = compact;
+            if (g_keep_band_lists) {
+                int64_t n_send = 0;
+                for (int64_t c : fr.send_splits) n_send += c;
+                g_last_plan.ranges = fr.ranges.clone();
+                g_last_plan.sorted_g = fr.sorted_g.clone();
+                g_last_plan.send_list = fr.halo_send.narrow(0, 0, n_send).clone();
+            }
         }
         Tensor uv_t = far.block(1, 2 * (int64_t)N).view({N, 2}).narrow(0, 0, V);
         Tensor mask_t = iar.block(6, (N + 3) / 4).view(torch::kBool).narrow(0, 0, N);
@@ -1034,9 +1057,10 @@ struct OwnerRender : public torch::autograd::Function<OwnerRender> {
             hip_ok(hipEventRecord(ev, (hipStream_t)stream));
             {
                 std::lock_guard<std::mutex> lock(g_mutex);
-                if (g_row_costs.event) (void)hipEventDestroy(g_row_costs.event);
-                g_row_costs.host = host_costs;
-                g_row_costs.event = ev;
+                RowCosts& rc = g_row_costs[(int)image.device().index()];
+                if (rc.event) (void)hipEventDestroy(rc.event);
+                rc.host = host_costs;
+                rc.event = ev;
             }
             return full;
         }
@@ -1213,6 +1237,13 @@ py::dict last_plan() {
     d["S"] = g_last_plan.S;
     d["send_splits"] = g_last_plan.send_splits;
     d["recv_splits"] = g_last_plan.recv_splits;
+    d["L"] = g_last_plan.L;
+    d["compact"] = g_last_plan.compact;
+    if (g_keep_band_lists && g_last_plan.ranges.defined()) {
+        d["ranges"] = g_last_plan.ranges;
+        d["sorted_g"] = g_last_plan.sorted_g;
+        d["send_list"] = g_last_plan.send_list;
+    }
     return d;
 }
 
@@ -1351,6 +1382,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("sharded_rasterize", &sharded_rasterize,
           "one rank of the tile-row sharded frame, owner-sliced gradients, equal or cost-balanced bands: -> (image, culling_mask, uv)");
     m.def("last_plan", &last_plan);
+    m.def("debug_keep_band_lists", [](bool on) {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        g_keep_band_lists = on;
+        if (!on) g_last_plan.ranges = g_last_plan.sorted_g = g_last_plan.send_list = Tensor();
+    }, py::arg("on"));
     m.def("take_row_costs", &take_row_costs);
     m.def("counters", &counters);
     m.def("reset_counters", &reset_counters);

@@ -147,6 +147,18 @@ __global__ __launch_bounds__(256) void k_grad_stats(const float* __restrict__ uv
     }
 }
 
+// A plain float4 stream copy (bench.py: the practical HBM roof of THIS box, next to the 8 TB/s nominal -- a library
+// copy_() measures the library, MI355X_MICROARCH.md quotes 6.29 TB/s for this kernel shape): grid-stride, 16 bytes per
+// lane per trip, non-temporal so that the 256 MiB Infinity Cache does not serve part of the stream.
+typedef float copy_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_stream_copy(const copy_f4* __restrict__ src, copy_f4* __restrict__ dst, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const copy_f4 v = __builtin_nontemporal_load(&src[i]);
+        __builtin_nontemporal_store(v, &dst[i]);
+    }
+}
+
 }  // namespace gs
 
 using namespace gs;
@@ -193,6 +205,14 @@ int gs_adam_step(int n_groups, void* const* params, const void* const* grads, vo
     const float w1 = (float)(1.0 - beta1), w2 = (float)(1.0 - beta2);
     k_adam<<<grid, 256, 0, (hipStream_t)stream>>>(G, w1, (float)beta2, w2, (float)eps);
     return check_launch("adam_step");
+}
+
+int gs_stream_copy(void* dst, const void* src, size_t bytes, int blocks, void* stream) {
+    GS_REQUIRE((((uintptr_t)dst | (uintptr_t)src | bytes) & 15) == 0, "stream_copy: pointers and size must be multiples of 16");
+    GS_REQUIRE(blocks >= 1, "stream_copy: blocks >= 1");
+    if (bytes == 0) return GS_OK;
+    k_stream_copy<<<blocks, 256, 0, (hipStream_t)stream>>>((const copy_f4*)src, (copy_f4*)dst, bytes / 16);
+    return check_launch("stream_copy");
 }
 
 int gs_accumulate_grad_stats(const void* uv_grad, int uv_row_stride, const int32_t* rank,

@@ -107,10 +107,18 @@ def main():
     if args.check:
         ref = torch.load(args.check)
         out["image_equal"] = bool(torch.equal(image.cpu(), ref["image"]))
+        out["image_max_abs_diff"] = float((image.cpu() - ref["image"]).abs().max())
+        out["nsp_mismatches"] = int((nsp.cpu() != ref["nsp"]).sum())
         out["nsp_equal"] = bool(torch.equal(nsp.cpu(), ref["nsp"]))
         a, b = slab.cpu().double(), ref["slab"].double()
         out["slab_scaled_err_per_column"] = [float(((a[:, j] - b[:, j]).abs().max() / b[:, j].abs().max().clamp(min=1e-300)))
                                              for j in range(a.shape[1])]
+        # SURVEY 8(d)'s measure with the 1 % floor, per gradient tensor (colour 0-2, opacity 3, uv 4-5, conic 6-8)
+        def floor_err(c0, c1):
+            top = b[:, c0:c1].abs().max().clamp(min=1e-300)
+            return float(((a[:, c0:c1] - b[:, c0:c1]).abs() / b[:, c0:c1].abs().clamp(min=1e-2 * top)).max())
+        out["slab_rel_err_floor_1e-2"] = {"rgb": floor_err(0, 3), "opacity": floor_err(3, 4), "uv": floor_err(4, 6),
+                                          "conic": floor_err(6, 9)}
     print(json.dumps(out))
 
 

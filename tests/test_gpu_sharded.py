@@ -305,3 +305,127 @@ def test_band_project_masks_are_a_superset_of_the_exact_windows(workload, G):
     n_exact = int(((exact >> me) & 1).sum())
     n_bound = int(((bound >> me) & 1).sum())
     assert n_exact <= n_bound <= 1.35 * n_exact + 64, (n_exact, n_bound)   # tight enough to be worth it
+
+
+def test_config4_workload_D_sharded_over_8_simulated_ranks():
+    """BASELINE.json configs[3] as a correctness case: workload D (2.86 M Gaussians, 1297x840, SH 3) tile-row sharded
+    over G = 8 ranks, every rank's real kernels through the native orchestration with the band-compact per-Gaussian
+    stage (the path `bench.py --gpus 8` times), the all_to_all routed in-process with the very split lists RCCL would
+    get; one rank also through the Python orchestration.  Asserted: the sum of the band images is the single-GPU image
+    bit for bit; every band's tile lists are the single-GPU lists restricted to its rows (counts of all
+    tiles, and entry by entry over the prefix the renderer may read); send / recv row counts agree between every pair
+    of ranks and with the exchange's sparsity; owned-slice parameter gradients within 2e-5 of the tensor scale."""
+    from gaussian_splatting_amd import sharded
+    from gaussian_splatting_amd import _hip
+    from gaussian_splatting_amd.synthetic import DEFAULTS, WORKLOADS
+    G = 8
+    N, W, H, deg = WORKLOADS["D"]
+    d = DEFAULTS
+    args = (d["near_thresh"], d["far_thresh"], d["cull_mask_padding"], d["mh_dist"])
+    bg = torch.zeros(3, device=DEV)
+    gi = make_grad_image(W, H, seed=1, device=DEV)
+    g, cam, T = make_scene(N, W, H, deg, seed=0, device=DEV)
+    ntx, nty = (W + 15) // 16, (H + 15) // 16
+
+    # the single-GPU frame: image, dense gradients, complete tile lists
+    ref_g = type(g)(*[getattr(g, k).detach().clone().requires_grad_(True) for k in ("xyz", "rgb", "opacity", "scale",
+                                                                                     "quaternion", "sh")])
+    ref_img, ref_mask, ref_uv, aux = fused.rasterize(ref_g, T, cam, *args, True, bg, return_aux=True)
+    ref_img.backward(gi)
+    ref_img = ref_img.detach()
+    ref_grads = {k: getattr(ref_g, k).grad for k in PARAMS}
+    ref_ranges, ref_sorted = aux["tile_ranges"].long(), aux["sorted_gaussians"].long()
+    V = int((~ref_mask).sum())
+    del aux, ref_uv
+
+    def check_band_lists(rank, ranges, sorted_g, to_visible):
+        r0, r1 = sharded.band_of(nty, G, rank)
+        t0, t1 = r0 * ntx, r1 * ntx
+        if t1 <= t0:
+            return 0
+        mine = ranges.long()[t0:t1 + 1]
+        want = ref_ranges[t0:t1 + 1]
+        assert torch.equal(mine[1:] - mine[:-1], want[1:] - want[:-1]), f"rank {rank}: tile counts differ"
+        # entry by entry over what the renderer may read: the whole list of a tile up to the prefix-sort length, its
+        # 1024 nearest entries beyond (a longer list is only ordered further when the tile was repaired)
+        n = (want[1:] - want[:-1]).clamp(max=_hip.GS_SORT_PREFIX)
+        tile = torch.repeat_interleave(torch.arange(t1 - t0, device=DEV), n)
+        k = torch.arange(int(n.sum()), device=DEV) - torch.repeat_interleave(torch.cumsum(n, 0) - n, n)
+        got = sorted_g.long()[mine[:-1][tile] + k]
+        if to_visible is not None:
+            got = to_visible.long()[got]
+        assert torch.equal(got, ref_sorted[want[:-1][tile] + k]), f"rank {rank}: band list differs from the single-GPU list"
+        return int(n.sum())
+
+    sent, plans = {}, {}
+    nat = fused.native()
+    prev = sharded.NATIVE, sharded.BAND_COMPACT
+
+    def run(rank, a2a, native):
+        sharded.NATIVE, sharded.BAND_COMPACT = native, native
+        owned = owned_slice(g, G, rank)
+        rast = ShardedRasterizer(H, G, rank, grad_mode="owner", all_to_all=a2a)
+        img, mask, uv = rast.rasterize(g, T, cam, *args, True, bg, owned=owned)
+        img.backward(gi)
+        return img.detach(), mask, owned, rast
+
+    def recorder(rank):
+        def a2a(recv, send, recv_splits, send_splits):
+            sent[rank] = (send.clone(), list(send_splits))
+            plans[rank] = (list(send_splits), list(recv_splits))
+            recv.zero_()
+        return a2a
+
+    def router(rank):
+        def a2a(recv, send, recv_splits, send_splits):
+            off = 0
+            for s in range(G):
+                buf, splits = sent[s]
+                lo = sum(splits[:rank])
+                assert splits[rank] == recv_splits[s]
+                recv[off:off + recv_splits[s]] = buf[lo:lo + splits[rank]]
+                off += recv_splits[s]
+        return a2a
+
+    try:
+        nat.debug_keep_band_lists(True)
+        checked = 0
+        for r in range(G):   # pass 1: every rank's partial rows, its plan and its band lists
+            run(r, recorder(r), True)
+            p = nat.last_plan()
+            assert p["compact"] and p["V"] == V
+            checked += check_band_lists(r, p["ranges"], p["sorted_g"], p["send_list"])
+        assert checked > 4_000_000   # (4.4 M of the 12.2 M instances lie within their tile's 1024 nearest)
+        # the plans agree pairwise: what s sends to r is what r expects from s
+        for s in range(G):
+            for r in range(G):
+                assert plans[s][0][r] == plans[r][1][s], (s, r)
+        rows = sum(sum(plans[r][0]) for r in range(G))
+        assert V < rows < 0.25 * G * V, "the exchange should be sparse: a Gaussian reaches 1-2 bands of 8"
+        total = torch.zeros_like(ref_img)
+        for r in range(G):   # pass 2: the real exchange data
+            img, mask, owned, rast = run(r, router(r), True)
+            total += img
+            assert torch.equal(mask, ref_mask)
+            i0, i1 = owner_range(N, G, r)
+            for k, ref in ref_grads.items():
+                got = getattr(owned, k).grad
+                err = (got - ref[i0:i1]).abs().max() / ref.abs().max().clamp(min=1e-30)
+                assert float(err) < 2e-5, (r, k, float(err))
+        assert torch.equal(total, ref_img)
+        # one rank through the Python orchestration (no band-compact stage: exact candidate windows, so its plan is
+        # not the compact frames' plan -- every rank's partial rows are recorded again on that path first)
+        sent.clear()
+        for r in range(G):
+            run(r, recorder(r), False)
+        r = 3
+        img, mask, owned, rast = run(r, router(r), False)
+        r0, r1 = sharded.band_of(nty, G, r)
+        assert torch.equal(img[16 * r0:min(H, 16 * r1)], ref_img[16 * r0:min(H, 16 * r1)])
+        i0, i1 = owner_range(N, G, r)
+        for k, ref in ref_grads.items():
+            err = (getattr(owned, k).grad - ref[i0:i1]).abs().max() / ref.abs().max().clamp(min=1e-30)
+            assert float(err) < 2e-5, ("python", k, float(err))
+    finally:
+        nat.debug_keep_band_lists(False)
+        sharded.NATIVE, sharded.BAND_COMPACT = prev
