@@ -1328,11 +1328,15 @@ py::object take_row_costs() {
     Tensor host;
     hipEvent_t ev = nullptr;
     {
+        // the costs of the CURRENT device's latest frame (one slot per device)
+        int dev = 0;
+        hip_ok(hipGetDevice(&dev));
         std::lock_guard<std::mutex> lock(g_mutex);
-        host = g_row_costs.host;
-        ev = g_row_costs.event;
-        g_row_costs.host = Tensor();
-        g_row_costs.event = nullptr;
+        RowCosts& rc = g_row_costs[dev];
+        host = rc.host;
+        ev = rc.event;
+        rc.host = Tensor();
+        rc.event = nullptr;
     }
     if (!host.defined()) return py::none();
     if (ev) {

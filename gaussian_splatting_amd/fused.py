@@ -185,7 +185,14 @@ def want_depth_cut(hint_key, N, ntx, row0, row1, whole):
         return False
     if DEPTH_CUT is True:
         return True
-    return _mean_list_hint.get(hint_key, 0) >= DEPTH_CUT_MIN_MEAN_LIST * (row1 - row0) * ntx
+    n_tiles = (row1 - row0) * ntx
+    known = _mean_list_hint.get(hint_key, 0)
+    if known < DEPTH_CUT_MIN_MEAN_LIST * n_tiles:
+        return False
+    # "auto" cut and "auto" segments exclude each other per shape: a cut frame takes the unsegmented backward, so a
+    # small dense frame would change backward kernels (and the last bits of its gradients) whenever the cut policy
+    # switches; such shapes keep the segments (csrc/frame_hip.cpp want_depth_cut does the same)
+    return not want_segments(known, n_tiles)
 
 
 def preprocess_forward(xyz, quaternion, scale, opacity, rgb, sh, camera_T_world, K, width, height, near_thresh,

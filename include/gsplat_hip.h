@@ -222,6 +222,17 @@ int gs_preprocess_forward(const void* xyz, const void* quaternion, const void* s
                           uint8_t* culling_mask, int32_t* rank, int32_t* vis_idx, void* uv,
                           void* xyz_camera_frame, void* conic, void* opacity_act, void* rgb_render,
                           void* packed, void* stream);
+int gs_preprocess_forward_cut(const void* xyz, const void* quaternion, const void* scale,
+                              const void* opacity, const void* rgb, const void* sh, int n_sh,
+                              const void* camera_T_world, const void* K, int N, int W, int H,
+                              float near_thresh, float far_thresh, float cull_mask_padding,
+                              float mh_dist, int band_row0, int band_row1,
+                              int32_t* workspace, void* camera_center, int32_t* visible_count,
+                              uint8_t* culling_mask, int32_t* rank, int32_t* vis_idx, void* uv,
+                              void* xyz_camera_frame, void* conic, void* opacity_act, void* rgb_render,
+                              void* packed, void* bin_records, int32_t* cut_workspace, int32_t* depth_hist,
+                              int sample_stride, void* stream);
+
 /* Backward of the above (projection_backward.cu:9-471, precompute_sh.cu:61-111 and the autograd of
  * the glue: sigmoid', the cat split, the dense scatter of rasterize.py:52-75, matmul').
  * grad_slab: the render gradients, one row of 9 floats per visible Gaussian in the order
@@ -234,16 +245,6 @@ int gs_preprocess_forward(const void* xyz, const void* quaternion, const void* s
  * the parameter / rank / output pointers advanced to row i0, N = i1 - i0, and a slab that holds
  * the rows of the slice's visible Gaussians with v_base = their first visible index;
  * opacity_act stays the full array (it is indexed by v). */
-int gs_preprocess_forward_cut(const void* xyz, const void* quaternion, const void* scale,
-                              const void* opacity, const void* rgb, const void* sh, int n_sh,
-                              const void* camera_T_world, const void* K, int N, int W, int H,
-                              float near_thresh, float far_thresh, float cull_mask_padding,
-                              float mh_dist, int band_row0, int band_row1,
-                              int32_t* workspace, void* camera_center, int32_t* visible_count,
-                              uint8_t* culling_mask, int32_t* rank, int32_t* vis_idx, void* uv,
-                              void* xyz_camera_frame, void* conic, void* opacity_act, void* rgb_render,
-                              void* packed, void* bin_records, int32_t* cut_workspace, int32_t* depth_hist,
-                              int sample_stride, void* stream);
 int gs_preprocess_backward(const void* xyz, const void* quaternion, const void* scale, int n_sh,
                            const void* camera_T_world, const void* K, const void* camera_center,
                            const int32_t* rank, const void* opacity_act, const void* grad_slab,

@@ -178,12 +178,15 @@ def test_cut_frame_repairs_tiles_that_need_more(case, native):
 
 def test_auto_policy_takes_the_cut_only_for_long_lists():
     """"auto": the first frame of a shape runs uncut (nothing is known about its lists); dense shapes then switch to
-    the cut, sparse ones never do"""
+    the cut, sparse ones never do -- and neither do small dense frames (fewer than 1500 tiles with long lists): they
+    take the depth-segmented backward, a cut frame takes the unsegmented one, and a shape that switched between the two
+    whenever the cut policy changed its mind would change the last bits of its gradients from frame to frame (round-4
+    advisor finding; csrc/frame_hip.cpp want_depth_cut)"""
     fused.reset_counters()
     prev = fused.DEPTH_CUT
     fused.DEPTH_CUT = "auto"
     try:
-        for N, W, H, expect in ((400_000, 320, 240, 2), (60_000, 640, 480, 0)):
+        for N, W, H, expect in ((1_200_000, 1024, 640, 2), (400_000, 320, 240, 0), (60_000, 640, 480, 0)):
             g, cam, T = make_scene(N, W, H, 0, seed=7, device=DEV)
             bg = torch.zeros(3, device=DEV)
             before = fused.counters().get("depth_cut_frames", 0)

@@ -128,7 +128,16 @@ def test_band_backward_from_the_oracles_own_inputs(workload):
 # top of the order noise, <= 3e-7 of the element's own leaf-term magnitude (the floor-free criterion asserted in
 # check_band_backward).  NOT the cause: the hardware reciprocal in the transmittance walk -- a build with a Newton
 # step on it (make variant EXTRA=-DGS_BWD_RCP_REFINE) reads the same 0.9e-3 .. 1.0e-3 for the opacity.
-REORDER_FACTOR = {"rgb_render": 2.0, "opacity_act": 8.0, "uv": 8.0, "conic": 8.0}
+# Round 5: the factors are what was MEASURED plus a quarter, per kernel -- the unsegmented walk (band rows 26-28 /
+# the whole frame at D, profiles/r04/parity_report.json): colour 1.35 / 1.48, opacity 4.06 / 3.22, uv 1.31 / 2.75,
+# conic 0.70 / 1.14 x the spread; the depth-segmented walk (band): 0.99, 7.55, 4.81, 0.64 (one more rounding per
+# segment boundary on every weight behind it).  Until round 4 one table allowed 8x for three tensors
+# of BOTH kernels: a kernel error worth 5x the noise floor on small elements would have passed.  Across the four
+# tensors together the unsegmented kernel must stay within 2x of the largest spread (measured 1.77 on the whole
+# frame: 0.0145 against 0.0082).
+REORDER_FACTOR = {"rgb_render": 2.0, "opacity_act": 5.0, "uv": 3.5, "conic": 2.0}
+REORDER_FACTOR_SEGMENTED = {"rgb_render": 2.0, "opacity_act": 9.5, "uv": 6.0, "conic": 2.0}
+REORDER_FACTOR_ALL_TENSORS = 2.0
 
 
 @pytest.mark.parametrize("segments", [False, True], ids=["unsegmented", "depth-segmented"])
@@ -184,5 +193,8 @@ def test_gradient_error_is_within_the_fp32_reorder_spread(segments):
         rows_out.append((name, kernel, spread))
         # the pure order spread alone is already above the 1e-4 target at this floor
         assert spread > 1e-4, (name, spread)
+    factor = REORDER_FACTOR_SEGMENTED if segments else REORDER_FACTOR
     for name, kernel, spread in rows_out:
-        assert kernel <= REORDER_FACTOR[name] * spread, (name, kernel, spread)
+        assert kernel <= factor[name] * spread, (name, kernel, spread)
+    if not segments:
+        assert max(k for _, k, _ in rows_out) <= REORDER_FACTOR_ALL_TENSORS * max(sp for _, _, sp in rows_out), rows_out
