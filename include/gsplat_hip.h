@@ -491,7 +491,7 @@ int gs_preprocess_forward_list(const void* xyz, const void* quaternion, const vo
 int gs_adam_step(int n_groups, void* const* params, const void* const* grads, void* const* exp_avg,
                  void* const* exp_avg_sq, const int64_t* numel, const double* lr,
                  const int64_t* step, double beta1, double beta2, double eps, void* stream);
-/* Measurement aid (bench.py `roofline.hbm_copy_gbs_measured`): a float4 grid-stride stream copy of `bytes` bytes
+/* Measurement aid (ABI 7; bench.py `roofline.hbm_copy_gbs_measured`): a float4 grid-stride stream copy of `bytes` bytes
  * (multiple of 16, as are both pointers) with `blocks` workgroups of 256 lanes, non-temporal loads and stores.
  * No reference counterpart. */
 int gs_stream_copy(void* dst, const void* src, size_t bytes, int blocks, void* stream);

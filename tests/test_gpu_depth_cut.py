@@ -227,8 +227,10 @@ def test_auto_policy_backs_off_when_most_tiles_need_their_complete_lists():
     nat = fused.native()
     if nat is None:
         pytest.skip("native frame module not built")
-    W, H = 256, 176
-    g, cam, T = make_scene(280_000, W, H, 0, seed=11, device=DEV)
+    # (1900 tiles: a frame of fewer than 1500 tiles with lists this long keeps the depth segments and is never cut
+    # by "auto", csrc/frame_hip.cpp want_depth_cut)
+    W, H = 800, 608
+    g, cam, T = make_scene(800_000, W, H, 0, seed=11, device=DEV)
     g.opacity.fill_(-5.0)
     gi = make_grad_image(W, H, seed=2, device=DEV)
     ref = run_frame(g, cam, T, gi, False, True)
