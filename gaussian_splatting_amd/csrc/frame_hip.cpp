@@ -50,6 +50,7 @@ std::map<HintKey, int64_t> g_capacity;
 // depth cut (include/gsplat_hip.h "depth-bucketed binning"): capacity of the overflow buffers (the frame's complete
 // instance count) and the complete instance count of the latest frame of a shape (what "auto" decides on)
 std::map<HintKey, int64_t> g_overflow_capacity, g_complete_count;
+std::map<HintKey, int64_t> g_visible_count;   // V of the shape's latest frame (the cut's partition scales with V, not N)
 std::map<HintKey, int64_t> g_longest_list;   // longest tile list of the shape's last complete-list frame (a guess for the next)
 struct PinnedRing {
     std::vector<Tensor> bufs;
@@ -112,6 +113,10 @@ bool want_depth_cut(const HintKey& shape, int N, int ntx, int row0, int row1, bo
     auto it = g_complete_count.find(shape);
     const int64_t n_tiles = (int64_t)(row1 - row0) * ntx;
     if (it == g_complete_count.end() || it->second < g_cut_min_mean_list * n_tiles) return false;
+    // gs_cut_supported gates on N, the capacity; what the cut's partition and count passes walk is the VISIBLE set: a
+    // heavily culled view of a large scene can pass the gate on N and not pay (round-4 advisor finding)
+    auto iv = g_visible_count.find(shape);
+    if (iv != g_visible_count.end() && !gs_cut_supported(ntx, row0, row1, (int)std::min<int64_t>(iv->second, N))) return false;
     // "auto" cut and "auto" segments exclude each other per shape: a cut frame takes the unsegmented backward, so a
     // small whole frame that qualifies for both (fewer than 1500 tiles, long lists) would otherwise change backward
     // kernels -- and the last bits of its gradients -- whenever the cut policy switches (first frame of a shape,
@@ -479,6 +484,7 @@ struct Preprocess : public torch::autograd::Function<Preprocess> {
                 ho = std::max(ho, S_complete + S_complete / 4 + 4096);
             }
             g_complete_count[shape] = S_complete;
+            g_visible_count[shape] = V;
             if (!cut && sort_prefix) g_longest_list[key] = longest;
         }
         if (!speculative || miss) {
