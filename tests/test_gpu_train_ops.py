@@ -192,3 +192,24 @@ def test_adam_step_unaligned_views_take_the_scalar_path():
     err = (p_hip.detach().cpu() - p_ref.detach()).abs().max() / p_ref.detach().abs().max()
     assert float(err) < 2e-6
     assert float(store[0]) == float(base[0])             # the element before the view is untouched
+
+
+def test_stream_copy_is_a_copy_and_checks_its_arguments():
+    """gs_stream_copy (bench.py's measured-bandwidth denominator): bytes arrive unchanged for a size that is not a
+    multiple of the grid, any grid; misaligned pointers / sizes are refused with an error, not copied wrongly"""
+    import ctypes
+
+    from gaussian_splatting_amd import _hip
+    n = 4 * 1_000_003   # floats: a multiple of 4 (16 bytes), nothing else
+    a = torch.randn(n, device=DEV)
+    p = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + off)
+    for blocks in (1, 7, 4096):
+        b = torch.zeros(n + 8, device=DEV)
+        _hip.call("gs_stream_copy", p(b), p(a), ctypes.c_size_t(n * 4), blocks, _hip.current_stream())
+        assert torch.equal(b[:n], a) and not b[n:].any()
+    b = torch.zeros(n, device=DEV)
+    with pytest.raises(RuntimeError):
+        _hip.call("gs_stream_copy", p(b, 4), p(a), ctypes.c_size_t(1024), 16, _hip.current_stream())
+    with pytest.raises(RuntimeError):
+        _hip.call("gs_stream_copy", p(b), p(a), ctypes.c_size_t(1000), 16, _hip.current_stream())
+    _hip.call("gs_stream_copy", p(b), p(a), ctypes.c_size_t(0), 16, _hip.current_stream())   # nothing to do: fine
