@@ -268,7 +268,7 @@ def test_bench_helpers():
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
-@pytest.mark.parametrize("rnd", ["r02", "r04"])
+@pytest.mark.parametrize("rnd", ["r02", "r04", "r05"])
 def test_committed_traffic_and_valu_json_follow_from_the_committed_pmc_passes(tmp_path, rnd):
     """profiles/<round>/hbm_traffic_D.json and valu_insts_D.json (what bench.py reports as roofline.traffic /
     roofline.valu) are exactly what scripts/make_traffic_json.py derives from the committed rocprofv3 passes
@@ -283,12 +283,12 @@ def test_committed_traffic_and_valu_json_follow_from_the_committed_pmc_passes(tm
                     str(out), "D", str(valu)], check=True, cwd=root, capture_output=True)
     assert json.load(open(out)) == json.load(open(os.path.join(root, "profiles", rnd, "hbm_traffic_D.json")))
     assert json.load(open(valu)) == json.load(open(os.path.join(root, "profiles", rnd, "valu_insts_D.json")))
-    if rnd == "r04":
+    if rnd in ("r04", "r05"):
         assert json.load(open(out))["binning"] == "depth cut"
 
 
 @pytest.mark.parametrize("name", ["r02/bench_D.json", "r02/bench_B.json", "r02/bench_C.json",
-                                  "r02/bench_D_moving_camera.json", "r04/bench_D.json"])
+                                  "r02/bench_D_moving_camera.json", "r04/bench_D.json", "r05/bench_D.json"])
 def test_committed_bench_lines_keep_the_contract(name):
     """the JSON lines under profiles/ are what `python bench.py` printed: the contract's fields, BASELINE.json's
     metric verbatim, a roofline object whose fraction is achieved / peak and whose achieved rate is the algorithmic
@@ -316,6 +316,30 @@ def test_committed_bench_lines_keep_the_contract(name):
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mpixels/s" and c["sample"]
         assert d["parity"]["image_max_abs_err"] == 0.0 and d["parity"]["grad_max_rel_err"] < 1e-4
         assert r["traffic"] is not None and r["traffic_source"].startswith("profiles/")
+    if name == "bench_D.json" and "hbm_achievable_gbs_guide" in r:   # round 5 on
+        assert r["hbm_achievable_gbs_guide"] == 6290.0 and "gs_stream_copy" in r["hbm_copy_kernel"]
+        assert abs(r["frame_frac_of_achievable"] - r["frame_frac"] * 8000.0 / 6290.0) < 1e-3
+        h = d["parity"]["headline"]
+        assert h["grad_max_rel_err_floor_1e-2"] < h["target"] == 1e-4
+        assert abs(h["ratio_kernel_to_pure_fp32_reorder_spread"]
+                   - h["grad_max_rel_err_floor_1e-6"] / h["fp32_reorder_spread_floor_1e-6"]) < 1e-9
+        assert h["ratio_kernel_to_pure_fp32_reorder_spread"] <= 2.0   # the gate tests/test_gpu_wholeframe_parity.py asserts
+
+
+def test_committed_training_trace_converges():
+    """profiles/r05/train_loop_convergence.json is what `bench.py --train-loop 7000` printed: the config-5-sized loop
+    fits its training views at every mark; the view-determined problem also rises on the held-out views"""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tl = json.load(open(os.path.join(root, "profiles", "r05", "train_loop_convergence.json")))["train_loop"]
+    for run in (tl, tl["well_posed_problem"]):
+        c = run["convergence"]
+        assert run["iterations"] == 7000 and c["monotone_train_loss"] and c["monotone_train_psnr"]
+        assert [q["at"] for q in run["quality_trace"]].count("after opacity reset") == 2
+        assert c["train_psnr_db_start_end"][1] > 30.0
+    c = tl["well_posed_problem"]["convergence"]
+    assert c["monotone_held_out_psnr"] and c["held_out_psnr_db_start_end"][1] - c["held_out_psnr_db_start_end"][0] > 7.0
 
 
 def test_every_python_file_of_the_repo_compiles(tmp_path):
