@@ -101,6 +101,11 @@ int32_t* cut_feedback_word(const HintKey& shape) {
         fb.flagged = torch::zeros({1}, torch::TensorOptions().dtype(torch::kInt32).pinned_memory(true));
     return fb.flagged.data_ptr<int32_t>();
 }
+// "auto" is decided ONCE per frame shape, from the exact instance count of the first frame of that shape (which is
+// never speculative), and kept: a speculative frame only knows a capacity (S * 1.25 + 4096), so near the
+// 192-entries-per-tile threshold the first frame and later frames of the same scene would pick different backward
+// kernels and their gradients would differ in the last bits from frame to frame (round-3 advisor finding).
+std::map<HintKey, bool> g_segment_choice;
 bool want_segments(int64_t n_instances, int64_t n_tiles) {
     if (g_segments == 0) return n_tiles > 0 && n_tiles < 1500 && n_instances >= 192 * n_tiles;
     return g_segments > 0 && n_tiles > 0;
@@ -121,7 +126,16 @@ bool want_depth_cut(const HintKey& shape, int N, int ntx, int row0, int row1, bo
     // small whole frame that qualifies for both (fewer than 1500 tiles, long lists) would otherwise change backward
     // kernels -- and the last bits of its gradients -- whenever the cut policy switches (first frame of a shape,
     // every backoff).  Such shapes keep the segments (round-4 advisor finding).
-    if (want_segments(it->second, n_tiles)) return false;
+    // What counts is what the backward of this shape will really take: the choice segments_for() STORED from the
+    // shape's first exact count when there is one (a shape whose lists grew past the cut's threshold later -- a
+    // densifying scene -- keeps its stored "no segments" and may take the cut), want_segments() on the latest
+    // complete count only before that.  Segments FORCED on (g_segments > 0) are an explicit request for the
+    // segmented backward, which a cut frame cannot honour: the auto cut then stays off (round-5 advisor finding).
+    if (g_segments > 0) return false;
+    if (g_segments == 0) {
+        auto sc = g_segment_choice.find(shape);
+        if (sc != g_segment_choice.end() ? sc->second : want_segments(it->second, n_tiles)) return false;
+    }
     auto fb = g_cut_feedback.find(shape);
     if (fb != g_cut_feedback.end() && fb->second.flagged.defined()) {
         volatile int32_t* w = fb->second.flagged.data_ptr<int32_t>();
@@ -141,11 +155,6 @@ bool want_depth_cut(const HintKey& shape, int N, int ntx, int row0, int row1, bo
     }
     return true;
 }
-// "auto" is decided ONCE per frame shape, from the exact instance count of the first frame of that shape (which is
-// never speculative), and kept: a speculative frame only knows a capacity (S * 1.25 + 4096), so near the
-// 192-entries-per-tile threshold the first frame and later frames of the same scene would pick different backward
-// kernels and their gradients would differ in the last bits from frame to frame (round-3 advisor finding).
-std::map<HintKey, bool> g_segment_choice;
 bool segments_for(const HintKey& key, int64_t n_instances, bool exact_count, int64_t n_tiles) {
     if (g_segments != 0) return want_segments(n_instances, n_tiles);
     std::lock_guard<std::mutex> lock(g_mutex);

@@ -168,29 +168,15 @@ template <> __host__ __device__ constexpr int ref_chunk<double>(int n_sh) {
 
 // XCD-aware tile order: block b -> tile index inside [0, nt) (or >= nt: nothing to do).  The hardware
 // hands block b to XCD b % 8, a fixed eighth of the grid each.  Default: one contiguous eighth of the
-// frame per XCD (its L2 holds the records neighbouring tiles share).  GS_XCD_SEG > 0 deals runs of that
-// many consecutive tiles to the XCDs in turn instead; the wave timeline (scripts/render_timeline.py)
-// shows the eight XCDs finishing within 10 % of each other either way and the kernel times do not move
-// (workloads B, C, D: +-1 %), so the option stays off.
-#ifndef GS_XCD_SEG
-#define GS_XCD_SEG 0
-#endif
+// frame per XCD (its L2 holds the records neighbouring tiles share).  Dealing runs of 8 / 16 / 32 / 82 consecutive
+// tiles to the XCDs in turn instead was measured (scripts/experiments/render_macro_experiments.patch, its XCD_SEG option;
+// profiles/r02/kbench_xcd_segments.log): kernel times within 1.5 %, not kept.
 __host__ __device__ inline int render_grid(int nt) {
-#if GS_XCD_SEG > 0   // (experiment builds only: tile_order_body assumes the contiguous eighths)
-    const int nseg = (nt + GS_XCD_SEG - 1) / GS_XCD_SEG;
-    return ((nseg + 7) / 8) * GS_XCD_SEG * 8;
-#else
     return ((nt + 7) / 8) * 8;
-#endif
 }
 __device__ inline int tile_of_block(int b, int nt) {
-#if GS_XCD_SEG > 0
-    const int x = b & 7, j = b >> 3;
-    return ((j / GS_XCD_SEG) * 8 + x) * GS_XCD_SEG + j % GS_XCD_SEG;
-#else
     const int per = (nt + 7) >> 3;
     return (b & 7) * per + (b >> 3);
-#endif
 }
 
 struct PixelMap {
@@ -260,9 +246,6 @@ __device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_
 // < 2^-100, and in fp32 the callers only use such a value through `opacity * value < 1/255`
 // (render.cu:145, render_backward.cu:170), which it fails either way.  mh > 0 and not NaN here.
 __device__ __forceinline__ float exp_neg_half(float mh) {
-#ifdef GS_ARITH_FAST   // A/B build (profiles/r05/arith_fast_ab.txt): the hardware exponential, as the reference's __expf is on its GPU
-    return __builtin_amdgcn_exp2f(mh * (-0.5f * 1.44269504088896341f));
-#endif
     const float t = mh * (-0.5f * 1.44269504088896341f);
     const float n = __builtin_rintf(t);
     const float f = t - n;
@@ -436,7 +419,7 @@ __device__ __forceinline__ void tile_order_body(const int* __restrict__ cost, in
     __shared__ int s_wave[16];
     __shared__ int s_max;
     const int tid = threadIdx.x;
-    const int per = n_grid >> 3;   // tiles per XCD (render_grid / tile_of_block with GS_XCD_SEG == 0)
+    const int per = n_grid >> 3;   // tiles per XCD (render_grid / tile_of_block)
     s_hist[tid] = 0;
     if (tid == 0) s_max = 1;
     for (int b = tid; b < n_grid; b += 1024) order[b] = -1;
@@ -654,9 +637,7 @@ __device__ __forceinline__ void render_tile_fwd(
         if constexpr (CK) {
             Vec4<float> r4;
             r4.x = segL; r4.y = sg0; r4.z = sg1; r4.w = sg2;
-#ifndef GS_CK_NOREC   // (A/B builds that time the parts of the extra work; wrong gradients)
             seg.rec[((size_t)(tile - seg.tile0) * SEG_MAX + b_cur) * RB + tid] = r4;
-#endif
             segL = 1; sg0 = 0; sg1 = 0; sg2 = 0;
         }
     };
@@ -732,11 +713,7 @@ __device__ __forceinline__ void render_tile_fwd(
                             // once, exactly as the reference's double multiplication rounds its exact operands.
                             // Same bits, four fp64-rate instructions and one fp32.
                             fw = 1.0f - acc;
-#ifdef GS_ARITH_FAST
-                            const T weight = alpha * fw;   // one fp32 rounding more than the reference's narrowed double product
-#else
                             const T weight = (T)__builtin_fma((double)alpha, -(double)acc, (double)alpha);
-#endif
                             img[0] += r.g2.y * weight;
                             img[1] += r.g2.z * weight;
                             img[2] += r.g2.w * weight;
@@ -864,11 +841,7 @@ __device__ __forceinline__ void render_tile_fwd(
             // the pixel's last contributor once more, in the BACKWARD's arithmetic (k_render_bwd: alpha from
             // mh * (1 / det), capped at 0.9999): what its first step does to weight and colour_accum
             T oma_last = 1, bgw = 0;
-#ifdef GS_CK_NOEPI
-            if (kend < 0) {
-#else
             if (kend > 0) {
-#endif
                 const int g = sorted[s0 + kend - 1];
                 const Vec4<T>* rec = reinterpret_cast<const Vec4<T>*>(packed + (size_t)g * GS_PACKED_WIDTH);
                 const Vec4<T> g0 = rec[0], g1 = rec[1], g2 = rec[2];
@@ -1089,43 +1062,6 @@ __device__ __forceinline__ void reduce9_to_slot(const float* val, int lane, int 
     if (lane_offset >= 0) slot[lane_offset] = total;
 }
 
-// Three values instead of nine (experiment builds, GS_EMU_MM: what would be left on the VALU if the six separable
-// sums of a visit -- aw x (gi_r, gi_g, gi_b) and w x (1, px, py) -- went through the matrix cores): same trades,
-// 6 DPP adds + 2 swaps.  After it bank k of every row holds the wave total of value (0, 2, 1, -)[k].
-__device__ __forceinline__ void reduce3_to_slot(float v0, float v1, float v2, int lane, float* slot) {
-    float r0, r1 = 0.0f, s;
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %3, %3 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %1, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %0, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %2, %0, %0 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %2, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "=&v"(r0), "+&v"(r1), "=&v"(s)
-        : "v"(v0), "v"(v1), "v"(v2));
-    float t = s, u = s;
-    permlane16_swap(t, u);
-    float e = t + u;
-    float f = e, g = e;
-    permlane32_swap(f, g);
-    const float total = f + g;
-    // bank 0 -> value 0, bank 1 -> value 2, bank 2 -> value 1
-    const int bank = (lane >> 2) & 3;
-    if (lane < 16 && (lane & 3) == 0 && bank < 3) slot[bank == 0 ? 0 : (bank == 1 ? 2 : 1)] = total;
-}
-#ifndef GS_EMU_MM
-#define GS_EMU_MM 0   // 1: three-value reduction + the batch's two LDS stores, no flush; 2: + a flush of the batch's cost
-#endif
-#ifndef GS_EMU_MM_NB
-#define GS_EMU_MM_NB 4   // splats per batch: what 22.8 KB of LDS per workgroup (7 per CU) leave room for
-#endif
-
 // ---------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------
@@ -1173,11 +1109,6 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     __shared__ int s_max[4];
     __shared__ unsigned long long s_mask[4][NWORD];
     __shared__ unsigned long long s_hit[SLOTS ? 4 : 1][NWORD];   // SLOTS: slots written by each wave
-#if GS_EMU_MM
-    __shared__ alignas(16) float s_emu[SLOTS && N_SH == 1 ? 4 * GS_EMU_MM_NB * 128 : 4];   // [wave][slot][kind][pixel]
-    __shared__ alignas(16) float s_emu_gi[SLOTS && N_SH == 1 && GS_EMU_MM >= 2 ? 4 * 3 * 64 : 4];
-    int emu_nb = 0;
-#endif
 
     // depth segments (fused renderer, seg.rec != nullptr): work item = (tile, segment), block index =
     // segment * grid + block of the tile; segment 0 -- every pixel active, the most work -- starts first
@@ -1233,12 +1164,6 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
         if constexpr (N_SH > 1) sh_basis<T, N_SH>(d, Y);
         else Y[0] = T(GS_SH_0);
     }
-#if GS_EMU_MM >= 2
-    if constexpr (SLOTS && N_SH == 1) {
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) s_emu_gi[(wave * 3 + ch) * 64 + lane] = float(gi[ch]);
-    }
-#endif
     // the tile's deepest used splat (render_backward.cu:131 makes everything beyond it a no-op)
     int m = nsp;
 #pragma unroll
@@ -1453,13 +1378,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                         // values only from here on (no threshold depends on them): contraction allowed
                         {
 #pragma clang fp contract(fast)
-#ifdef GS_BWD_RCP_REFINE   // A/B build: one Newton step on the hardware reciprocal (tests/test_gpu_fullsize_parity.py)
-                            const T x1ma = T(1) - alpha;
-                            const T r0 = fast_rcp(x1ma);
-                            const T r1ma = __builtin_fmaf(r0, __builtin_fmaf(-x1ma, r0, 1.0f), r0);
-#else
                             const T r1ma = fast_rcp(T(1) - alpha);
-#endif
                             if ((exact ? k : k % REF_CH) < nsp - 1) weight = weight * r1ma;   // Q1 (chunk-local index) unless exact
                             aw = alpha * weight;
                             // grad_alpha (render_backward.cu:196-203); the record's colour is Y0 * coefficient
@@ -1494,61 +1413,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                 val[0] = awy * gi[0]; val[1] = awy * gi[1]; val[2] = awy * gi[2];
                 val[3] = w; val[4] = w * du; val[5] = w * dv;
                 val[6] = q0; val[7] = q1; val[8] = q2;
-#if GS_EMU_MM
-                // EMULATION (timing only, colour / opacity / uv gradients are garbage): the three conic sums on the
-                // VALU, aw and w into the wave's open batch [slot][kind][pixel]; GS_EMU_MM == 2 adds a flush that costs
-                // what the real one would (operand reads, 16 MFMAs per GS_EMU_MM_NB splats, the D stores)
-                reduce3_to_slot(val[6], val[7], val[8], lane, &s_acc[(wave * RCHUNK + i) * SV + 6]);
-                {
-                    float* bb = s_emu + (wave * GS_EMU_MM_NB + (emu_nb & (GS_EMU_MM_NB - 1))) * 128;
-                    bb[lane] = aw;
-                    bb[64 + lane] = w;
-                    emu_nb++;
-#if GS_EMU_MM >= 2
-                    if ((emu_nb & (GS_EMU_MM_NB - 1)) == 0) {
-                        typedef float f32x4 __attribute__((ext_vector_type(4)));
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        const int j = lane & 15, q = lane >> 4;
-                        // B: column j = 2 slot + kind (j < 2 NB), pixels 16 q .. 16 q + 15; A: rows gi_r gi_g gi_b 1 px py
-                        const float* brow = s_emu + (wave * GS_EMU_MM_NB + ((j >> 1) & (GS_EMU_MM_NB - 1))) * 128 + (j & 1) * 64 + 16 * q;
-                        const float* arow = s_emu_gi + (wave * 3 + (j < 3 ? j : 0)) * 64 + 16 * q;
-                        float b[16], a[16];
-#pragma unroll
-                        for (int m4 = 0; m4 < 4; m4++) {
-                            const Vec4<float> v4 = reinterpret_cast<const Vec4<float>*>(brow)[m4];
-                            const Vec4<float> a4 = reinterpret_cast<const Vec4<float>*>(arow)[m4];
-                            b[4 * m4 + 0] = v4.x; b[4 * m4 + 1] = v4.y; b[4 * m4 + 2] = v4.z; b[4 * m4 + 3] = v4.w;
-                            a[4 * m4 + 0] = a4.x; a[4 * m4 + 1] = a4.y; a[4 * m4 + 2] = a4.z; a[4 * m4 + 3] = a4.w;
-                        }
-                        const float c0 = j == 3 ? 1.0f : (j == 4 ? float((wave & 1) * 8) : (j == 5 ? float((wave >> 1) * 8 + 2 * q) : 0.0f));
-                        const float c1 = j == 4 ? 1.0f : 0.0f, c2 = j == 5 ? 1.0f : 0.0f;
-#pragma unroll
-                        for (int t = 0; t < 16; t++) a[t] = j < 3 ? a[t] : (c0 + c1 * float(t & 7) + c2 * float(t >> 3));
-                        f32x4 even = {0, 0, 0, 0}, odd = {0, 0, 0, 0};
-#pragma unroll
-                        for (int t = 0; t < 16; t += 2) {
-                            even = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], even, 0, 0, 0);
-                            odd = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t + 1], b[t + 1], odd, 0, 0, 0);
-                        }
-                        const f32x4 d = even + odd;
-                        // D rows 0-3 sit in lanes 0-15, rows 4-5 in lanes 16-31 (registers 0, 1): into the splats' slots
-                        float* sl = &s_acc[(wave * RCHUNK + i) * SV];
-                        if (lane < 2 * GS_EMU_MM_NB) {
-                            if (lane & 1) sl[3] = d[3];
-                            else { sl[0] = d[0]; sl[1] = d[1]; sl[2] = d[2]; }
-                        } else if (lane >= 16 && lane < 16 + 2 * GS_EMU_MM_NB && (lane & 1)) {
-                            sl[4] = d[0]; sl[5] = d[1];
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                    }
-#endif
-                }
-#else
                 reduce9_to_slot(val, lane, slot_off, &s_acc[(wave * RCHUNK + i) * SV]);
-#endif
                 hit |= 1ull << bit;
                 if constexpr (SHMM) {
                     // column nb of the batch's B: this splat's aw at the wave's 64 pixels (0 where it does not contribute)

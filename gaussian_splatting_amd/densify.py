@@ -53,6 +53,9 @@ class DensifyConfig:
     uv_grad_threshold: float = 0.0002
     split_scale_factor: float = 1.6
     num_split_samples: int = 2
+    # learning rate of the SH group add_sh_band creates when there is none yet: base_lr * sh_lr_multiplier
+    # (config.py:80,93 -> optimizer_manager.py:60-63)
+    sh_lr: float = 0.002 * 0.1
 
 
 def inverse_sigmoid(x):   # utils.py:11-15
@@ -134,8 +137,7 @@ class DensityController:
             return
         if g.sh is None:
             g.sh = torch.nn.Parameter(torch.zeros(n, 3, 3, dtype=g.rgb.dtype, device=g.rgb.device))
-            lr = getattr(cfg, "sh_lr", None)
-            self.optimizer.add_param_group({"params": g.sh, **({"lr": lr} if lr is not None else {})})
+            self.optimizer.add_param_group({"params": g.sh, "lr": cfg.sh_lr})
             return
         width = g.sh.shape[2]
         grow = {3: 8, 8: 15}.get(width)

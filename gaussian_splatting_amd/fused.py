@@ -191,7 +191,13 @@ def want_depth_cut(hint_key, N, ntx, row0, row1, whole):
         return False
     # "auto" cut and "auto" segments exclude each other per shape: a cut frame takes the unsegmented backward, so a
     # small dense frame would change backward kernels (and the last bits of its gradients) whenever the cut policy
-    # switches; such shapes keep the segments (csrc/frame_hip.cpp want_depth_cut does the same)
+    # switches; such shapes keep the segments.  What counts is the choice segments_for() STORED for the shape when
+    # there is one; segments forced on (SEGMENTS = True) keep the auto cut off -- a cut frame cannot honour them
+    # (csrc/frame_hip.cpp want_depth_cut does the same)
+    if SEGMENTS != "auto":
+        return not bool(SEGMENTS)
+    if hint_key in _segment_choice:
+        return not _segment_choice[hint_key]
     return not want_segments(known, n_tiles)
 
 

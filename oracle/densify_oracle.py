@@ -12,6 +12,12 @@ Adam's per-parameter state and to the three accumulators:
     splat_py/optimizer_manager.py:44-172   the matching exp_avg / exp_avg_sq surgery
 The random numbers of the split (trainer.py:176 torch.rand) are supplied by the caller, so that the
 checker and the checked see the same samples.  Pure torch: runs on CPU or GPU tensors.
+
+PINNED (round 6) to the reference's own execution: tests/golden/ref_host_densify_*.npz are states before / after
+the reference's SplatTrainer.adaptive_density_control / reset_opacity / add_sh_band run in the authoring
+container (tests/golden/make_golden_densify.py imports /root/reference/splat_py/trainer.py with cv2 /
+torchmetrics / tyro stubbed at module level); tests/test_densify_golden.py holds this restatement to them bit
+for bit -- rows, layout, clones, split samples given the recorded torch.rand stream, every Adam moment.
 """
 import math
 

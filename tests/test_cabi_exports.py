@@ -118,3 +118,17 @@ def test_python_call_sites_pass_as_many_arguments_as_the_header_declares():
                 bad.append((os.path.relpath(path, ROOT), node.lineno, name, n_args, protos.get(name)))
     assert checked >= 40, checked
     assert not bad, bad
+
+
+def test_product_sources_carry_no_experiment_builds():
+    """timing-only emulations and A/B switches live in scripts/experiments/*.patch, not in the shipping translation
+    units (round-5 review): no GS_EMU_* token and none of the retired A/B macros in csrc/ or include/"""
+    banned = re.compile(r"GS_EMU_|GS_CK_NOREC|GS_CK_NOEPI|GS_XCD_SEG|GS_ARITH_FAST|GS_BWD_RCP_REFINE")
+    hits = []
+    for d in (os.path.join(ROOT, "gaussian_splatting_amd", "csrc"), os.path.join(ROOT, "include")):
+        for name in sorted(os.listdir(d)):
+            if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":
+                for i, line in enumerate(open(os.path.join(d, name), errors="replace"), 1):
+                    if banned.search(line):
+                        hits.append(f"{name}:{i}")
+    assert not hits, hits

@@ -127,7 +127,7 @@ def test_band_backward_from_the_oracles_own_inputs(workload):
 # form (as an nvcc build of the reference would: nvcc contracts by default): per-term differences of a few ulp on
 # top of the order noise, <= 3e-7 of the element's own leaf-term magnitude (the floor-free criterion asserted in
 # check_band_backward).  NOT the cause: the hardware reciprocal in the transmittance walk -- a build with a Newton
-# step on it (make variant EXTRA=-DGS_BWD_RCP_REFINE) reads the same 0.9e-3 .. 1.0e-3 for the opacity.
+# step on it (the BWD_RCP_REFINE build of scripts/experiments/render_macro_experiments.patch) reads the same 0.9e-3 .. 1.0e-3 for the opacity.
 # Round 5: the factors are what was MEASURED plus a quarter, per kernel -- the unsegmented walk (band rows 26-28 /
 # the whole frame at D, profiles/r04/parity_report.json): colour 1.35 / 1.48, opacity 4.06 / 3.22, uv 1.31 / 2.75,
 # conic 0.70 / 1.14 x the spread; the depth-segmented walk (band): 0.99, 7.55, 4.81, 0.64 (one more rounding per

@@ -307,9 +307,10 @@ def test_band_project_masks_are_a_superset_of_the_exact_windows(workload, G):
     assert n_exact <= n_bound <= 1.35 * n_exact + 64, (n_exact, n_bound)   # tight enough to be worth it
 
 
-def test_config4_workload_D_sharded_over_8_simulated_ranks():
+@pytest.mark.parametrize("G", [2, 4, 8])
+def test_config4_workload_D_sharded_over_simulated_ranks(G):
     """BASELINE.json configs[3] as a correctness case: workload D (2.86 M Gaussians, 1297x840, SH 3) tile-row sharded
-    over G = 8 ranks, every rank's real kernels through the native orchestration with the band-compact per-Gaussian
+    over G = 2 / 4 / 8 ranks (the config's own list), every rank's real kernels through the native orchestration with the band-compact per-Gaussian
     stage (the path `bench.py --gpus 8` times), the all_to_all routed in-process with the very split lists RCCL would
     get; one rank also through the Python orchestration.  Asserted: the sum of the band images is the single-GPU image
     bit for bit; every band's tile lists are the single-GPU lists restricted to its rows (counts of all
@@ -318,7 +319,9 @@ def test_config4_workload_D_sharded_over_8_simulated_ranks():
     from gaussian_splatting_amd import sharded
     from gaussian_splatting_amd import _hip
     from gaussian_splatting_amd.synthetic import DEFAULTS, WORKLOADS
-    G = 8
+    nat = fused.native()
+    if nat is None:
+        pytest.skip("native frame module not built")
     N, W, H, deg = WORKLOADS["D"]
     d = DEFAULTS
     args = (d["near_thresh"], d["far_thresh"], d["cull_mask_padding"], d["mh_dist"])
@@ -358,7 +361,6 @@ def test_config4_workload_D_sharded_over_8_simulated_ranks():
         return int(n.sum())
 
     sent, plans = {}, {}
-    nat = fused.native()
     prev = sharded.NATIVE, sharded.BAND_COMPACT
 
     def run(rank, a2a, native):
@@ -401,7 +403,8 @@ def test_config4_workload_D_sharded_over_8_simulated_ranks():
             for r in range(G):
                 assert plans[s][0][r] == plans[r][1][s], (s, r)
         rows = sum(sum(plans[r][0]) for r in range(G))
-        assert V < rows < 0.25 * G * V, "the exchange should be sparse: a Gaussian reaches 1-2 bands of 8"
+        # sparse: a Gaussian reaches 1-2 bands however many there are (every visible Gaussian reaches at least one)
+        assert V < rows < max(0.25 * G, 1.3) * V, (rows, V)
         total = torch.zeros_like(ref_img)
         for r in range(G):   # pass 2: the real exchange data
             img, mask, owned, rast = run(r, router(r), True)
@@ -418,7 +421,7 @@ def test_config4_workload_D_sharded_over_8_simulated_ranks():
         sent.clear()
         for r in range(G):
             run(r, recorder(r), False)
-        r = 3
+        r = min(3, G - 1)
         img, mask, owned, rast = run(r, router(r), False)
         r0, r1 = sharded.band_of(nty, G, r)
         assert torch.equal(img[16 * r0:min(H, 16 * r1)], ref_img[16 * r0:min(H, 16 * r1)])

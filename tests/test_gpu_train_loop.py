@@ -6,7 +6,8 @@ that its views determine: a hidden scene of 40 k Gaussians rendered from 48 pose
 started from half of the hidden centres (perturbed) the way dataloader.py:43-67 starts from SfM points.  Evaluated as
 compute_test_psnr does (trainer.py:297-346).  What must hold: the training loss falls and the training PSNR rises at
 every 1000-iteration mark (marks on either side of an opacity reset are compared with the evaluation right after the
-reset), the held-out PSNR rises at every mark too, and the run ends far from where it started."""
+reset, AND with each other: the reset's cost is won back by the next mark), the held-out PSNR does not fall by more
+than 0.1 dB at any mark, and the run ends far from where it started."""
 import os
 import sys
 
@@ -27,7 +28,13 @@ def test_seven_thousand_iterations_converge_on_training_and_held_out_views():
     c = out["convergence"]
     assert c["training_views"] == 40 and len(c["held_out_views"]) == 8
     assert c["monotone_train_loss"] and c["monotone_train_psnr"], c["steps"]
-    assert c["monotone_held_out_psnr"], c["steps"]
+    # held-out: a floor per step instead of strict monotonicity (the smallest committed gain is 0.20 dB and the
+    # gradients are summed by atomics: run-to-run noise must not fail the suite), plus the end-to-end gain below
+    assert all(st["held_out_psnr_gain_db"] > -0.1 for st in c["steps"]), c["steps"]
+    # mark against mark, nothing substituted: what an opacity reset costs is won back within 1000 iterations
+    for st in c["mark_to_mark"]:
+        assert st["train_psnr_gain_db"] > (-0.5 if st["crosses_reset"] else 0.0), st
+        assert st["held_out_psnr_gain_db"] > (-1.0 if st["crosses_reset"] else -0.1), st
     t0, t1 = c["train_psnr_db_start_end"]
     h0, h1 = c["held_out_psnr_db_start_end"]
     # measured (profiles/r05/train_loop_convergence.json): training 12.6 -> 35.2 dB, held-out 13.2 -> 23.6 dB
