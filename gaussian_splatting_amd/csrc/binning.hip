@@ -1424,14 +1424,17 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_overflow(const int* __
     }
 }
 
+// sort_too = false: only the emit; the caller's repair render sorts each flagged tile itself (render.hip
+// k_render_fwd_flagged: one launch less on the frames without a flagged tile, i.e. nearly all)
 int depth_cut_repair(const float* bin_records, int N, int ntx, int nty, float mh, int row0, int row1,
                      const int* full_ranges, int32_t* workspace, int32_t* cut_ws, uint64_t* okeys, int64_t ocap,
-                     int* osorted, const int* flags, hipStream_t s) {
+                     int* osorted, const int* flags, hipStream_t s, bool sort_too) {
     const int T = ntx * nty, t0 = row0 * ntx, Tb = (row1 - row0) * ntx;
     if (Tb <= 0) return GS_OK;
     const CutState cs = cut_state_of(cut_ws, N, T);
     k_bin_emit_buckets<2, PRIV_BLOCK><<<NBK, PRIV_BLOCK, sizeof(int) * (size_t)Tb, s>>>(
         bin_records, ntx, nty, mh, row0, row1, full_ranges, workspace + T, okeys, ocap, flags, cs);
+    if (!sort_too) return GS_OK;
     static std::atomic<uint64_t> seen{0};
     if (first_call_on_this_device(seen))
         (void)hipFuncSetAttribute((const void*)k_tile_sort_overflow, hipFuncAttributeMaxDynamicSharedMemorySize,

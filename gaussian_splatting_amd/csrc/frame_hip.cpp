@@ -69,6 +69,10 @@ bool g_sort_prefix = true, g_early_render = true;
 // bands of fewer than 1500 tiles whose lists average >= 192 entries: a multi-GPU rank's band), 1 = always, -1 = never
 int g_segments = 0;
 bool g_band_compact = true;   // multi-GPU: band-compact per-Gaussian stage (OwnerPreprocess)
+// band-compact frames: the fused frontend (gs_band_frontend, ABI 8) and the gathering per-Gaussian backward; false =
+// the three-call pipeline of rounds 3-5 (gs_band_project, gs_halo_plan_masked, gs_preprocess_forward_list;
+// gs_halo_gather_sum), kept for A/B measurements and as the checker of the fused form (tests/test_gpu_band_frontend.py)
+bool g_band_fused = true;
 // depth cut: 0 = auto (whole frames in the LDS-histogram regime whose lists averaged g_cut_min_mean_list entries or
 // more in an earlier frame of the same shape), 1 = always (where supported), -1 = never
 int g_depth_cut = 0;
@@ -748,9 +752,15 @@ struct FrameRec {
     Tensor packed, rgbr, ranges, sorted_g, center, rank_t, opa_act, halo_mask, halo_send, halo_ws;
     RenderOut out;
     int64_t V = 0, L = 0, S = 0, v_lo = 0, v_hi = 0;
-    bool compact = false;
+    bool compact = false, fused = false;   // fused: compact through gs_band_frontend (its workspace layout in halo_ws)
     std::vector<int64_t> send_splits, recv_splits;
     Tensor owned_rows, rendered_uv_grad;
+    // band-compact frames: the received rows and their per-sender offsets, handed from the render node's backward to
+    // the per-Gaussian backward, which sums them on the spot (gs_preprocess_backward_gathered) unless somebody needs
+    // the owned rows as a tensor (uv.grad retained, a loss term on uv)
+    Tensor recv_rows;
+    std::vector<int32_t> recv_offsets;
+    bool gather_pending = false;
     // the uv output (weak: the record must not keep its own graph alive), to see whether its gradient is retained
     c10::weak_intrusive_ptr<c10::TensorImpl, c10::UndefinedTensorImpl> uv_weak{
         c10::intrusive_ptr<c10::TensorImpl, c10::UndefinedTensorImpl>()};
@@ -804,7 +814,9 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
         // band-compact per-Gaussian stage (csrc/preprocess.hip): the full evaluation only for the Gaussians that can
         // reach the band, arrays compacted to those rows (row index l); everything downstream then works on rows l
         const bool compact = g_band_compact && G > 1;
+        const bool fused = compact && g_band_fused;
         fr.compact = compact;
+        fr.fused = fused;
         void* stream = cur_stream();
 
         const int64_t n_ws = (int64_t)gs_preprocess_workspace_ints(N), n_tc = (int64_t)gs_tile_workspace_ints(T);
@@ -818,7 +830,7 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
         uint8_t* mask = (uint8_t*)iar.ptr<int32_t>(6);
         float *center = far.ptr<float>(0), *uv = far.ptr<float>(1), *xyz_cam = far.ptr<float>(2), *conic = far.ptr<float>(3),
               *opa = far.ptr<float>(4), *rgbr = far.ptr<float>(5), *packed = far.ptr<float>(6), *uv_l = far.ptr<float>(7);
-        const int64_t n_hw = (int64_t)gs_halo_workspace_ints(N, G);
+        const int64_t n_hw = fused ? (int64_t)gs_band_frontend_workspace_ints(N, G) : (int64_t)gs_halo_workspace_ints(N, G);
         Tensor hbuf = torch::empty({2 * (int64_t)N + n_hw}, torch::TensorOptions().dtype(torch::kInt32).device(dev));
         int32_t* h = hbuf.data_ptr<int32_t>();
         int32_t* record = ranges_buf + T + 2;
@@ -834,7 +846,22 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
             std::tie(host, ready) = pinned_slot((int)dev.index());
         }
         const int rec_at = compact ? 3 : 2;   // where the plan record starts in the host buffer
-        if (compact) {
+        if (fused) {
+            // the fused band frontend: cull + band masks, scan, compaction of the API arrays and of the band's rows,
+            // evaluation of the band's rows, the exchange plan (device + pinned host) -- four launches
+            // h: list_g[N] | send_index[N] | frontend workspace
+            timed("gs_band_frontend", stream, [&] {
+                return gs_band_frontend(fr.xyz.data_ptr(), fr.quaternion.data_ptr(), fr.scale.data_ptr(), fr.opacity.data_ptr(),
+                                        fr.rgb.data_ptr(), has_sh ? fr.sh.data_ptr() : nullptr, n_sh, fr.camera_T_world.data_ptr(),
+                                        fr.K.data_ptr(), N, W, H, (float)fr.near_thresh, (float)fr.far_thresh, (float)fr.padding,
+                                        (float)fr.mh_dist, sp.bounds.data(), sp.owner_blocks.data(), G, me, h + 2 * (int64_t)N,
+                                        center, mask, rank, uv, opa, h + N, h, uv_l, xyz_cam, conic, packed, record,
+                                        host + rec_at, stream);
+            });
+            bin_uv = uv_l;
+            items_n = record;   // record[0] = rows of the send list = rows of the compact arrays
+            rgbr = packed;      // (the one-coefficient render reads the colour from the record)
+        } else if (compact) {
             timed("gs_band_project", stream, [&] {
                 return gs_band_project(fr.xyz.data_ptr(), fr.scale.data_ptr(), fr.opacity.data_ptr(), fr.camera_T_world.data_ptr(),
                                        fr.K.data_ptr(), N, W, H, (float)fr.near_thresh, (float)fr.far_thresh, (float)fr.padding,
@@ -988,7 +1015,7 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
     static variable_list backward(AutogradContext* ctx, variable_list g) {
         variable_list out(7);
         FrameRec& fr = frame_of(ctx->saved_data["fr"].toTensor());
-        if (!fr.owned_rows.defined()) {
+        if (!fr.owned_rows.defined() && !fr.gather_pending) {
             // the render node's backward did not run (no loss term on the image).  A loss on uv alone would be
             // dropped silently: its gradient reaches only the owned rows through the render node's exchange
             TORCH_CHECK(!g[0].defined(),
@@ -998,8 +1025,31 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
         }
         const auto dev = fr.xyz.device();
         const int n_sh = fr.n_sh;
+        const ShardSpec& sp = fr.spec;
         Tensor owned = fr.owned_rows;
         fr.owned_rows = Tensor();
+        Tensor recv = fr.recv_rows;
+        fr.recv_rows = Tensor();
+        bool gathered = fr.gather_pending;
+        fr.gather_pending = false;
+        {
+            // a loss term put directly on uv needs the owned rows as a tensor after all
+            const Tensor& gu = g[0];
+            const Tensor& rendered0 = fr.rendered_uv_grad;
+            const bool extra_uv = gu.defined() && fr.v_hi > fr.v_lo && gu.stride(0) != 0 &&
+                                  !(rendered0.defined() && gu.unsafeGetTensorImpl() == rendered0.unsafeGetTensorImpl());
+            if (gathered && extra_uv) {
+                const int64_t n_own = fr.v_hi - fr.v_lo;
+                owned = torch::empty({std::max<int64_t>(n_own, 1), SLAB_WIDTH}, recv.options()).narrow(0, 0, n_own);
+                void* stream = cur_stream();
+                timed("gs_halo_gather_sum", stream, [&] {
+                    return gs_band_gather_sum(fr.halo_ws.data_ptr<int32_t>(), fr.N, sp.G, sp.rank, sp.owner_blocks.data(),
+                                              fr.rank_t.data_ptr<int32_t>(), (int)fr.v_lo, recv.data_ptr(),
+                                              fr.recv_offsets.data(), owned.data_ptr(), stream);
+                });
+                gathered = false;
+            }
+        }
         // a loss term put directly on uv arrives on top of what node 2 handed over (the owned rows' uv columns,
         // or a stride-0 placeholder): add the rest for the owned rows
         const Tensor& g_uv = g[0];
@@ -1018,6 +1068,14 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
             void* stream = cur_stream();
             const int64_t i0 = fr.i0;
             timed("gs_preprocess_backward", stream, [&] {
+                if (gathered)
+                    return gs_preprocess_backward_gathered(
+                        fr.xyz.data_ptr<float>() + 3 * i0, fr.quaternion.data_ptr<float>() + 4 * i0,
+                        fr.scale.data_ptr<float>() + 3 * i0, n_sh, fr.camera_T_world.data_ptr(), fr.K.data_ptr(),
+                        fr.center.data_ptr(), fr.rank_t.data_ptr<int32_t>() + i0, fr.opa_act.data_ptr(),
+                        fr.halo_ws.data_ptr<int32_t>(), fr.N, sp.G, sp.rank, sp.owner_blocks.data(), recv.data_ptr(),
+                        fr.recv_offsets.data(), (int)n, ga.ptr<float>(0), ga.ptr<float>(1), ga.ptr<float>(2),
+                        ga.ptr<float>(3), ga.ptr<float>(4), n_sh > 1 ? ga.ptr<float>(5) : nullptr, stream);
                 return gs_preprocess_backward(fr.xyz.data_ptr<float>() + 3 * i0, fr.quaternion.data_ptr<float>() + 4 * i0,
                                               fr.scale.data_ptr<float>() + 3 * i0, n_sh, fr.camera_T_world.data_ptr(),
                                               fr.K.data_ptr(), fr.center.data_ptr(), fr.rank_t.data_ptr<int32_t>() + i0,
@@ -1119,25 +1177,39 @@ struct OwnerRender : public torch::autograd::Function<OwnerRender> {
                          [&] { sp.pg->alltoall_base(recv, send, fr.recv_splits, fr.send_splits)->wait(); });
         }
         const int64_t n_own = fr.v_hi - fr.v_lo;
-        Tensor owned = torch::empty({std::max<int64_t>(n_own, 1), SLAB_WIDTH}, slab.options()).narrow(0, 0, n_own);
-        if (n_own > 0) {
-            std::vector<int32_t> offs(sp.G);
+        std::vector<int32_t> offs(sp.G);
+        {
             int32_t off = 0;
             for (int s2 = 0; s2 < sp.G; s2++) {
                 offs[s2] = off;
                 off += (int32_t)fr.recv_splits[s2];
             }
-            timed("gs_halo_gather_sum", stream, [&] {
-                return gs_halo_gather_sum((const uint32_t*)fr.halo_mask.data_ptr<int32_t>(), fr.halo_ws.data_ptr<int32_t>(), fr.N,
-                                          sp.G, sp.rank, (int)fr.v_lo, (int)fr.v_hi, recv.data_ptr(), offs.data(),
-                                          owned.data_ptr(), stream);
-            });
         }
-        fr.owned_rows = owned;
         // uv.grad (trainer.py:360,379): the complete rows of the owned Gaussians, zeros elsewhere -- materialised
         // only when somebody retains it; a stride-0 zero routes the backward otherwise
         bool retained = false;
         if (auto impl = fr.uv_weak.lock()) retained = Tensor(std::move(impl)).retains_grad();
+        Tensor owned;
+        if (fr.fused && !retained) {
+            // fused band frames: the per-Gaussian backward sums the received rows itself (no [owned, 9] round trip)
+            fr.recv_rows = recv;
+            fr.recv_offsets = offs;
+            fr.gather_pending = true;
+        } else {
+            owned = torch::empty({std::max<int64_t>(n_own, 1), SLAB_WIDTH}, slab.options()).narrow(0, 0, n_own);
+            if (n_own > 0) {
+                timed("gs_halo_gather_sum", stream, [&] {
+                    if (fr.fused)
+                        return gs_band_gather_sum(fr.halo_ws.data_ptr<int32_t>(), fr.N, sp.G, sp.rank, sp.owner_blocks.data(),
+                                                  fr.rank_t.data_ptr<int32_t>(), (int)fr.v_lo, recv.data_ptr(), offs.data(),
+                                                  owned.data_ptr(), stream);
+                    return gs_halo_gather_sum((const uint32_t*)fr.halo_mask.data_ptr<int32_t>(), fr.halo_ws.data_ptr<int32_t>(),
+                                              fr.N, sp.G, sp.rank, (int)fr.v_lo, (int)fr.v_hi, recv.data_ptr(), offs.data(),
+                                              owned.data_ptr(), stream);
+                });
+            }
+            fr.owned_rows = owned;
+        }
         Tensor g_uv;
         if (retained) {
             g_uv = torch::zeros({V, 2}, slab.options());
@@ -1384,6 +1456,7 @@ void set_depth_cut(int mode, int64_t min_mean_list) {
     if (min_mean_list > 0) g_cut_min_mean_list = min_mean_list;
 }
 void set_band_compact(bool on) { g_band_compact = on; }
+void set_band_fused(bool on) { g_band_fused = on; }
 
 void set_modes(bool sort_prefix, bool early_render) {
     g_sort_prefix = sort_prefix;
@@ -1415,6 +1488,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("debug_set_longest_list_hints", &debug_set_longest_list_hints, py::arg("value"));
     m.def("set_depth_cut", &set_depth_cut, py::arg("mode"), py::arg("min_mean_list") = 0);
     m.def("set_band_compact", &set_band_compact, py::arg("on"));
+    m.def("set_band_fused", &set_band_fused, py::arg("on"));
     m.def("last_tile_flags", &last_tile_flags, py::arg("clear") = false);
     m.def("enable_timing", &enable_timing, py::arg("on"), py::arg("only") = std::string());
     m.def("reserve_events", &reserve_events);

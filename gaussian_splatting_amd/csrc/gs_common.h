@@ -235,7 +235,7 @@ __host__ __device__ inline CutState cut_state_of(int32_t* ws, int N, int T) {
 // frame's flagged-tile counter inside the cut workspace
 int depth_cut_repair(const float* bin_records, int N, int ntx, int nty, float mh, int row0, int row1,
                      const int* full_ranges, int32_t* workspace, int32_t* cut_ws, uint64_t* okeys, int64_t ocap,
-                     int* osorted, const int* flags, hipStream_t s);
+                     int* osorted, const int* flags, hipStream_t s, bool sort_too = true);
 int* depth_cut_flag_counter(int32_t* cut_ws, int N, int T);
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }

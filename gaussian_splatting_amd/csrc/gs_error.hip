@@ -28,5 +28,5 @@ int check_launch(const char* what) {
 
 extern "C" {
 const char* gs_last_error(void) { return gs::g_err; }
-int gs_abi_version(void) { return 7; }
+int gs_abi_version(void) { return 8; }
 }

@@ -444,6 +444,32 @@ __device__ inline float rotation_norm2_bound(const float* __restrict__ M) {
     return best;
 }
 
+// bit s = the Gaussian CAN reach the tile rows of band s: the candidate window of tile_culling.cu:138-156 with its
+// radius bounded from the largest scale (see the block comment above) -- a superset of the exact window, the same
+// on every rank
+__device__ inline uint32_t band_mask_bound(const float* c, const float* uv, const float* __restrict__ scale3,
+                                           const float* __restrict__ M, const float* __restrict__ K, float mh, int nty,
+                                           const BandRows& rows, int G) {
+    const float s_max = fmaxf(fmaxf(det_expf(scale3[0]), det_expf(scale3[1])), det_expf(scale3[2]));
+    const float iz = 1.0f / c[2];
+    const float jx = K[0] * iz, jy = K[4] * iz, tx = K[0] * c[0] * iz * iz, ty = K[4] * c[1] * iz * iz;
+    const float A = jx * jx + tx * tx, C = jy * jy + ty * ty, B = tx * ty;
+    const float lam = 0.5f * (A + C) + __builtin_sqrtf(0.25f * (A - C) * (A - C) + B * B);
+    const float l1 = s_max * s_max * rotation_norm2_bound(M) * lam * 1.001f + 0.25f;
+    const float rt = __builtin_ceilf(mh * __builtin_sqrtf(l1) * 1.001f / 16.0f) + 1.0f;
+    uint32_t m = 0;
+    if (rt < 1.0e6f) {
+        const int r = (int)rt;
+        const int py = f2i(__builtin_floorf(uv[1] / 16.0f));
+        const int sy = max(0, py - r), ey = min(nty, py + r);
+        for (int s2 = 0; s2 < G; s2++)
+            if (sy < rows.v[s2 + 1] && ey > rows.v[s2] && sy < ey) m |= 1u << s2;
+    } else {
+        m = (1u << G) - 1;   // unbounded or not a number: every band (a superset is always safe)
+    }
+    return m;
+}
+
 template <int PASS>   // 0: count per block; 1: write
 __global__ __launch_bounds__(PP_BLOCK) void k_band_project(
     const float* __restrict__ xyz, const float* __restrict__ scale, const float* __restrict__ opacity,
@@ -474,25 +500,7 @@ __global__ __launch_bounds__(PP_BLOCK) void k_band_project(
     uv_out[v * 2 + 0] = uv[0];
     uv_out[v * 2 + 1] = uv[1];
     opa_out[v] = sigmoid_det(opacity[g]);
-    // upper bound of the candidate window's radius in tiles
-    const float s_max = fmaxf(fmaxf(det_expf(scale[g * 3 + 0]), det_expf(scale[g * 3 + 1])), det_expf(scale[g * 3 + 2]));
-    const float iz = 1.0f / c[2];
-    const float jx = K[0] * iz, jy = K[4] * iz, tx = K[0] * c[0] * iz * iz, ty = K[4] * c[1] * iz * iz;
-    const float A = jx * jx + tx * tx, C = jy * jy + ty * ty, B = tx * ty;
-    const float lam = 0.5f * (A + C) + __builtin_sqrtf(0.25f * (A - C) * (A - C) + B * B);
-    const float l1 = s_max * s_max * rotation_norm2_bound(M) * lam * 1.001f + 0.25f;
-    const float rt = __builtin_ceilf(mh * __builtin_sqrtf(l1) * 1.001f / 16.0f) + 1.0f;
-    uint32_t m = 0;
-    if (rt < 1.0e6f) {
-        const int r = (int)rt;
-        const int py = f2i(__builtin_floorf(uv[1] / 16.0f));
-        const int sy = max(0, py - r), ey = min(nty, py + r);
-        for (int s2 = 0; s2 < G; s2++)
-            if (sy < rows.v[s2 + 1] && ey > rows.v[s2] && sy < ey) m |= 1u << s2;
-    } else {
-        m = (1u << G) - 1;   // unbounded or not a number: every band (a superset is always safe)
-    }
-    mask[v] = m;
+    mask[v] = band_mask_bound(c, uv, scale + (size_t)g * 3, M, K, mh, nty, rows, G);
 }
 
 // per-256-block counts of every mask bit, by VISIBLE index (the layout gs_halo_plan's scan expects)
@@ -579,6 +587,289 @@ __global__ __launch_bounds__(PP_BLOCK) void k_preprocess_list(
     dst[2] = make_float4(pk[8], pk[9], pk[10], pk[11]);
 }
 
+// ---- multi-GPU: the fused band frontend (ABI 8) ---------------------------------------------------------------
+// gs_band_project + gs_halo_plan_masked + gs_preprocess_forward_list were nine launches (cull count, scan, project,
+// bit counts, scan of G rows, send list + bounds, list evaluation: 0.14 of a rank's 0.49 ms at 8 ranks) that read xyz
+// three times and chained list -> visible index -> Gaussian index gathers.  Four launches here, every count by
+// GAUSSIAN-index block -- owner slices are whole blocks of the Gaussian index, so the exchange plan is 2 G
+// differences of scanned offsets and the receive layout needs no visible-index bookkeeping:
+//   k_band_count   every Gaussian: transform, cull, band mask (band_mask_bound) -> gmask[g] (bit 15 = visible, bit s =
+//                  can reach band s) and per-block counts of the visible Gaussians (row 0) and of every band's
+//                  Gaussians (row 1 + s); the camera centre
+//   k_band_scan    one workgroup per row: exclusive prefix per block, total at [nb]
+//   k_band_write   every Gaussian again: culling mask, rank, uv[v], sigmoid(opacity)[v] (API + owned backward), and
+//                  for the Gaussians of MY band -- rows l = row (1 + me)'s prefix, ascending in g, hence in v: the
+//                  send list -- send_index[l] = v, list_g[l] = g, uv_l[l], xyz_cam_l[l], the opacity slot of
+//                  packed_l[l] and the world position (staged in conic_l[l]); its extra workgroup writes the plan
+//   k_band_rows    row l: Sigma, J, conic, SH colour, packed record (k_preprocess_list's evaluation: the same device
+//                  functions in the same order, the same bits) from coalesced reads of what k_band_write left plus
+//                  gathers of quaternion / scale / rgb / sh
+struct BandOwners {
+    int v[GS_MAX_RANKS + 1];   // owner slices in 256-blocks of the Gaussian index
+};
+
+__global__ __launch_bounds__(PP_BLOCK) void k_band_count(
+    const float* __restrict__ xyz, const float* __restrict__ scale, const float* __restrict__ M,
+    const float* __restrict__ K, int N, Frustum fr, float mh, int nty, BandRows rows, int G,
+    int* __restrict__ counts, int nbp, uint16_t* __restrict__ gmask, float* __restrict__ center) {
+    __shared__ int s_cnt[GS_MAX_RANKS + 1][PP_BLOCK / GS_WAVE];
+    const int g = blockIdx.x * PP_BLOCK + threadIdx.x;
+    if (g == 0) camera_center(M, center);
+    uint32_t m = 0;
+    if (g < N) {
+        float c[3], uv[2];
+        to_camera(M, xyz[g * 3 + 0], xyz[g * 3 + 1], xyz[g * 3 + 2], c);
+        if (!is_culled(c, K, fr, uv)) m = 0x8000u | band_mask_bound(c, uv, scale + (size_t)g * 3, M, K, mh, nty, rows, G);
+        gmask[g] = (uint16_t)m;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        const int n = __popcll(__ballot((m >> 15) & 1u));
+        if (lane == 0) s_cnt[0][wave] = n;
+    }
+    for (int s2 = 0; s2 < G; s2++) {
+        const int n = __popcll(__ballot((m >> s2) & 1u));
+        if (lane == 0) s_cnt[1 + s2][wave] = n;
+    }
+    __syncthreads();
+    if (threadIdx.x <= G)
+        counts[threadIdx.x * nbp + blockIdx.x] =
+            s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
+}
+
+// row r of counts[.][nbp] (nb entries used) -> exclusive prefix in row r of offsets, the total at [nb]
+__global__ __launch_bounds__(1024) void k_band_scan(const int* __restrict__ counts, int nb, int nbp,
+                                                    int* __restrict__ offsets) {
+    __shared__ int s_wave[16];
+    __shared__ int s_carry;
+    counts += (size_t)blockIdx.x * nbp;
+    offsets += (size_t)blockIdx.x * nbp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 4096) {
+        int v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = base + tid * 4 + k;
+            v[k] = i < nb ? counts[i] : 0;
+            sum += v[k];
+        }
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int off = s_carry;
+        for (int w = 0; w < wave; w++) off += s_wave[w];
+        int run = off + incl - sum;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = base + tid * 4 + k;
+            if (i < nb) offsets[i] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = run;
+        __syncthreads();
+    }
+    if (tid == 0) offsets[nb] = s_carry;
+}
+
+__global__ __launch_bounds__(PP_BLOCK) void k_band_write(
+    const float* __restrict__ xyz, const float* __restrict__ opacity, const float* __restrict__ M,
+    const float* __restrict__ K, int N, Frustum fr, const uint16_t* __restrict__ gmask,
+    const int* __restrict__ offsets, int nb, int nbp, int G, int me, BandOwners owners,
+    uint8_t* __restrict__ culled, int* __restrict__ rank, float* __restrict__ uv_out, float* __restrict__ opa_out,
+    int* __restrict__ send_index, int* __restrict__ list_g, float* __restrict__ uv_l, float* __restrict__ xyz_cam_l,
+    float* __restrict__ p_stage /* conic_l: the world position until k_band_rows replaces it */,
+    float* __restrict__ packed_l, int* __restrict__ plan, int* __restrict__ plan_host) {
+    if ((int)blockIdx.x == nb) {
+        // the extra workgroup: the frame's plan record (rows of my list, V, v_lo, v_hi, send[G], recv[G]) from the
+        // scanned offsets at the owner slices' block boundaries
+        const int t = threadIdx.x;
+        auto at = [&](int row, int blk) { return offsets[row * nbp + min(blk, nb)]; };
+        int val = 0;
+        if (t == 0) val = at(1 + me, nb);
+        else if (t == 1) val = at(0, nb);
+        else if (t == 2) val = at(0, owners.v[me]);
+        else if (t == 3) val = at(0, owners.v[me + 1]);
+        else if (t < 4 + G) val = at(1 + me, owners.v[t - 4 + 1]) - at(1 + me, owners.v[t - 4]);          // rows I send to owner t - 4
+        else if (t < 4 + 2 * G) val = at(1 + t - 4 - G, owners.v[me + 1]) - at(1 + t - 4 - G, owners.v[me]);   // rows from sender t - 4 - G
+        if (t < 4 + 2 * G) {
+            plan[t] = val;
+            if (plan_host != nullptr) plan_host[t] = val;
+        }
+        if (plan_host != nullptr) __threadfence_system();
+        return;
+    }
+    __shared__ int s_vis[PP_BLOCK / GS_WAVE], s_mine[PP_BLOCK / GS_WAVE];
+    const int g = blockIdx.x * PP_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t m = g < N ? gmask[g] : 0u;
+    const bool vis = (m >> 15) & 1u, mine = (m >> me) & 1u;
+    const unsigned long long bv = __ballot(vis), bm = __ballot(mine);
+    if (lane == 0) {
+        s_vis[wave] = __popcll(bv);
+        s_mine[wave] = __popcll(bm);
+    }
+    __syncthreads();
+    if (g >= N) return;
+    culled[g] = vis ? 0 : 1;
+    int v = offsets[blockIdx.x] + __popcll(bv & ((1ull << lane) - 1));
+    int l = offsets[(1 + me) * nbp + blockIdx.x] + __popcll(bm & ((1ull << lane) - 1));
+    for (int w = 0; w < wave; w++) {
+        v += s_vis[w];
+        l += s_mine[w];
+    }
+    rank[g] = vis ? v : -1;
+    if (!vis) return;
+    const float p[3] = {xyz[g * 3 + 0], xyz[g * 3 + 1], xyz[g * 3 + 2]};
+    float c[3], uv[2];
+    to_camera(M, p[0], p[1], p[2], c);
+    (void)is_culled(c, K, fr, uv);   // (uv: the expression every other kernel uses)
+    uv_out[v * 2 + 0] = uv[0];
+    uv_out[v * 2 + 1] = uv[1];
+    const float opa = sigmoid_det(opacity[g]);
+    opa_out[v] = opa;
+    if (!mine) return;
+    send_index[l] = v;
+    list_g[l] = g;
+    uv_l[l * 2 + 0] = uv[0];
+    uv_l[l * 2 + 1] = uv[1];
+    xyz_cam_l[l * 3 + 0] = c[0];
+    xyz_cam_l[l * 3 + 1] = c[1];
+    xyz_cam_l[l * 3 + 2] = c[2];
+    p_stage[l * 3 + 0] = p[0];
+    p_stage[l * 3 + 1] = p[1];
+    p_stage[l * 3 + 2] = p[2];
+    packed_l[(size_t)l * GS_PACKED_WIDTH + 3] = opa;
+}
+
+template <int N_SH>
+__global__ __launch_bounds__(PP_BLOCK) void k_band_rows(
+    const float* __restrict__ quat, const float* __restrict__ scale, const float* __restrict__ rgb,
+    const float* __restrict__ sh, const float* __restrict__ M, const float* __restrict__ K,
+    const float* __restrict__ center, const int* __restrict__ list_g, const int* __restrict__ list_count,
+    const float* __restrict__ uv_l, const float* __restrict__ xyz_cam_l, float* __restrict__ conic_l,
+    float* __restrict__ packed_l) {
+    constexpr int SHW = 3 * (N_SH - 1);
+    // (the SH row is walked by its own lane: a row-cooperative fetch -- twelve lanes per row, 16-byte chunks through
+    // wave-private LDS -- was measured and is 24 % slower, scripts/experiments/list_coop_sh_fetch.patch)
+    const int l = blockIdx.x * PP_BLOCK + threadIdx.x;
+    const bool act = l < *list_count;
+    if (!act) return;
+    const int g = list_g[l];
+    float col[3] = {0, 0, 0}, p[3] = {0, 0, 0}, c[3] = {0, 0, 1}, uv[2] = {0, 0}, opa = 0;
+    float q4[4] = {1, 0, 0, 0}, s3[3] = {0, 0, 0}, c0[3] = {0, 0, 0};
+    if (act) {
+        p[0] = conic_l[l * 3 + 0]; p[1] = conic_l[l * 3 + 1]; p[2] = conic_l[l * 3 + 2];
+        c[0] = xyz_cam_l[l * 3 + 0]; c[1] = xyz_cam_l[l * 3 + 1]; c[2] = xyz_cam_l[l * 3 + 2];
+        uv[0] = uv_l[l * 2 + 0]; uv[1] = uv_l[l * 2 + 1];
+        opa = packed_l[(size_t)l * GS_PACKED_WIDTH + 3];
+        const float4 q = *reinterpret_cast<const float4*>(quat + (size_t)g * 4);
+        q4[0] = q.x; q4[1] = q.y; q4[2] = q.z; q4[3] = q.w;
+        s3[0] = scale[g * 3 + 0]; s3[1] = scale[g * 3 + 1]; s3[2] = scale[g * 3 + 2];
+        c0[0] = rgb[g * 3 + 0]; c0[1] = rgb[g * 3 + 1]; c0[2] = rgb[g * 3 + 2];
+    }
+    if constexpr (N_SH == 1) {
+        col[0] = c0[0]; col[1] = c0[1]; col[2] = c0[2];
+    } else {
+        float Y[N_SH];
+        if (act) {
+            float d[3] = {p[0] - center[0], p[1] - center[1], p[2] - center[2]};
+            const float r = 1.0f / __builtin_sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            d[0] *= r; d[1] *= r; d[2] *= r;
+            sh_basis<float, N_SH>(d, Y);
+        }
+        auto colour_from = [&](const float* shg) {   // precompute_sh.cu:28-55, coefficient 0 = rgb (rasterize.py:89)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                float t = 0;
+                t += Y[0] * c0[ch];
+#pragma unroll
+                for (int s2 = 1; s2 < N_SH; s2++) t += Y[s2] * shg[(N_SH - 1) * ch + (s2 - 1)];
+                t *= GS_R_SH_0;
+                col[ch] = t;
+            }
+        };
+        if (act) colour_from(sh + (size_t)g * SHW);
+    }
+    if (!act) return;
+    float S9[9], W[9], J6[6], c3[3];
+    sigma_world_of(q4, s3, S9);
+    load_rotation(M, W);
+    J6[0] = K[0] / c[2];                       // projection.cu:169-174
+    J6[1] = 0;
+    J6[2] = -K[0] * c[0] / (c[2] * c[2]);
+    J6[3] = 0;
+    J6[4] = K[4] / c[2];
+    J6[5] = -K[4] * c[1] / (c[2] * c[2]);
+    conic_of(J6, W, S9, c3);
+    conic_l[l * 3 + 0] = c3[0];
+    conic_l[l * 3 + 1] = c3[1];
+    conic_l[l * 3 + 2] = c3[2];
+    float pk[GS_PACKED_WIDTH];
+    pack_record<float>(uv[0], uv[1], c3, opa, col, pk);
+    float4* dst = reinterpret_cast<float4*>(packed_l + (size_t)l * GS_PACKED_WIDTH);
+    dst[0] = make_float4(pk[0], pk[1], pk[2], pk[3]);
+    dst[1] = make_float4(pk[4], pk[5], pk[6], pk[7]);
+    dst[2] = make_float4(pk[8], pk[9], pk[10], pk[11]);
+}
+
+// the receive side of the gradient exchange by Gaussian-index blocks: sender s's rows for my slice are its band's
+// Gaussians inside [256 owners[me], 256 owners[me + 1]), ascending, so the row of Gaussian g from sender s sits at
+// (offsets[1 + s][block of g] - offsets[1 + s][owners[me]]) + (the bit-s Gaussians of g's block in front of g)
+struct GatherPlan {
+    const uint16_t* gmask;   // [N]
+    const int* offsets;      // [G + 1][nbp]
+    const float* recv;       // [sum of recv counts][9]
+    int nbp, G, blk0;        // blk0 = owners[me]
+    int recv_off[GS_MAX_RANKS];
+};
+// -> true and row[9] = the sum over the senders (ascending) of the received rows of Gaussian g; every thread of the
+// workgroup must call it (ballots + a barrier).  blk = the 256-block of g, tid = its index inside the block
+__device__ inline uint32_t gather_row(const GatherPlan& gp, int blk, int g, bool in_range, float* row,
+                                      int (*s_cnt)[PP_BLOCK / GS_WAVE]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t m = in_range ? gp.gmask[g] : 0u;
+    unsigned long long bal[GS_MAX_RANKS];
+    for (int s2 = 0; s2 < gp.G; s2++) {
+        bal[s2] = __ballot((m >> s2) & 1u);
+        if (lane == 0) s_cnt[s2][wave] = __popcll(bal[s2]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 9; j++) row[j] = 0;
+    for (int s2 = 0; s2 < gp.G; s2++) {
+        if (((m >> s2) & 1u) == 0) continue;
+        int pos = gp.offsets[(1 + s2) * gp.nbp + blk] - gp.offsets[(1 + s2) * gp.nbp + gp.blk0];
+        for (int w = 0; w < wave; w++) pos += s_cnt[s2][w];
+        pos += __popcll(bal[s2] & ((1ull << lane) - 1));
+        const float* src = gp.recv + (size_t)(gp.recv_off[s2] + pos) * 9;
+#pragma unroll
+        for (int j = 0; j < 9; j++) row[j] += src[j];
+    }
+    return m;
+}
+
+// the owned rows materialised ([v_hi - v_lo, 9] by visible index: what uv.grad of the owned Gaussians is a view of)
+__global__ __launch_bounds__(PP_BLOCK) void k_band_gather_sum(GatherPlan gp, int N, const int* __restrict__ rank, int v_lo,
+                                                              float* __restrict__ out) {
+    __shared__ int s_cnt[GS_MAX_RANKS][PP_BLOCK / GS_WAVE];
+    const int blk = gp.blk0 + blockIdx.x;
+    const int g = blk * PP_BLOCK + threadIdx.x;
+    float row[9];
+    const uint32_t m = gather_row(gp, blk, g, g < N, row, s_cnt);
+    if (!((m >> 15) & 1u)) return;
+    float* o = out + (size_t)(rank[g] - v_lo) * 9;
+#pragma unroll
+    for (int j = 0; j < 9; j++) o[j] = row[j];
+}
+
 struct PreGrad {
     float* xyz;         // [N,3]
     float* quaternion;  // [N,4]
@@ -588,13 +879,22 @@ struct PreGrad {
     float* sh;          // [N,3,N_SH-1] or null
 };
 
-template <int N_SH>
+// GATHER (multi-GPU, owner-sliced backward): the render-gradient row of a Gaussian is not read from a slab but summed
+// on the spot from the rows the all_to_all delivered (gather_row: the senders in ascending order, as
+// k_band_gather_sum adds them -- the same bits) -- no [owned, 9] buffer written and read back, one launch less
+template <int N_SH, bool GATHER = false>
 __global__ __launch_bounds__(PP_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_preprocess_bwd(
     const float* __restrict__ xyz, const float* __restrict__ quat, const float* __restrict__ scale,
     const float* __restrict__ M, const float* __restrict__ K, const float* __restrict__ center,
     const int* __restrict__ rank, const float* __restrict__ opacity_act,
-    const float* __restrict__ g_slab, int v_base, int N, PreGrad o) {
+    const float* __restrict__ g_slab, int v_base, int N, PreGrad o, GatherPlan gp = GatherPlan{}) {
     constexpr int SHW = 3 * (N_SH - 1);
+    __shared__ int s_gather[GATHER ? GS_MAX_RANKS : 1][PP_BLOCK / GS_WAVE];
+    float gathered[9];
+    if constexpr (GATHER) {
+        const int lg = blockIdx.x * PP_BLOCK + threadIdx.x;   // the slice starts at Gaussian 256 gp.blk0
+        gather_row(gp, gp.blk0 + blockIdx.x, gp.blk0 * PP_BLOCK + lg, lg < N, gathered, s_gather);
+    }
     // SH gradients (180 B per Gaussian at degree 3) are staged in LDS and written back as one
     // contiguous block with coalesced 16-byte stores -- half of the workgroup's rows at a time
     // (23 KiB of LDS instead of 46: more resident waves on this HBM-bound kernel)
@@ -615,7 +915,7 @@ __global__ __launch_bounds__(PP_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
         // colour: precompute_sh.cu:61-111, then the split of cat(rgb, sh) (rasterize.py:89)
         // render gradients of visible Gaussian v: row v - v_base of the [*, 9] slab
         // (rgb 3 | opacity 1 | uv 2 | conic 3)
-        const float* gsl = g_slab + (size_t)(v - v_base) * 9;
+        const float* gsl = GATHER ? gathered : g_slab + (size_t)(v - v_base) * 9;
         const float gr[3] = {gsl[0], gsl[1], gsl[2]};
         if constexpr (N_SH == 1) {
             gc[0] = gr[0]; gc[1] = gr[1]; gc[2] = gr[2];
@@ -853,6 +1153,120 @@ int gs_preprocess_forward_list(const void* xyz, const void* quaternion, const vo
                           list_count, vis_idx, (const float*)uv, (const float*)opacity_act, (float*)uv_l,
                           (float*)xyz_camera_frame_l, (float*)conic_l, (float*)packed_l)));
     return check_launch("preprocess_forward_list");
+}
+
+// ---- the fused band frontend (ABI 8) ----
+namespace {
+struct FrontendWs {
+    int nb, nbp;
+    int32_t *counts, *offsets;
+    uint16_t* gmask;
+};
+FrontendWs frontend_ws(int32_t* workspace, int N, int G) {
+    FrontendWs w;
+    w.nb = div_up(N > 0 ? N : 1, PP_BLOCK);
+    w.nbp = w.nb + 1;
+    w.counts = workspace;
+    w.offsets = workspace + (size_t)(G + 1) * w.nbp;
+    w.gmask = reinterpret_cast<uint16_t*>(workspace + 2 * (size_t)(G + 1) * w.nbp);
+    return w;
+}
+GatherPlan gather_plan(const FrontendWs& w, int G, int rank, const int32_t* owner_blocks, const void* recv,
+                       const int32_t* recv_offsets) {
+    GatherPlan gp;
+    gp.gmask = w.gmask;
+    gp.offsets = w.offsets;
+    gp.recv = (const float*)recv;
+    gp.nbp = w.nbp;
+    gp.G = G;
+    gp.blk0 = owner_blocks[rank] < w.nb ? owner_blocks[rank] : w.nb;
+    for (int i = 0; i < GS_MAX_RANKS; i++) gp.recv_off[i] = i < G ? recv_offsets[i] : 0;
+    return gp;
+}
+}  // namespace
+
+size_t gs_band_frontend_workspace_ints(int N, int G) {
+    const size_t nbp = (size_t)div_up(N > 0 ? N : 1, PP_BLOCK) + 1;
+    return 2 * (size_t)(G + 1) * nbp + ((size_t)(N > 0 ? N : 1) + 1) / 2;
+}
+
+int gs_band_frontend(const void* xyz, const void* quaternion, const void* scale, const void* opacity, const void* rgb,
+                     const void* sh, int n_sh, const void* camera_T_world, const void* K, int N, int W, int H,
+                     float near_thresh, float far_thresh, float cull_mask_padding, float mh_dist, const int32_t* band_rows,
+                     const int32_t* owner_blocks, int G, int rank, int32_t* workspace, void* camera_center,
+                     uint8_t* culling_mask, int32_t* rank_out, void* uv, void* opacity_act, int32_t* send_index,
+                     int32_t* list_g, void* uv_l, void* xyz_camera_frame_l, void* conic_l, void* packed_l, int32_t* plan,
+                     int32_t* plan_host, void* stream) {
+    GS_REQUIRE(G >= 1 && G <= GS_MAX_RANKS, "band_frontend: 1 <= G <= %d", GS_MAX_RANKS);
+    GS_REQUIRE(rank >= 0 && rank < G, "band_frontend: bad rank");
+    GS_REQUIRE(N > 0, "band_frontend: N must be positive");
+    GS_REQUIRE(n_sh == 1 || sh != nullptr, "sh must be given when n_sh > 1");
+    hipStream_t s = (hipStream_t)stream;
+    const Frustum fr = make_frustum(W, H, near_thresh, far_thresh, cull_mask_padding);
+    const FrontendWs w = frontend_ws(workspace, N, G);
+    BandRows rows;
+    BandOwners owners;
+    for (int i = 0; i <= GS_MAX_RANKS; i++) {
+        rows.v[i] = i <= G ? band_rows[i] : 0;
+        owners.v[i] = i <= G ? owner_blocks[i] : 0;
+        GS_REQUIRE(i == 0 || i > G || owner_blocks[i] >= owner_blocks[i - 1], "band_frontend: owner_blocks must ascend");
+    }
+    const int nty = (H + GS_TILE - 1) / GS_TILE;
+    k_band_count<<<w.nb, PP_BLOCK, 0, s>>>((const float*)xyz, (const float*)scale, (const float*)camera_T_world,
+                                           (const float*)K, N, fr, mh_dist, nty, rows, G, w.counts, w.nbp, w.gmask,
+                                           (float*)camera_center);
+    k_band_scan<<<G + 1, 1024, 0, s>>>(w.counts, w.nb, w.nbp, w.offsets);
+    k_band_write<<<w.nb + 1, PP_BLOCK, 0, s>>>((const float*)xyz, (const float*)opacity, (const float*)camera_T_world,
+                                               (const float*)K, N, fr, w.gmask, w.offsets, w.nb, w.nbp, G, rank, owners,
+                                               culling_mask, rank_out, (float*)uv, (float*)opacity_act, send_index, list_g,
+                                               (float*)uv_l, (float*)xyz_camera_frame_l, (float*)conic_l, (float*)packed_l,
+                                               plan, plan_host);
+    // rows of my list: offsets[1 + rank][nb] (device side); the grid covers the capacity, the surplus exits at once
+    const int32_t* list_count = w.offsets + (size_t)(1 + rank) * w.nbp + w.nb;
+    DISPATCH_SH(n_sh, (k_band_rows<N_SH><<<w.nb, PP_BLOCK, 0, s>>>(
+                          (const float*)quaternion, (const float*)scale, (const float*)rgb, (const float*)sh,
+                          (const float*)camera_T_world, (const float*)K, (const float*)camera_center, list_g, list_count,
+                          (const float*)uv_l, (const float*)xyz_camera_frame_l, (float*)conic_l, (float*)packed_l)));
+    return check_launch("band_frontend");
+}
+
+int gs_band_gather_sum(const int32_t* workspace, int N, int G, int rank, const int32_t* owner_blocks,
+                       const int32_t* rank_of_gaussian, int v_lo, const void* recv, const int32_t* recv_offsets, void* out,
+                       void* stream) {
+    GS_REQUIRE(G >= 1 && G <= GS_MAX_RANKS && rank >= 0 && rank < G, "band_gather_sum: bad G / rank");
+    const FrontendWs w = frontend_ws(const_cast<int32_t*>(workspace), N, G);
+    const GatherPlan gp = gather_plan(w, G, rank, owner_blocks, recv, recv_offsets);
+    const int blk1 = owner_blocks[rank + 1] < w.nb ? owner_blocks[rank + 1] : w.nb;
+    if (blk1 <= gp.blk0) return GS_OK;
+    k_band_gather_sum<<<blk1 - gp.blk0, PP_BLOCK, 0, (hipStream_t)stream>>>(gp, N, rank_of_gaussian, v_lo, (float*)out);
+    return check_launch("band_gather_sum");
+}
+
+int gs_preprocess_backward_gathered(const void* xyz, const void* quaternion, const void* scale, int n_sh,
+                                    const void* camera_T_world, const void* K, const void* camera_center,
+                                    const int32_t* rank_of_gaussian, const void* opacity_act, const int32_t* workspace,
+                                    int N_total, int G, int rank, const int32_t* owner_blocks, const void* recv,
+                                    const int32_t* recv_offsets, int n, void* grad_xyz, void* grad_quaternion,
+                                    void* grad_scale, void* grad_opacity_logit, void* grad_rgb_param, void* grad_sh,
+                                    void* stream) {
+    GS_REQUIRE(n_sh == 1 || grad_sh != nullptr, "grad_sh must be given when n_sh > 1");
+    GS_REQUIRE(G >= 1 && G <= GS_MAX_RANKS && rank >= 0 && rank < G, "preprocess_backward_gathered: bad G / rank");
+    if (n <= 0) return GS_OK;
+    const FrontendWs w = frontend_ws(const_cast<int32_t*>(workspace), N_total, G);
+    const GatherPlan gp = gather_plan(w, G, rank, owner_blocks, recv, recv_offsets);
+    GS_REQUIRE((size_t)gp.blk0 * PP_BLOCK + (size_t)n <= (size_t)N_total, "preprocess_backward_gathered: slice beyond N");
+    PreGrad o;
+    o.xyz = (float*)grad_xyz;
+    o.quaternion = (float*)grad_quaternion;
+    o.scale = (float*)grad_scale;
+    o.opacity = (float*)grad_opacity_logit;
+    o.rgb = (float*)grad_rgb_param;
+    o.sh = (float*)grad_sh;
+    DISPATCH_SH(n_sh, (k_preprocess_bwd<N_SH, true><<<div_up(n, PP_BLOCK), PP_BLOCK, 0, (hipStream_t)stream>>>(
+                          (const float*)xyz, (const float*)quaternion, (const float*)scale, (const float*)camera_T_world,
+                          (const float*)K, (const float*)camera_center, rank_of_gaussian, (const float*)opacity_act, nullptr,
+                          0, n, o, gp)));
+    return check_launch("preprocess_backward_gathered");
 }
 
 int gs_preprocess_backward(const void* xyz, const void* quaternion, const void* scale, int n_sh,

@@ -37,6 +37,7 @@
 // from the stored reciprocal, div_by_reciprocal), det_expf in place of __expf.  Backward forms alpha and
 // the skip decisions bit-identically (render_backward.cu:141-170) and evaluates the gradient formulas in T.
 #include "pg_math.h"
+#include "tile_sort.h"
 #include <atomic>
 
 namespace gs {
@@ -905,26 +906,60 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(GS_FWD_CK_WA
                                     seg);
 }
 
-// repair pass of the prefix mode: a small grid walks the flags and renders the flagged tiles again,
-// now from their fully sorted lists
+// repair pass of the prefix mode / of the depth cut, ONE launch: a small grid walks the flags; a flagged tile's list is
+// first sorted in full by the workgroup (sort_keys != nullptr: lists up to SORT_MAX_LDS_KEYS entries in LDS, longer
+// ones -- sort_beyond -- in global memory; in prefix mode, sort_prefix > 0, only the lists that were prefix-sorted need
+// it) and then rendered again from it.  (Two launches until round 5 -- a sort kernel and this one: ~5 us each on the
+// frames where no tile is flagged, which is nearly all of them.)
 template <bool CK>
 __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(GS_FWD_CK_WAVES, 8))) void k_render_fwd_flagged(
     const float* __restrict__ packed, const float* __restrict__ rgb, const int* __restrict__ ranges,
-    const int* __restrict__ sorted, const float* __restrict__ bg, int W, int H, int ntx, int tile0,
+    int* __restrict__ sorted, const float* __restrict__ bg, int W, int H, int ntx, int tile0,
     int nt, int* __restrict__ nsp_out, float* __restrict__ fw_out, float* __restrict__ image,
     int* __restrict__ tile_flags, int64_t cap, int* __restrict__ tile_cost, const SegState seg,
-    const int* __restrict__ flag_counter, int* __restrict__ host_flagged) {
+    const int* __restrict__ flag_counter, int* __restrict__ host_flagged, uint64_t* __restrict__ sort_keys,
+    int sort_prefix, int sort_beyond) {
+    extern __shared__ uint64_t s_sort_keys[];
+    static_assert(RB == SORT_BLOCK, "the repair workgroup sorts with the binning's network");
     // (depth cut) how many tiles of the frame had to be repaired, into the caller's pinned host word: what the
     // orchestration's policy looks at before later frames (never waited for)
     if (host_flagged != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *host_flagged = *flag_counter;
     if (flag_counter != nullptr && *flag_counter == 0) return;   // (depth cut: no tile of the frame is flagged)
+    const int tid = threadIdx.x;
     for (int t = blockIdx.x; t < nt; t += gridDim.x) {
-        if (tile_flags[tile0 + t] == 0) continue;
-        render_tile_fwd<float, 1, CK>(tile0 + t, packed, rgb, nullptr, ranges, sorted, bg, W, H, ntx,
+        const int tile = tile0 + t;
+        if (tile_flags[tile] == 0) continue;
+        if (sort_keys != nullptr) {
+            const int s0 = ranges[tile];
+            const int n = ranges[tile + 1] - s0;
+            const bool wanted = sort_prefix > 0 ? prefix_sorted_tile(n, sort_prefix) : n > 1;
+            if (wanted && (int64_t)s0 + n <= cap) {   // (block-uniform)
+                if (n <= SORT_MAX_LDS_KEYS) {
+                    for (int i = tid; i < n; i += SORT_BLOCK) s_sort_keys[slot(i)] = sort_keys[s0 + i];
+                    __syncthreads();
+                    lds_bitonic_sort(s_sort_keys, n, tid);
+                    for (int i = tid; i < n; i += SORT_BLOCK) sorted[s0 + i] = (int)(uint32_t)s_sort_keys[slot(i)];
+                } else if (sort_beyond) {
+                    global_sort_tile(sort_keys + s0, sorted + s0, n, tid);
+                }
+            }
+            __syncthreads();   // the list is in place for every thread of the workgroup (workgroup-scope fence + barrier)
+        }
+        render_tile_fwd<float, 1, CK>(tile, packed, rgb, nullptr, ranges, sorted, bg, W, H, ntx,
                                       nsp_out, fw_out, image, 0, tile_flags, true, cap, tile_cost, nullptr, nullptr,
                                       seg);
         __syncthreads();
     }
+}
+// the repair kernel's dynamic LDS (the sort's keys): the limit is raised once per device
+template <bool CK> static void repair_attr_once() {
+    static std::atomic<uint64_t> seen{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    const uint64_t bit = 1ull << dev;
+    if ((seen.fetch_or(bit) & bit) == 0)
+        (void)hipFuncSetAttribute((const void*)k_render_fwd_flagged<CK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)sort_lds_bytes(SORT_MAX_LDS_KEYS));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1856,13 +1891,21 @@ int gs_render_tiles_prefix_phased(const void* packed, const void* rgb, const int
                 nullptr, nullptr);
     }
     if ((phases & GS_PREFIX_REPAIR) && S > GS_SORT_PREFIX) {
-        // 2. + 3. flagged tiles: full sort, render again (no-ops on a dense scene)
-        sort_flagged_tiles(tile_ranges, keys, sorted_gaussians, t0, nt, S, tile_flags, s);
-        auto again = segment_state ? k_render_fwd_flagged<true> : k_render_fwd_flagged<false>;
-        again<<<nt < 512 ? nt : 512, RB, 0, s>>>(
-            (const float*)packed, (const float*)rgb, tile_ranges, sorted_gaussians,
-            (const float*)background_rgb, W, H, ntx, t0, nt, num_splats_per_pixel,
-            (float*)final_weight_per_pixel, (float*)image, tile_flags, S, tile_cost, seg, nullptr, nullptr);
+        // 2. flagged tiles: full sort + render again, one launch (exits at once on a dense scene)
+        const size_t lds = sort_lds_bytes(S <= 4096 ? 4096 : SORT_MAX_LDS_KEYS);
+        if (segment_state) {
+            repair_attr_once<true>();
+            k_render_fwd_flagged<true><<<nt < 512 ? nt : 512, RB, lds, s>>>(
+                (const float*)packed, (const float*)rgb, tile_ranges, sorted_gaussians, (const float*)background_rgb, W, H, ntx,
+                t0, nt, num_splats_per_pixel, (float*)final_weight_per_pixel, (float*)image, tile_flags, S, tile_cost, seg,
+                nullptr, nullptr, const_cast<uint64_t*>(keys), GS_SORT_PREFIX, 0);
+        } else {
+            repair_attr_once<false>();
+            k_render_fwd_flagged<false><<<nt < 512 ? nt : 512, RB, lds, s>>>(
+                (const float*)packed, (const float*)rgb, tile_ranges, sorted_gaussians, (const float*)background_rgb, W, H, ntx,
+                t0, nt, num_splats_per_pixel, (float*)final_weight_per_pixel, (float*)image, tile_flags, S, tile_cost, seg,
+                nullptr, nullptr, const_cast<uint64_t*>(keys), GS_SORT_PREFIX, 0);
+        }
     }
     return check_launch("render_tiles_prefix");
 }
@@ -1889,15 +1932,16 @@ int gs_render_tiles_cut(const void* packed, const void* rgb, const int32_t* tile
         (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians, (const float*)background_rgb, W, H,
         ntx, t0, nt, num_splats_per_pixel, (float*)final_weight_per_pixel, (float*)image, 0, tile_flags, S, tile_cost,
         nullptr, nullptr, full_ranges, flag_counter);
-    // 2. + 3. flagged tiles: complete lists into the overflow buffers, sorted, rendered again (all three exit at once
-    // while the frame has no flagged tile)
+    // 2. + 3. flagged tiles: complete lists into the overflow buffers; sorted and rendered again by one workgroup each
+    // (both launches exit at once while the frame has no flagged tile)
     if (int e = depth_cut_repair((const float*)bin_records, N, ntx, nty, mh_dist, tile_row0, tile_row1, full_ranges, workspace,
-                                 cut_workspace, overflow_keys, overflow_capacity, overflow_sorted, tile_flags, s))
+                                 cut_workspace, overflow_keys, overflow_capacity, overflow_sorted, tile_flags, s, false))
         return e;
-    k_render_fwd_flagged<false><<<nt < 512 ? nt : 512, RB, 0, s>>>(
+    repair_attr_once<false>();
+    k_render_fwd_flagged<false><<<nt < 512 ? nt : 512, RB, sort_lds_bytes(SORT_MAX_LDS_KEYS), s>>>(
         (const float*)packed, (const float*)rgb, full_ranges, overflow_sorted, (const float*)background_rgb, W, H, ntx, t0,
         nt, num_splats_per_pixel, (float*)final_weight_per_pixel, (float*)image, tile_flags, overflow_capacity, tile_cost,
-        SEG_NONE, flag_counter, host_flagged);
+        SEG_NONE, flag_counter, host_flagged, overflow_keys, 0, 1);
     return check_launch("render_tiles_cut");
 }
 

@@ -480,6 +480,43 @@ int gs_preprocess_forward_list(const void* xyz, const void* quaternion, const vo
                                const void* uv, const void* opacity_act, void* uv_l, void* xyz_camera_frame_l, void* conic_l,
                                void* packed_l, void* stream);
 
+/* ---- multi-GPU: the fused band frontend (ABI 8; no reference counterpart) --------------------------------------
+ * gs_band_frontend = gs_band_project + gs_halo_plan_masked + gs_preprocess_forward_list in four launches instead of
+ * nine, with every count taken per 256-block of the GAUSSIAN index (owner slices are whole such blocks, so the
+ * exchange plan is 2 G differences of scanned offsets).  Same outputs, bit for bit: culling_mask[N], rank[N]
+ * (Gaussian -> visible index or -1), uv[V,2] and opacity_act[V] by visible index, camera_center; the send list
+ * send_index[L] (visible indices with this rank's band bit, ascending) and, at its rows l, list_g[L] (their Gaussian
+ * indices) and the band-compact arrays uv_l[L,2], xyz_camera_frame_l[L,3], conic_l[L,3], packed_l[L,12]; plan[4 + 2G]
+ * = (L, V, v_lo, v_hi, send counts[G], receive counts[G]) on the device and -- plan_host != NULL -- the same ints
+ * in device-accessible pinned host memory.  All row arrays need capacity N.  workspace:
+ * int32[gs_band_frontend_workspace_ints(N, G)] = per-block counts and scanned offsets of the visible Gaussians and of
+ * every band's Gaussians, and a 16-bit mask per Gaussian (bit 15 = visible, bit s = can reach band s); it is read
+ * again by the two calls below.  band_rows, owner_blocks: host arrays of G + 1 ints.
+ * gs_band_gather_sum (after the all_to_all; recv / recv_offsets as for gs_halo_gather_sum): out[(v - v_lo) * 9 ..] =
+ *   the sum over the senders, ascending, of the received rows of every visible Gaussian this rank owns.
+ * gs_preprocess_backward_gathered: gs_preprocess_backward for the owned slice (pointers of xyz, quaternion, scale,
+ *   rank_of_gaussian and of the six gradients start at Gaussian 256 * owner_blocks[rank]; n rows) with the
+ *   render-gradient row of each Gaussian summed on the spot from recv instead of read from a slab -- the same bits as
+ *   gs_band_gather_sum followed by gs_preprocess_backward, one launch and one [owned, 9] round trip less. */
+size_t gs_band_frontend_workspace_ints(int N, int G);
+int gs_band_frontend(const void* xyz, const void* quaternion, const void* scale, const void* opacity, const void* rgb,
+                     const void* sh, int n_sh, const void* camera_T_world, const void* K, int N, int W, int H,
+                     float near_thresh, float far_thresh, float cull_mask_padding, float mh_dist, const int32_t* band_rows,
+                     const int32_t* owner_blocks, int G, int rank, int32_t* workspace, void* camera_center,
+                     uint8_t* culling_mask, int32_t* rank_out, void* uv, void* opacity_act, int32_t* send_index,
+                     int32_t* list_g, void* uv_l, void* xyz_camera_frame_l, void* conic_l, void* packed_l, int32_t* plan,
+                     int32_t* plan_host, void* stream);
+int gs_band_gather_sum(const int32_t* workspace, int N, int G, int rank, const int32_t* owner_blocks,
+                       const int32_t* rank_of_gaussian, int v_lo, const void* recv, const int32_t* recv_offsets, void* out,
+                       void* stream);
+int gs_preprocess_backward_gathered(const void* xyz, const void* quaternion, const void* scale, int n_sh,
+                                    const void* camera_T_world, const void* K, const void* camera_center,
+                                    const int32_t* rank_of_gaussian, const void* opacity_act, const int32_t* workspace,
+                                    int N_total, int G, int rank, const int32_t* owner_blocks, const void* recv,
+                                    const int32_t* recv_offsets, int n, void* grad_xyz, void* grad_quaternion,
+                                    void* grad_scale, void* grad_opacity_logit, void* grad_rgb_param, void* grad_sh,
+                                    void* stream);
+
 /* ---- training-loop operations behind the rasterizer ------------------------------
  * gs_adam_step: torch.optim.Adam.step() as the reference uses it (splat_py/optimizer_manager.py:15-42
  * builds the optimizer with one group per parameter tensor and a learning rate each; trainer.py:376

@@ -21,7 +21,10 @@ ap.add_argument("--grad-mode", default="replicated", choices=["replicated", "own
                 help="owner: the sparse-exchange path with the all_to_all replaced by a local fill (compute only)")
 ap.add_argument("--native", type=int, default=1, help="0: the Python orchestration of the sharded frame")
 ap.add_argument("--compact", type=int, default=1, help="0: replicated per-Gaussian stage (native path)")
+ap.add_argument("--fused", type=int, default=1, help="0: the three-call band pipeline of rounds 3-5 (A/B)")
 a = ap.parse_args()
+if fused.native() is not None:
+    fused.native().set_band_fused(bool(a.fused))
 from gaussian_splatting_amd import sharded as _sh
 _sh.NATIVE = bool(a.native)
 _sh.BAND_COMPACT = bool(a.compact)
@@ -72,5 +75,5 @@ for _ in range(a.steps):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / a.steps * 1e3
 t = _hip.collect_timing()
-print(f"world {a.world} rank {a.rank} rows {rows} native {a.native} compact {a.compact}: {ms:.3f} ms/step",
+print(f"world {a.world} rank {a.rank} rows {rows} native {a.native} compact {a.compact} fused {a.fused}: {ms:.3f} ms/step",
       {k: round(sum(v) / len(v), 4) for k, v in sorted(t.items())}, moved)

@@ -17,7 +17,10 @@ ap.add_argument("--defer", type=int, default=0)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--native", type=int, default=1, help="0: the Python orchestration of the sharded frame")
 ap.add_argument("--compact", type=int, default=1, help="0: replicated per-Gaussian stage (native path)")
+ap.add_argument("--fused", type=int, default=1, help="0: the three-call band pipeline of rounds 3-5 (A/B)")
 a = ap.parse_args()
+if fused.native() is not None:
+    fused.native().set_band_fused(bool(a.fused))
 sharded.DEFER_HOST_READ = bool(a.defer)
 sharded.NATIVE = bool(a.native)
 sharded.BAND_COMPACT = bool(a.compact)
@@ -68,7 +71,7 @@ t_all = time.perf_counter()
 for _ in range(a.steps):
     step()
 torch.cuda.synchronize()
-print(f"native={a.native} compact={a.compact} defer={a.defer} world={a.world}: {(time.perf_counter() - t_all) / a.steps * 1e3:.3f} ms/step")
+print(f"native={a.native} compact={a.compact} fused={a.fused} defer={a.defer} world={a.world}: {(time.perf_counter() - t_all) / a.steps * 1e3:.3f} ms/step")
 marks.clear()
 torch.cuda.synchronize()
 t0 = time.perf_counter()

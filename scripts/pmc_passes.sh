@@ -9,7 +9,8 @@ export TMPDIR=/tmp
 cd /tmp
 # (GSPLAT_DEPTH_CUT: 1 = the depth-cut kernels from the first frame on, so that a kernel name has one meaning in the run)
 export GSPLAT_DEPTH_CUT=${GSPLAT_DEPTH_CUT:-1}
-CMD="python $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --also="
+# PMC_CMD overrides the profiled command (e.g. one rank's band frame: PMC_CMD="python $R/scripts/host_timeline.py --world 8 --steps 3")
+CMD=${PMC_CMD:-"python $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --also="}
 i=0
 for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
