@@ -20,7 +20,11 @@ Before timing, every rank checks one sharded frame against the single-GPU frame 
 Before the W warm-up steps the bench runs --spinup-steps untimed frames (default 100, ~0.2 s) so that the
 measurement does not depend on what ran on the box before (clocks, allocator, capacity hints); the timed
 region is exactly K steps between barriers, as the contract asks: ms_per_step = wall / K (max over ranks);
-ms_per_step_median / min / max are the per-step GPU times between events on the launch stream.  `metric` is
+ms_per_step_median / min / max / p10 / p90 are the per-step GPU times between events on the launch stream.  The
+host's own preparation (events, gc.collect) is done in front of the W warm-up frames and --respin-steps (10) more
+untimed frames run behind the warm-up's event read-out, so that only the barrier separates untimed from timed frames:
+an idle GPU drops to its sleep clock within milliseconds and the ~10 frames after it run on the ramp (1.80, 1.46,
+1.45 ... 1.37 ms at D, scripts/step_spread.py) -- with K = 20 that ramp WAS the measurement until round 5.  `metric` is
 BASELINE.json's string verbatim; `value` is its first half (Mpixels/s), the second half ("grad max-rel-err
 vs ref") is reported in the `parity` object.  --moving-camera gives every step its own seeded pose, so the
 visible set and the instance count change per frame; frame_counters then reports how often the speculative
@@ -94,6 +98,8 @@ def parse():
                     help="multi-GPU only: 'owner' = every rank produces the parameter gradients of the Gaussians "
                     "it owns (sparse all_to_all of the partial render gradients); 'replicated' = identical dense "
                     "gradients on every rank (all-reduce of the whole render-gradient slab)")
+    ap.add_argument("--respin-steps", type=int, default=10,
+                    help="untimed frames between the warm-up's bookkeeping and the timed region (no idle GPU in front of it)")
     ap.add_argument("--spinup-steps", type=int, default=100,
                     help="untimed frames run BEFORE the W warm-up steps (the same count on every rank), so that "
                     "allocator caches, capacity hints and GPU clocks are in steady state whatever ran on the box "
@@ -357,7 +363,7 @@ def main():
                 raise
         path = "fused" if fused_mod is not None else "reference"
 
-    n_frames = args.spinup_steps + args.warmup + args.steps
+    n_frames = args.spinup_steps + args.warmup + args.respin_steps + args.steps
     poses = camera_poses(n_frames, 1234, dev, args.moving_camera)
 
     def set_requires_grad(gs, on):
@@ -433,7 +439,16 @@ def main():
         # bracketed -- its launch duration is what `roofline` is computed from -- because an event pair around a
         # call costs the stream ~10 us: the five other pairs per frame were 0.05 ms, 12 % of workload B's frame
         # and 3 % of D's (B 0.412 -> 0.364 ms, D 1.588 -> 1.538 ms).
+        # Everything the host has to prepare happens BEFORE the warm-up frames (events, the collector's pass), so that
+        # nothing but the barrier separates the last untimed frame from the first timed one: after a few ms without
+        # work the GPU drops to its sleep clock (S: ~100 MHz in pp_dpm_sclk) and the next ~10 frames run while it ramps
+        # back up -- 1.80, 1.46, 1.455, 1.44 ... 1.37 ms at workload D (scripts/step_spread.py,
+        # profiles/r06/step_spread.json).  A 20-step timed region that starts behind a gc.collect() and the event
+        # bookkeeping measured mostly that ramp (the driver's min / median / max 1.379 / 1.421 / 1.562 of round 5).
         _hip.reserve_events(2 * 16 * max(args.warmup, 1) + 2 * 16 * args.steps)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        gc.collect()
+        gc.disable()   # no collector pause inside the timed region
         _hip.enable_timing(True)
         for _ in range(args.warmup):
             step(i)
@@ -443,11 +458,15 @@ def main():
         per_entry = {k: (sum(v) / len(v), len(v) / max(args.warmup, 1)) for k, v in table.items() if v}
         ranked = [k for k in per_entry if k.startswith("gs_")]   # rccl_* regions are reported, not ranked
         dom = max(ranked, key=lambda k: per_entry[k][0] * per_entry[k][1]) if ranked else None
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         if fused_mod is not None:
             fused_mod.reset_counters()
-        gc.collect()
-        gc.disable()   # no collector pause inside the timed region
+        # (reading the warm-up's events above synchronised and took the host a moment: a few untimed frames bring the
+        # queue -- and the clock -- back to the state the timed frames should see)
+        for _ in range(args.respin_steps):
+            step(i)
+            i += 1
+        if fused_mod is not None:
+            fused_mod.reset_counters()
         barrier()
         _hip.enable_timing(True, only=dom)   # dom None (W = 0): every entry point, as in the warm-up
         t0 = time.perf_counter()
@@ -630,7 +649,9 @@ def main():
             "metric": "forward+backward Mpixels/s @ ~1MP, N Gaussians; grad max-rel-err vs ref", "value": round(value, 3),
             "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "ms_per_step_median": round(median(ps), 4),
-            "ms_per_step_min": round(min(ps), 4), "ms_per_step_max": round(max(ps), 4), "higher_is_better": True,
+            "ms_per_step_min": round(min(ps), 4), "ms_per_step_max": round(max(ps), 4),
+            "ms_per_step_p10": round(sorted(ps)[int(0.10 * len(ps))], 4),
+            "ms_per_step_p90": round(sorted(ps)[min(len(ps) - 1, int(0.90 * len(ps)))], 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {N} Gaussians, {W}x{H}, SH degree {deg}, seed 0",
                        "N": N, "V": V, "S": S, "P": P, "path": path,

@@ -903,23 +903,28 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
         });
         auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(dev);
         Tensor sorted, keys;
-        auto emit_sort = [&](int64_t capacity) {
+        auto emit_sort = [&](int64_t capacity, int64_t longest = -1) {
             sorted = torch::empty({capacity}, i32);
             keys = torch::empty({capacity}, i32.dtype(torch::kInt64));
             if (capacity > 0)
                 timed("gs_tile_emit_sort", stream, [&] {
-                    return gs_tile_emit_sort(bin_uv, bin_xyz, bin_conic, N, items_n, subset, subset_n, ntx, nty,
-                                             (float)fr.mh_dist, row0, row1, ranges_buf, tile_counts,
-                                             (uint64_t*)keys.data_ptr<int64_t>(), capacity, sorted.data_ptr<int32_t>(),
-                                             sort_prefix, stream);
+                    return gs_tile_emit_sort_bounded(bin_uv, bin_xyz, bin_conic, N, items_n, subset, subset_n, ntx, nty,
+                                                     (float)fr.mh_dist, row0, row1, ranges_buf, tile_counts,
+                                                     (uint64_t*)keys.data_ptr<int64_t>(), capacity,
+                                                     sorted.data_ptr<int32_t>(), sort_prefix, longest, stream);
                 });
         };
         const HintKey key{(int)dev.index(), N, T, row0, row1};
-        int64_t guess = -1;
+        // compact frames also guess the band's LONGEST list from the shape's last frame (the tile scan reports it with
+        // the counts): none beyond 4096 entries -> the sort's walk-grid kernel for those is not enqueued (~5 us that
+        // find nothing to do); a guess that was too small repeats emit + sort + render, as a capacity miss does
+        int64_t guess = -1, longest_guess = -1;
         {
             std::lock_guard<std::mutex> lock(g_mutex);
             auto it = g_capacity.find(key);
             if (it != g_capacity.end()) guess = it->second;
+            auto il = g_longest_list.find(key);
+            if (compact && sort_prefix && il != g_longest_list.end()) longest_guess = il->second;
         }
         if (!compact)
             hip_ok(hipMemcpyAsync(host, ranges_buf + T, (2 + plan_ints) * sizeof(int32_t), hipMemcpyDeviceToHost,
@@ -936,7 +941,7 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
         int64_t capacity = 0;
         if (speculative) {
             capacity = guess;
-            emit_sort(capacity);
+            emit_sort(capacity, longest_guess);
             if (g_early_render && sort_prefix && capacity > sort_prefix) {
                 fr.out = render_forward(packed, rgbr, ranges_buf, sorted, keys, fr.bg, W, H, row0, row1, whole, sort_prefix, stream,
                                         key, false, image_rows);
@@ -947,18 +952,24 @@ struct OwnerPreprocess : public torch::autograd::Function<OwnerPreprocess> {
         // the plan's host half: rows to send, V, v_lo, v_hi, send[G], recv[G]
         const int32_t* rec = host + rec_at;
         const int64_t S = host[0], V = rec[1], L = compact ? rec[0] : rec[1];
+        const int64_t longest = compact ? host[2] : -1;   // (k_scan_tiles' host mirror: S, V, longest list)
+        // (a list beyond 4096 entries whose sort kernel was not enqueued: the lists are not what the render needs)
+        const bool unsorted_long = speculative && longest_guess >= 0 && longest_guess <= 4096 && longest > 4096;
+        const bool miss = speculative && (S > capacity || unsorted_long);
         {
             std::lock_guard<std::mutex> lock(g_mutex);
             g_counters.frames++;
             g_counters.speculative += speculative;
             g_counters.s_min = g_counters.s_min < 0 ? S : std::min(g_counters.s_min, S);
             g_counters.s_max = std::max(g_counters.s_max, S);
-            if (!speculative || S > capacity) g_counters.misses += speculative;
+            g_counters.misses += miss;
+            g_counters.long_list_misses += unsorted_long;
             int64_t& hint = g_capacity[key];
             hint = std::max(hint, S + S / 4 + 4096);
+            if (compact && sort_prefix) g_longest_list[key] = longest;
         }
-        if (!speculative || S > capacity) {
-            emit_sort(S);
+        if (!speculative || miss) {
+            emit_sort(S, longest);
             rendered = false;
         }
         Tensor sorted_g = sorted.narrow(0, 0, S), keys_g = keys.narrow(0, 0, S);

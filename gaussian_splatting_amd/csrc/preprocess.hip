@@ -447,15 +447,18 @@ __device__ inline float rotation_norm2_bound(const float* __restrict__ M) {
 // bit s = the Gaussian CAN reach the tile rows of band s: the candidate window of tile_culling.cu:138-156 with its
 // radius bounded from the largest scale (see the block comment above) -- a superset of the exact window, the same
 // on every rank
-__device__ inline uint32_t band_mask_bound(const float* c, const float* uv, const float* __restrict__ scale3,
-                                           const float* __restrict__ M, const float* __restrict__ K, float mh, int nty,
-                                           const BandRows& rows, int G) {
-    const float s_max = fmaxf(fmaxf(det_expf(scale3[0]), det_expf(scale3[1])), det_expf(scale3[2]));
+// rot2 = rotation_norm2_bound(M), the same value for every Gaussian of the frame (callers form it once per workgroup)
+__device__ inline uint32_t band_mask_bound(const float* c, const float* uv, const float* __restrict__ scale3, float rot2,
+                                           const float* __restrict__ K, float mh, int nty, const BandRows& rows, int G) {
+    // the largest of the three scales: one exponential of the largest logarithm (round 6; three exponentials and their
+    // maximum until then -- the bound carries 0.1 % of slack twice over, an ulp either way is immaterial, and every
+    // rank evaluates this same expression)
+    const float s_max = det_expf(fmaxf(fmaxf(scale3[0], scale3[1]), scale3[2]));
     const float iz = 1.0f / c[2];
     const float jx = K[0] * iz, jy = K[4] * iz, tx = K[0] * c[0] * iz * iz, ty = K[4] * c[1] * iz * iz;
     const float A = jx * jx + tx * tx, C = jy * jy + ty * ty, B = tx * ty;
     const float lam = 0.5f * (A + C) + __builtin_sqrtf(0.25f * (A - C) * (A - C) + B * B);
-    const float l1 = s_max * s_max * rotation_norm2_bound(M) * lam * 1.001f + 0.25f;
+    const float l1 = s_max * s_max * rot2 * lam * 1.001f + 0.25f;
     const float rt = __builtin_ceilf(mh * __builtin_sqrtf(l1) * 1.001f / 16.0f) + 1.0f;
     uint32_t m = 0;
     if (rt < 1.0e6f) {
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(PP_BLOCK) void k_band_project(
     uv_out[v * 2 + 0] = uv[0];
     uv_out[v * 2 + 1] = uv[1];
     opa_out[v] = sigmoid_det(opacity[g]);
-    mask[v] = band_mask_bound(c, uv, scale + (size_t)g * 3, M, K, mh, nty, rows, G);
+    mask[v] = band_mask_bound(c, uv, scale + (size_t)g * 3, rotation_norm2_bound(M), K, mh, nty, rows, G);
 }
 
 // per-256-block counts of every mask bit, by VISIBLE index (the layout gs_halo_plan's scan expects)
@@ -613,13 +616,16 @@ __global__ __launch_bounds__(PP_BLOCK) void k_band_count(
     const float* __restrict__ K, int N, Frustum fr, float mh, int nty, BandRows rows, int G,
     int* __restrict__ counts, int nbp, uint16_t* __restrict__ gmask, float* __restrict__ center) {
     __shared__ int s_cnt[GS_MAX_RANKS + 1][PP_BLOCK / GS_WAVE];
+    __shared__ float s_rot2;
     const int g = blockIdx.x * PP_BLOCK + threadIdx.x;
     if (g == 0) camera_center(M, center);
+    if (threadIdx.x == 0) s_rot2 = rotation_norm2_bound(M);   // (once per workgroup instead of once per lane)
+    __syncthreads();
     uint32_t m = 0;
     if (g < N) {
         float c[3], uv[2];
         to_camera(M, xyz[g * 3 + 0], xyz[g * 3 + 1], xyz[g * 3 + 2], c);
-        if (!is_culled(c, K, fr, uv)) m = 0x8000u | band_mask_bound(c, uv, scale + (size_t)g * 3, M, K, mh, nty, rows, G);
+        if (!is_culled(c, K, fr, uv)) m = 0x8000u | band_mask_bound(c, uv, scale + (size_t)g * 3, s_rot2, K, mh, nty, rows, G);
         gmask[g] = (uint16_t)m;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

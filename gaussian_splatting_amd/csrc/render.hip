@@ -1339,8 +1339,14 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     }
     const int first_chunk = seg_lo / RCHUNK;
     const int last_chunk = (seg_hi - 1) / RCHUNK;
+    // Q1 (render_backward.cu:185 compares a chunk-local index): k % REF_CH for k = base + i, i < RCHUNK <= REF_CH, is
+    // base % REF_CH + i with at most one wrap -- one scalar division per CHUNK instead of a multiply-high sequence
+    // (9 scalar instructions) per visit; exact mode never wraps
+    static_assert(RCHUNK <= REF_CH, "one wrap per chunk");
+    const int q1_wrap = exact ? 0x7fffffff : REF_CH;
     for (int chunk = last_chunk; chunk >= first_chunk; chunk--) {
         const int base = chunk * RCHUNK;
+        const int base_q = exact ? base : base % REF_CH;
         const int cnt = min(RCHUNK, seg_hi - base);
         GS_STAT(1, 1);
         __syncthreads();   // previous chunk fully flushed
@@ -1362,6 +1368,8 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
             m &= ~(1ull << bit);
             const int i = (word << 6) + bit;
             const int k = base + i;
+            int kq = base_q + i;   // = exact ? k : k % REF_CH
+            kq = kq >= q1_wrap ? kq - q1_wrap : kq;
             const bool reach = k < reach_end;   // render_backward.cu:131 (nsp == 0 outside the image)
             GS_STAT(2, 1);                          // visits
             if (ballot(reach) == 0) continue;      // wave-uniform: no lane reaches this splat
@@ -1414,7 +1422,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                         {
 #pragma clang fp contract(fast)
                             const T r1ma = fast_rcp(T(1) - alpha);
-                            if ((exact ? k : k % REF_CH) < nsp - 1) weight = weight * r1ma;   // Q1 (chunk-local index) unless exact
+                            if (kq < nsp - 1) weight = weight * r1ma;   // Q1 (chunk-local index) unless exact
                             aw = alpha * weight;
                             // grad_alpha (render_backward.cu:196-203); the record's colour is Y0 * coefficient
                             T c0 = g2.y, c1 = g2.z, c2 = g2.w;
@@ -1497,7 +1505,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                     {
 #pragma clang fp contract(fast)
                         const T r1ma = fast_rcp(T(1) - alpha);
-                        if ((exact ? k : k % REF_CH) < nsp - 1) weight = weight * r1ma;   // Q1 (chunk-local index) unless exact
+                        if (kq < nsp - 1) weight = weight * r1ma;   // Q1 (chunk-local index) unless exact
                         T col[3];
                         splat_colour<T, N_SH>(s_geom, s_col, i, Y, col);
                         const T aw = alpha * weight;
