@@ -556,7 +556,8 @@ def main():
     # runs and corrected for gfx950: scripts/pmc_passes.sh, scripts/make_traffic_json.py) -- a committed
     # profile of this workload, NOT measured by this run: tagged with its source
     traffic, traffic_source = {}, None
-    for rel in (f"profiles/r05/hbm_traffic_{args.workload}.json", f"profiles/r04/hbm_traffic_{args.workload}.json",
+    for rel in (f"profiles/r06/hbm_traffic_{args.workload}.json", f"profiles/r05/hbm_traffic_{args.workload}.json",
+                f"profiles/r04/hbm_traffic_{args.workload}.json",
                 f"profiles/r03/hbm_traffic_{args.workload}.json",
                 f"profiles/r02/hbm_traffic_{args.workload}.json",
                 f"profiles/r01_hbm_traffic_{args.workload}.json"):
@@ -738,7 +739,7 @@ def valu_roofline(entry, launch_ms, workload):
     """VALU issue view of the dominant kernel: wave-instructions from the committed PMC pass (source tagged)
     over the launch time measured by THIS run, against the plain-fp32 issue peak of the chip
     (256 CUs x 4 SIMDs x one wave-instruction per 2 cycles at 2.4 GHz; profiles/r02/ubench_valu_rate.txt)."""
-    rnd = next((r for r in ("r05", "r04", "r03", "r02") if os.path.exists(os.path.join(ROOT, "profiles", r, f"valu_insts_{workload}.json"))),
+    rnd = next((r for r in ("r06", "r05", "r04", "r03", "r02") if os.path.exists(os.path.join(ROOT, "profiles", r, f"valu_insts_{workload}.json"))),
                None)
     if rnd is None:
         return None

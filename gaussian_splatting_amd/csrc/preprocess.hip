@@ -450,16 +450,18 @@ __device__ inline float rotation_norm2_bound(const float* __restrict__ M) {
 // rot2 = rotation_norm2_bound(M), the same value for every Gaussian of the frame (callers form it once per workgroup)
 __device__ inline uint32_t band_mask_bound(const float* c, const float* uv, const float* __restrict__ scale3, float rot2,
                                            const float* __restrict__ K, float mh, int nty, const BandRows& rows, int G) {
-    // the largest of the three scales: one exponential of the largest logarithm (round 6; three exponentials and their
-    // maximum until then -- the bound carries 0.1 % of slack twice over, an ulp either way is immaterial, and every
-    // rank evaluates this same expression)
-    const float s_max = det_expf(fmaxf(fmaxf(scale3[0], scale3[1]), scale3[2]));
-    const float iz = 1.0f / c[2];
+    // A BOUND, not a reference quantity: it carries 0.1 % of slack twice over, so the hardware's approximate
+    // exponential, reciprocal and square root (1-2 ulp) serve -- every rank issues these same instructions on the same
+    // inputs, so the masks agree across ranks, and the old and the fused frontends share this function.  One
+    // exponential of the largest log-scale instead of three and their maximum (round 6: ~40 instructions less per
+    // visible Gaussian in the kernels that stream all N)
+    const float s_max = __builtin_amdgcn_exp2f(fmaxf(fmaxf(scale3[0], scale3[1]), scale3[2]) * 1.44269504088896341f);
+    const float iz = __builtin_amdgcn_rcpf(c[2]);
     const float jx = K[0] * iz, jy = K[4] * iz, tx = K[0] * c[0] * iz * iz, ty = K[4] * c[1] * iz * iz;
     const float A = jx * jx + tx * tx, C = jy * jy + ty * ty, B = tx * ty;
-    const float lam = 0.5f * (A + C) + __builtin_sqrtf(0.25f * (A - C) * (A - C) + B * B);
+    const float lam = 0.5f * (A + C) + __builtin_amdgcn_sqrtf(0.25f * (A - C) * (A - C) + B * B);
     const float l1 = s_max * s_max * rot2 * lam * 1.001f + 0.25f;
-    const float rt = __builtin_ceilf(mh * __builtin_sqrtf(l1) * 1.001f / 16.0f) + 1.0f;
+    const float rt = __builtin_ceilf(mh * __builtin_amdgcn_sqrtf(l1) * 1.001f * 0.0625f) + 1.0f;
     uint32_t m = 0;
     if (rt < 1.0e6f) {
         const int r = (int)rt;
