@@ -79,7 +79,8 @@ def run_new(g, cam, T, W, H, G, me, rows, oblk):
 
 @pytest.mark.parametrize("shape,G,me", [((60_000, 640, 480, 3), 2, 0), ((60_000, 640, 480, 3), 3, 1),
                                          ((60_000, 640, 480, 3), 8, 7), ((40_001, 320, 240, 0), 4, 2),
-                                         ((5_000, 320, 240, 1), 8, 0), ("D", 8, 4), ("D", 2, 1)])
+                                         ((5_000, 320, 240, 1), 8, 0), ((300, 64, 48, 0), 8, 5), ((300, 64, 48, 3), 8, 0),
+                                         ((700, 64, 48, 0), 8, 2), ("D", 8, 4), ("D", 2, 1)])
 def test_fused_band_frontend_equals_the_three_call_pipeline(shape, G, me):
     N, W, H, deg = WORKLOADS[shape] if isinstance(shape, str) else shape
     g, cam, T = make_scene(N, W, H, deg, seed=3, device=DEV)
@@ -92,7 +93,7 @@ def test_fused_band_frontend_equals_the_three_call_pipeline(shape, G, me):
     plan = old["plan"].tolist()
     L, V = plan[0], plan[1]
     assert new["plan"].tolist() == plan and new["plan_host"].tolist() == plan
-    assert V == int(old["count"]) and 0 < L <= V
+    assert V == int(old["count"]) and 0 <= L <= V   # (64x48: three tile rows, ranks 3.. of 8 own no rows; 300 Gaussians: most ranks own none)
     assert torch.equal(new["center"][:3], old["center"][:3])
     assert torch.equal(new["culled"], old["culled"]) and torch.equal(new["rank"], old["rank"])
     assert torch.equal(new["uv"][:V], old["uv"][:V]) and torch.equal(new["opa"][:V], old["opa"][:V])
@@ -144,4 +145,35 @@ def test_fused_band_frontend_equals_the_three_call_pipeline(shape, G, me):
         for x, y in zip(a, b):
             if x is not None:
                 assert torch.equal(x, y)
-        assert any(bool((x != 0).any()) for x in b if x is not None)
+        if sum(recv_counts) > 0:
+            assert any(bool((x != 0).any()) for x in b if x is not None)
+
+
+def test_fused_band_frontend_on_random_shapes():
+    """30 seeded random shapes (N 1 .. 30 000 incl. non-multiples of 256, image sizes with partial tiles, SH degree 0-3,
+    G 1-8, every rank position incl. ranks without tile rows or without Gaussians): plan, send list and band-compact
+    rows of the fused frontend equal the three-call pipeline's"""
+    import random
+    rnd = random.Random(20260601)
+    for trial in range(30):
+        N = rnd.choice([1, 37, 255, 256, 257, 1000, 4097, rnd.randrange(2, 30_000)])
+        W, H = rnd.randrange(17, 400), rnd.randrange(17, 300)
+        deg = rnd.randrange(0, 4)
+        G = rnd.randrange(1, 9)
+        me = rnd.randrange(0, G)
+        g, cam, T = make_scene(N, W, H, deg, seed=100 + trial, device=DEV)
+        nty = (H + 15) // 16
+        rows = [band_of(nty, G, r)[0] for r in range(G)] + [nty]
+        oblk = owner_blocks(N, G)
+        old = run_old(g, cam, T, W, H, G, me, rows, oblk)
+        new = run_new(g, cam, T, W, H, G, me, rows, oblk)
+        torch.cuda.synchronize()
+        plan = old["plan"].tolist()
+        L, V = plan[0], plan[1]
+        tag = (trial, N, W, H, deg, G, me)
+        assert new["plan"].tolist() == plan, tag
+        assert torch.equal(new["culled"], old["culled"]) and torch.equal(new["rank"], old["rank"]), tag
+        assert torch.equal(new["uv"][:V], old["uv"][:V]) and torch.equal(new["opa"][:V], old["opa"][:V]), tag
+        assert torch.equal(new["send"][:L], old["send"][:L]), tag
+        for k in ("uv_l", "xyz_l", "conic_l", "packed_l"):
+            assert torch.equal(new[k][:L], old[k][:L]), (tag, k)
