@@ -363,6 +363,59 @@ __device__ inline void build_touch_masks(const T* s_geom, int cnt, int tid, int 
     }
 }
 
+// The same masks for a 64-entry chunk (the fused backward's), by the whole workgroup: wave p tests the 64 staged
+// records against patch p -- one patch test per thread instead of four on wave 0 while the other three waves wait at
+// the barrier (the masks were 9 % of the backward's wave time, profiles/r04/wave_timeline_D.json).  Every
+// (record, patch) pair is tested with the very expressions of build_touch_masks: the same bits.  The records must be
+// visible to all waves (barrier after staging).
+template <typename T>
+__device__ inline void build_touch_masks_by_patch(const T* s_geom, int cnt, int tid, int tile_x, int tile_y,
+                                                  unsigned long long (*s_mask)[1]) {
+    const int r = tid & 63, p = tid >> 6;
+    bool hit = false;
+    if (r < cnt) {
+        const T* rec = s_geom + r * GS_PACKED_WIDTH;
+        const T u = rec[0], v = rec[1], r2 = rec[2];
+        bool use_q = false;
+        T a = 0, b = 0, c = 0, rdet = 0, tau_m = 0, b_over_a = 0, b_over_c = 0;
+        if (fast_mode<T>() && r2 > T(0) && r2 < T(1e30)) {
+            a = rec[4]; b = rec[5]; c = rec[6]; rdet = rec[8];
+            const T half = T(0.5) * (a + c);
+            const T lmax = half + fast_sqrt(T(0.25) * (a - c) * (a - c) + b * b);
+            tau_m = (r2 * fast_rcp(lmax)) * T(1.001);
+            use_q = a > T(0) && c > T(0) && rdet > T(0);
+            b_over_a = b * fast_rcp(a);
+            b_over_c = b * fast_rcp(c);
+        }
+        const T x0 = T(tile_x * 16 + ((p & 1) << 3)), y0 = T(tile_y * 16 + ((p >> 1) << 3));
+        const T x1 = x0 + T(7), y1 = y0 + T(7);
+        T dx = T(0), dy = T(0);
+        if (u < x0) dx = x0 - u;
+        if (u > x1) dx = x1 - u;
+        if (v < y0) dy = y0 - v;
+        if (v > y1) dy = y1 - v;
+        hit = !(dx * dx + dy * dy > r2);
+        if (hit && use_q && (dx != T(0) || dy != T(0))) {
+            const T X0 = x0 - u, X1 = x1 - u, Y0 = y0 - v, Y1 = y1 - v;
+            T qmin = T(3.0e38);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const T X = e ? X1 : X0;
+                T yy = b_over_a * X;
+                yy = tmin<T>(tmax<T>(yy, Y0), Y1);
+                qmin = tmin<T>(qmin, (c * X * X - T(2) * b * X * yy + a * yy * yy) * rdet);
+                const T Y = e ? Y1 : Y0;
+                T xx = b_over_c * Y;
+                xx = tmin<T>(tmax<T>(xx, X0), X1);
+                qmin = tmin<T>(qmin, (c * xx * xx - T(2) * b * xx * Y + a * Y * Y) * rdet);
+            }
+            hit = !(qmin > tau_m);
+        }
+    }
+    const unsigned long long m = __ballot(hit);
+    if (r == 0) s_mask[p][0] = m;
+}
+
 // colour of splat i of the staged chunk at this pixel's view direction
 template <typename T, int N_SH>
 __device__ inline void splat_colour(const T* s_geom, const T* s_col, int i, const T* Y, T* col) {
@@ -1354,8 +1407,14 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
         if constexpr (!SLOTS)
             for (int k = tid; k < cnt * NV; k += RB) s_acc[k] = 0;
         GS_PHASE(0);
-        // (no barrier in between: thread t tests the record thread t staged)
-        build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
+        if constexpr (SLOTS && RCHUNK == 64) {
+            // one patch per wave (round 6): the records wave 0 staged have to be visible to the other three first
+            __syncthreads();
+            build_touch_masks_by_patch<T>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
+        } else {
+            // (no barrier in between: thread t tests the record thread t staged)
+            build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
+        }
         __syncthreads();
         GS_PHASE(1);
 
