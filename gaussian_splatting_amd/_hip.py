@@ -50,6 +50,7 @@ EXPORTS = [
     "gs_set_backward_mode", "gs_get_backward_mode", "gs_render_depth", "gs_halo_workspace_ints", "gs_halo_plan", "gs_halo_gather_sum",
     "gs_band_project", "gs_halo_plan_masked", "gs_preprocess_forward_list",
     "gs_band_frontend_workspace_ints", "gs_band_frontend", "gs_band_gather_sum", "gs_preprocess_backward_gathered",
+    "gs_render_tiles_prefix_phased_m", "gs_render_tiles_cut_m", "gs_render_tiles_backward_slab_m",
     "gs_adam_step", "gs_accumulate_grad_stats", "gs_stream_copy", "gs_ssim_l1_workspace_bytes", "gs_ssim_l1_loss",
     "gs_densify_move",
     "gs_cut_workspace_ints", "gs_cut_sample_stride", "gs_cut_supported", "gs_preprocess_forward_cut", "gs_tile_count_cut",

@@ -17,6 +17,7 @@
 #include <torch/extension.h>
 #include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <mutex>
@@ -73,6 +74,8 @@ bool g_band_compact = true;   // multi-GPU: band-compact per-Gaussian stage (Own
 // the three-call pipeline of rounds 3-5 (gs_band_project, gs_halo_plan_masked, gs_preprocess_forward_list;
 // gs_halo_gather_sum), kept for A/B measurements and as the checker of the fused form (tests/test_gpu_band_frontend.py)
 bool g_band_fused = true;
+// the render backward reads the touch masks its forward built (512 bytes per tile) instead of rebuilding them
+bool g_touch_masks = true;
 // depth cut: 0 = auto (whole frames in the LDS-histogram regime whose lists averaged g_cut_min_mean_list entries or
 // more in an earlier frame of the same shape), 1 = always (where supported), -1 = never
 int g_depth_cut = 0;
@@ -260,6 +263,7 @@ struct RenderOut {
     Tensor cut_flags, overflow_sorted;   // depth-cut frames: flagged tiles and their complete lists (else undefined)
     Tensor prefix_flags;                 // prefix-sorted frames: the provisional render's tile flags (else undefined)
     int32_t* tile_cost = nullptr;        // per-tile render cost int32[T] inside buf (the backward's launch-order key)
+    Tensor masks;                        // touch masks the forward left for the backward (include/gsplat_hip.h, `_m` entries)
 };
 // what gs_render_tiles_cut needs from the frame's binning
 struct CutRef {
@@ -302,13 +306,15 @@ RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* 
         const int64_t ocap = std::max<int64_t>(cut->overflow_capacity, 1);
         r.overflow_sorted = torch::empty({ocap}, opt.dtype(torch::kInt32));
         Tensor okeys = torch::empty({ocap}, opt.dtype(torch::kInt64));
+        if (g_touch_masks) r.masks = torch::empty({T * 64}, opt.dtype(torch::kInt64));
+        uint64_t* masks_p = r.masks.defined() ? (uint64_t*)r.masks.data_ptr<int64_t>() : nullptr;
         timed("gs_render_tiles_prefix", stream, [&] {
-            return gs_render_tiles_cut(packed, rgbr, ranges, sorted.data_ptr<int32_t>(), sorted.size(0), cut->full_ranges,
-                                       cut->bin_rec, cut->N, cut->mh, cut->tile_counts, cut->cut_ws,
-                                       (uint64_t*)okeys.data_ptr<int64_t>(), r.overflow_sorted.data_ptr<int32_t>(),
-                                       cut->overflow_capacity, bg.data_ptr(), W, H, row0, row1,
-                                       r.cut_flags.data_ptr<int32_t>(), r.nsp.data_ptr<int32_t>(), r.fw.data_ptr(),
-                                       r.image.data_ptr(), tile_cost, cut->host_flagged, stream);
+            return gs_render_tiles_cut_m(packed, rgbr, ranges, sorted.data_ptr<int32_t>(), sorted.size(0), cut->full_ranges,
+                                         cut->bin_rec, cut->N, cut->mh, cut->tile_counts, cut->cut_ws,
+                                         (uint64_t*)okeys.data_ptr<int64_t>(), r.overflow_sorted.data_ptr<int32_t>(),
+                                         cut->overflow_capacity, bg.data_ptr(), W, H, row0, row1,
+                                         r.cut_flags.data_ptr<int32_t>(), r.nsp.data_ptr<int32_t>(), r.fw.data_ptr(),
+                                         r.image.data_ptr(), tile_cost, cut->host_flagged, masks_p, stream);
         });
         std::lock_guard<std::mutex> lock(g_mutex);
         if (g_flag_log.size() < 512) g_flag_log.push_back(r.cut_flags);
@@ -320,11 +326,14 @@ RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* 
     void* seg_p = segments ? r.seg.data_ptr() : nullptr;
     if (sort_prefix && sorted.size(0) > sort_prefix) {
         Tensor flags = torch::empty({(int64_t)ntx * nty}, opt.dtype(torch::kInt32));
+        if (g_touch_masks) r.masks = torch::empty({T * 64}, opt.dtype(torch::kInt64));
+        uint64_t* masks_p = r.masks.defined() ? (uint64_t*)r.masks.data_ptr<int64_t>() : nullptr;
         timed("gs_render_tiles_prefix", stream, [&] {
-            return gs_render_tiles_prefix_phased(packed, rgbr, ranges, sorted.data_ptr<int32_t>(),
-                                                 (const uint64_t*)keys.data_ptr<int64_t>(), sorted.size(0), bg.data_ptr(), W, H,
-                                                 row0, row1, flags.data_ptr<int32_t>(), r.nsp.data_ptr<int32_t>(),
-                                                 r.fw.data_ptr(), r.image.data_ptr(), tile_cost, seg_p, prefix_phases, stream);
+            return gs_render_tiles_prefix_phased_m(packed, rgbr, ranges, sorted.data_ptr<int32_t>(),
+                                                   (const uint64_t*)keys.data_ptr<int64_t>(), sorted.size(0), bg.data_ptr(), W, H,
+                                                   row0, row1, flags.data_ptr<int32_t>(), r.nsp.data_ptr<int32_t>(),
+                                                   r.fw.data_ptr(), r.image.data_ptr(), tile_cost, seg_p, prefix_phases, masks_p,
+                                                   stream);
         });
         r.prefix_flags = flags;
         std::lock_guard<std::mutex> lock(g_mutex);
@@ -347,11 +356,12 @@ RenderOut render_forward(const float* packed, const float* rgbr, const int32_t* 
 void render_prefix_repair(RenderOut& r, const float* packed, const float* rgbr, const int32_t* ranges, Tensor& sorted,
                           Tensor& keys, const Tensor& bg, int W, int H, int row0, int row1, void* stream) {
     timed("gs_render_tiles_prefix", stream, [&] {
-        return gs_render_tiles_prefix_phased(packed, rgbr, ranges, sorted.data_ptr<int32_t>(),
-                                             (const uint64_t*)keys.data_ptr<int64_t>(), sorted.size(0), bg.data_ptr(), W, H, row0,
-                                             row1, r.prefix_flags.data_ptr<int32_t>(), r.nsp.data_ptr<int32_t>(),
-                                             r.fw.data_ptr(), r.image.data_ptr(), r.tile_cost,
-                                             r.seg.numel() > 0 ? r.seg.data_ptr() : nullptr, GS_PREFIX_REPAIR, stream);
+        return gs_render_tiles_prefix_phased_m(packed, rgbr, ranges, sorted.data_ptr<int32_t>(),
+                                               (const uint64_t*)keys.data_ptr<int64_t>(), sorted.size(0), bg.data_ptr(), W, H, row0,
+                                               row1, r.prefix_flags.data_ptr<int32_t>(), r.nsp.data_ptr<int32_t>(),
+                                               r.fw.data_ptr(), r.image.data_ptr(), r.tile_cost,
+                                               r.seg.numel() > 0 ? r.seg.data_ptr() : nullptr, GS_PREFIX_REPAIR,
+                                               r.masks.defined() ? (uint64_t*)r.masks.data_ptr<int64_t>() : nullptr, stream);
     });
 }
 
@@ -543,15 +553,17 @@ struct Preprocess : public torch::autograd::Function<Preprocess> {
         Tensor flags_t = cut ? out.cut_flags : torch::empty({0}, i32);
         Tensor full_ranges_t = cut ? iar.block(8, T + 1) : torch::empty({0}, i32);
         Tensor overflow_t = cut ? out.overflow_sorted : torch::empty({0}, i32);
+        // the touch masks the forward left for the backward (empty: the backward builds its own)
+        Tensor masks_t = out.masks.defined() ? out.masks : torch::empty({0}, i32.dtype(torch::kInt64));
         ctx->save_for_backward({xyz, quaternion, scale, camera_T_world, K, far.block(0, 3), iar.block(2, N),
                                 far.block(4, N).view({N, 1})});
         ctx->saved_data["n_sh"] = (int64_t)n_sh;
         ctx->saved_data["V"] = V;
         ctx->set_materialize_grads(false);
         ctx->mark_non_differentiable({packed_t, ranges_t, sorted_g, mask_t, out.image, out.fw, out.nsp, out.seg, flags_t,
-                                      full_ranges_t, overflow_t});
+                                      full_ranges_t, overflow_t, masks_t});
         return {uv_t, conic_t, opa_t, rgbr_t, packed_t, ranges_t, sorted_g, mask_t, out.image, out.fw, out.nsp, out.seg,
-                flags_t, full_ranges_t, overflow_t};
+                flags_t, full_ranges_t, overflow_t, masks_t};
     }
 
     static variable_list backward(AutogradContext* ctx, variable_list g) {
@@ -616,8 +628,9 @@ struct Preprocess : public torch::autograd::Function<Preprocess> {
 struct Render : public torch::autograd::Function<Render> {
     static Tensor forward(AutogradContext* ctx, Tensor uv, Tensor conic, Tensor opacity, Tensor rgbr, Tensor packed,
                           Tensor ranges, Tensor sorted_g, Tensor bg, Tensor image, Tensor fw, Tensor nsp, Tensor seg,
-                          Tensor cut_flags, Tensor full_ranges, Tensor overflow_sorted, int64_t row0, int64_t row1) {
-        ctx->save_for_backward({packed, rgbr, ranges, sorted_g, bg, nsp, fw, seg, cut_flags, full_ranges, overflow_sorted});
+                          Tensor cut_flags, Tensor full_ranges, Tensor overflow_sorted, Tensor masks, int64_t row0,
+                          int64_t row1) {
+        ctx->save_for_backward({packed, rgbr, ranges, sorted_g, bg, nsp, fw, seg, cut_flags, full_ranges, overflow_sorted, masks});
         ctx->saved_data["row0"] = row0;
         ctx->saved_data["row1"] = row1;
         ctx->saved_data["V"] = uv.size(0);
@@ -629,11 +642,11 @@ struct Render : public torch::autograd::Function<Render> {
     }
 
     static variable_list backward(AutogradContext* ctx, variable_list g) {
-        variable_list out(17);
+        variable_list out(18);
         if (!g[0].defined()) return out;
         auto s = ctx->get_saved_variables();
         const Tensor &packed = s[0], &rgbr = s[1], &ranges = s[2], &sorted_g = s[3], &bg = s[4], &nsp = s[5], &fw = s[6],
-                     &seg = s[7], &cut_flags = s[8], &full_ranges = s[9], &overflow_sorted = s[10];
+                     &seg = s[7], &cut_flags = s[8], &full_ranges = s[9], &overflow_sorted = s[10], &masks = s[11];
         const bool cut = cut_flags.numel() > 0;
         const int64_t V = ctx->saved_data["V"].toInt();
         const int H = (int)nsp.size(0), W = (int)nsp.size(1);
@@ -655,15 +668,17 @@ struct Render : public torch::autograd::Function<Render> {
                                                ordered ? tile_cost + T : nullptr, W, H, row0, row1, stream);
         });
         timed("gs_render_tiles_backward_slab", stream, [&] {
-            return gs_render_tiles_backward_slab(packed.data_ptr(), rgbr.data_ptr(), ranges.data_ptr<int32_t>(),
-                                                 sorted_g.data_ptr<int32_t>(), bg.data_ptr(), nsp.data_ptr<int32_t>(),
-                                                 fw.data_ptr(), grad_image.data_ptr(), W, H, row0, row1, slab.data_ptr(),
-                                                 0, nullptr, ordered ? tile_cost + T : nullptr,
-                                                 segmented ? seg.data_ptr() : nullptr,
-                                                 cut ? cut_flags.data_ptr<int32_t>() : nullptr,
-                                                 cut ? full_ranges.data_ptr<int32_t>() : nullptr,
-                                                 cut ? overflow_sorted.data_ptr<int32_t>() : nullptr,
-                                                 (int)ctx->saved_data["bwd_mode"].toInt(), stream);
+            return gs_render_tiles_backward_slab_m(packed.data_ptr(), rgbr.data_ptr(), ranges.data_ptr<int32_t>(),
+                                                   sorted_g.data_ptr<int32_t>(), bg.data_ptr(), nsp.data_ptr<int32_t>(),
+                                                   fw.data_ptr(), grad_image.data_ptr(), W, H, row0, row1, slab.data_ptr(),
+                                                   0, nullptr, ordered ? tile_cost + T : nullptr,
+                                                   segmented ? seg.data_ptr() : nullptr,
+                                                   cut ? cut_flags.data_ptr<int32_t>() : nullptr,
+                                                   cut ? full_ranges.data_ptr<int32_t>() : nullptr,
+                                                   cut ? overflow_sorted.data_ptr<int32_t>() : nullptr,
+                                                   (int)ctx->saved_data["bwd_mode"].toInt(),
+                                                   masks.numel() > 0 ? (const uint64_t*)masks.data_ptr<int64_t>() : nullptr,
+                                                   stream);
         });
         Tensor rows = slab.narrow(0, 0, V);
         out[0] = rows.narrow(1, 4, 2);   // uv
@@ -705,7 +720,7 @@ std::tuple<Tensor, Tensor, Tensor> rasterize(Tensor xyz, Tensor quaternion, Tens
                                rgb.contiguous(), sh, camera_T_world.contiguous(), K.contiguous(), background_rgb.contiguous(),
                                width, height, near_thresh, far_thresh, cull_mask_padding, mh_dist, row0, row1);
     Tensor image = Render::apply(o[0], o[1], o[2], o[3], o[4], o[5], o[6], background_rgb.contiguous(), o[8], o[9], o[10],
-                                 o[11], o[12], o[13], o[14], row0, row1);
+                                 o[11], o[12], o[13], o[14], o[15], row0, row1);
     return std::make_tuple(image, o[7], o[0]);
 }
 
@@ -1166,12 +1181,14 @@ struct OwnerRender : public torch::autograd::Function<OwnerRender> {
             return gs_render_backward_prologue(slab.data_ptr(), slab.size(0), nullptr, nullptr, W, H, fr.row0, fr.row1, stream);
         });
         timed("gs_render_tiles_backward_slab", stream, [&] {
-            return gs_render_tiles_backward_slab(fr.packed.data_ptr(), fr.rgbr.data_ptr(), fr.ranges.data_ptr<int32_t>(),
-                                                 fr.sorted_g.data_ptr<int32_t>(), fr.bg.data_ptr(), fr.out.nsp.data_ptr<int32_t>(),
-                                                 fr.out.fw.data_ptr(), grad_image.data_ptr(), W, H, fr.row0, fr.row1,
-                                                 slab.data_ptr(), 0, nullptr, nullptr,
-                                                 segmented ? fr.out.seg.data_ptr() : nullptr, nullptr, nullptr, nullptr,
-                                                 fr.bwd_mode, stream);
+            return gs_render_tiles_backward_slab_m(fr.packed.data_ptr(), fr.rgbr.data_ptr(), fr.ranges.data_ptr<int32_t>(),
+                                                   fr.sorted_g.data_ptr<int32_t>(), fr.bg.data_ptr(), fr.out.nsp.data_ptr<int32_t>(),
+                                                   fr.out.fw.data_ptr(), grad_image.data_ptr(), W, H, fr.row0, fr.row1,
+                                                   slab.data_ptr(), 0, nullptr, nullptr,
+                                                   segmented ? fr.out.seg.data_ptr() : nullptr, nullptr, nullptr, nullptr,
+                                                   fr.bwd_mode,
+                                                   fr.out.masks.defined() ? (const uint64_t*)fr.out.masks.data_ptr<int64_t>() : nullptr,
+                                                   stream);
         });
         // rows of the send list -> owners; rows of the owned range <- the ranks whose band they reach
         int64_t n_send = 0, n_recv = 0;
@@ -1468,6 +1485,7 @@ void set_depth_cut(int mode, int64_t min_mean_list) {
 }
 void set_band_compact(bool on) { g_band_compact = on; }
 void set_band_fused(bool on) { g_band_fused = on; }
+void set_touch_masks(bool on) { g_touch_masks = on; }
 
 void set_modes(bool sort_prefix, bool early_render) {
     g_sort_prefix = sort_prefix;
@@ -1500,6 +1518,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("set_depth_cut", &set_depth_cut, py::arg("mode"), py::arg("min_mean_list") = 0);
     m.def("set_band_compact", &set_band_compact, py::arg("on"));
     m.def("set_band_fused", &set_band_fused, py::arg("on"));
+    m.def("set_touch_masks", &set_touch_masks, py::arg("on"));
+    if (const char* e = std::getenv("GSPLAT_TOUCH_MASKS")) g_touch_masks = std::atoi(e) != 0;   // (A/B runs of bench.py)
     m.def("last_tile_flags", &last_tile_flags, py::arg("clear") = false);
     m.def("enable_timing", &enable_timing, py::arg("on"), py::arg("only") = std::string());
     m.def("reserve_events", &reserve_events);

@@ -416,6 +416,14 @@ __device__ inline void build_touch_masks_by_patch(const T* s_geom, int cnt, int 
     if (r == 0) s_mask[p][0] = m;
 }
 
+// Touch masks handed from the forward to the backward (round 6).  The backward walks the same lists as the forward and
+// needs the same (64 entries x 4 patches) touch masks; the forward, which builds them for every chunk it stages, leaves
+// the first GS_MASK_WORDS words of every tile behind: touch_masks[(tile * GS_MASK_WORDS + word) * 4 + patch], 512 bytes
+// per tile of the GRID (the words beyond -- complete lists walked deeper than 1024 entries -- the backward builds itself).
+// Whatever list a tile's final forward pass rendered from (ordered prefix, kept depth prefix, or the complete list of a
+// flagged tile's repair pass) is the list its backward walks, and the last pass to render the tile wrote the words.
+constexpr int GS_MASK_WORDS = GS_SORT_PREFIX / 64;
+
 // colour of splat i of the staged chunk at this pixel's view direction
 template <typename T, int N_SH>
 __device__ inline void splat_colour(const T* s_geom, const T* s_col, int i, const T* Y, T* col) {
@@ -630,7 +638,7 @@ __device__ __forceinline__ void render_tile_fwd(
     bool flagged_only, int64_t cap, int* __restrict__ tile_cost = nullptr,
     const T* __restrict__ src_opacity = nullptr, const T* __restrict__ src_conic = nullptr,
     const SegState seg = SEG_NONE, const int* __restrict__ full_ranges = nullptr,
-    int* __restrict__ flag_counter = nullptr) {
+    int* __restrict__ flag_counter = nullptr, unsigned long long* __restrict__ touch_masks = nullptr) {
     static_assert(!CK || (sizeof(T) == 4 && N_SH == 1), "segment checkpoints: the fused renderer's kernel only");
     constexpr bool fast = sizeof(T) == 4;
     // the tile's own duration in 16-cycle units: the launch-order key of the backward (tile_order_body)
@@ -710,6 +718,13 @@ __device__ __forceinline__ void render_tile_fwd(
         // (no barrier in between: thread t tests the record thread t staged)
         build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
         __syncthreads();
+        if constexpr (fast && N_SH == 1) {
+            // the chunk's masks for the backward (see GS_MASK_WORDS): thread (word, patch) stores one 8-byte word
+            if (touch_masks != nullptr && tid < 4 * NW) {
+                const int word = base / 64 + (tid >> 2);
+                if (word < GS_MASK_WORDS) touch_masks[((size_t)tile * GS_MASK_WORDS + word) * 4 + (tid & 3)] = s_mask[tid & 3][tid >> 2];
+            }
+        }
         GS_PHASE(1);
         if constexpr (fast && N_SH == 1) {
             // pipelined walk: the record of the next visit is in flight while this one is composited
@@ -935,12 +950,12 @@ __global__ __launch_bounds__(RB) void k_render_fwd(
     int W, int H, int ntx, int tile0, int nt, int* __restrict__ nsp_out, T* __restrict__ fw_out,
     T* __restrict__ image, int sort_prefix, int* __restrict__ tile_flags, int64_t cap,
     int* __restrict__ tile_cost, const T* __restrict__ src_opacity, const T* __restrict__ src_conic,
-    const int* __restrict__ full_ranges, int* __restrict__ flag_counter) {
+    const int* __restrict__ full_ranges, int* __restrict__ flag_counter, unsigned long long* __restrict__ touch_masks) {
     const int t_local = tile_of_block(blockIdx.x, nt);
     if (t_local >= nt) return;
     render_tile_fwd<T, N_SH>(tile0 + t_local, packed, rgb, view_dir, ranges, sorted, bg, W, H, ntx,
                              nsp_out, fw_out, image, sort_prefix, tile_flags, false, cap, tile_cost, src_opacity,
-                             src_conic, SEG_NONE, full_ranges, flag_counter);
+                             src_conic, SEG_NONE, full_ranges, flag_counter, touch_masks);
 }
 
 // the fused renderer's forward that also leaves the state for the depth-segmented backward
@@ -951,12 +966,13 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(GS_FWD_CK_WA
     const float* __restrict__ packed, const float* __restrict__ rgb, const int* __restrict__ ranges,
     const int* __restrict__ sorted, const float* __restrict__ bg, int W, int H, int ntx, int tile0, int nt,
     int* __restrict__ nsp_out, float* __restrict__ fw_out, float* __restrict__ image, int sort_prefix,
-    int* __restrict__ tile_flags, int64_t cap, int* __restrict__ tile_cost, const SegState seg) {
+    int* __restrict__ tile_flags, int64_t cap, int* __restrict__ tile_cost, const SegState seg,
+    unsigned long long* __restrict__ touch_masks) {
     const int t_local = tile_of_block(blockIdx.x, nt);
     if (t_local >= nt) return;
     render_tile_fwd<float, 1, true>(tile0 + t_local, packed, rgb, nullptr, ranges, sorted, bg, W, H, ntx, nsp_out,
                                     fw_out, image, sort_prefix, tile_flags, false, cap, tile_cost, nullptr, nullptr,
-                                    seg);
+                                    seg, nullptr, nullptr, touch_masks);
 }
 
 // repair pass of the prefix mode / of the depth cut, ONE launch: a small grid walks the flags; a flagged tile's list is
@@ -971,7 +987,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(GS_FWD_CK_WA
     int nt, int* __restrict__ nsp_out, float* __restrict__ fw_out, float* __restrict__ image,
     int* __restrict__ tile_flags, int64_t cap, int* __restrict__ tile_cost, const SegState seg,
     const int* __restrict__ flag_counter, int* __restrict__ host_flagged, uint64_t* __restrict__ sort_keys,
-    int sort_prefix, int sort_beyond) {
+    int sort_prefix, int sort_beyond, unsigned long long* __restrict__ touch_masks) {
     extern __shared__ uint64_t s_sort_keys[];
     static_assert(RB == SORT_BLOCK, "the repair workgroup sorts with the binning's network");
     // (depth cut) how many tiles of the frame had to be repaired, into the caller's pinned host word: what the
@@ -1000,7 +1016,7 @@ __global__ __launch_bounds__(RB) __attribute__((amdgpu_waves_per_eu(GS_FWD_CK_WA
         }
         render_tile_fwd<float, 1, CK>(tile, packed, rgb, nullptr, ranges, sorted, bg, W, H, ntx,
                                       nsp_out, fw_out, image, 0, tile_flags, true, cap, tile_cost, nullptr, nullptr,
-                                      seg);
+                                      seg, nullptr, nullptr, touch_masks);
         __syncthreads();
     }
 }
@@ -1166,7 +1182,8 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
     int W, int H, int ntx, int tile0, int nt, T* __restrict__ g_rgb, T* __restrict__ g_opa,
     T* __restrict__ g_uv, T* __restrict__ g_conic, int slab, int exact, const int* __restrict__ tile_order,
     const T* __restrict__ src_opacity, const T* __restrict__ src_conic, const SegState seg,
-    const int* __restrict__ cut_flags, const int* __restrict__ full_ranges, const int* __restrict__ overflow_sorted) {
+    const int* __restrict__ cut_flags, const int* __restrict__ full_ranges, const int* __restrict__ overflow_sorted,
+    const unsigned long long* __restrict__ touch_masks) {
     constexpr bool fast = sizeof(T) == 4;
     constexpr int CW = ColW<N_SH>::value;
     constexpr int C = 3 * N_SH;
@@ -1408,9 +1425,17 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
             for (int k = tid; k < cnt * NV; k += RB) s_acc[k] = 0;
         GS_PHASE(0);
         if constexpr (SLOTS && RCHUNK == 64) {
-            // one patch per wave (round 6): the records wave 0 staged have to be visible to the other three first
-            __syncthreads();
-            build_touch_masks_by_patch<T>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
+            if (touch_masks != nullptr && chunk < GS_MASK_WORDS) {
+                // the forward's own masks of this word (GS_MASK_WORDS); entries beyond the used part are not staged here
+                if (tid < 4) {
+                    const unsigned long long keep = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1);
+                    s_mask[tid][0] = touch_masks[((size_t)tile * GS_MASK_WORDS + chunk) * 4 + tid] & keep;
+                }
+            } else {
+                // one patch per wave (round 6): the records wave 0 staged have to be visible to the other three first
+                __syncthreads();
+                build_touch_masks_by_patch<T>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
+            }
         } else {
             // (no barrier in between: thread t tests the record thread t staged)
             build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
@@ -1874,7 +1899,7 @@ static int launch_render_fwd(const void* packed_or_uvs, const void* opacity, con
             (const float*)packed_or_uvs, (const float*)rgb, tile_ranges, sorted_gaussians,
             (const float*)background_rgb, W, H, ntx, tile_row0 * ntx, nt, num_splats_per_pixel,
             (float*)final_weight_per_pixel, (float*)image, 0, nullptr, INT64_MAX, nullptr,
-            seg_state_of(segment_state, W, H, tile_row0, tile_row1));
+            seg_state_of(segment_state, W, H, tile_row0, tile_row1), nullptr);
         return check_launch("render_tiles");
     }
     DISPATCH_T(dtype, DISPATCH_SH(n_sh, (k_render_fwd<T, N_SH><<<grid, RB, 0, s>>>(
@@ -1884,7 +1909,7 @@ static int launch_render_fwd(const void* packed_or_uvs, const void* opacity, con
                                             tile_row0 * ntx, nt, num_splats_per_pixel,
                                             (T*)final_weight_per_pixel, (T*)image, 0,
                                             nullptr, INT64_MAX, nullptr, (const T*)opacity, (const T*)conic, nullptr,
-                                            nullptr))));
+                                            nullptr, nullptr))));
     return check_launch("render_tiles");
 }
 
@@ -1926,11 +1951,11 @@ int gs_render_tiles_prefix(const void* packed, const void* rgb, const int32_t* t
                                          tile_cost, segment_state, GS_PREFIX_RENDER | GS_PREFIX_REPAIR, stream);
 }
 
-int gs_render_tiles_prefix_phased(const void* packed, const void* rgb, const int32_t* tile_ranges,
+int gs_render_tiles_prefix_phased_m(const void* packed, const void* rgb, const int32_t* tile_ranges,
                                   int32_t* sorted_gaussians, const uint64_t* keys, int64_t S,
                                   const void* background_rgb, int W, int H, int tile_row0, int tile_row1,
                                   int32_t* tile_flags, int32_t* num_splats_per_pixel, void* final_weight_per_pixel,
-                                  void* image, int32_t* tile_cost, void* segment_state, int phases, void* stream) {
+                                  void* image, int32_t* tile_cost, void* segment_state, int phases, uint64_t* touch_masks, void* stream) {
     GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
     GS_REQUIRE(phases >= 1 && phases <= 3, "phases: GS_PREFIX_RENDER, GS_PREFIX_REPAIR or both");
     GS_REQUIRE(tile_flags != nullptr, "tile_flags must not be null");
@@ -1949,13 +1974,13 @@ int gs_render_tiles_prefix_phased(const void* packed, const void* rgb, const int
             k_render_fwd_ck<<<grid, RB, 0, s>>>(
                 (const float*)packed, (const float*)rgb, tile_ranges, sorted_gaussians, (const float*)background_rgb, W, H,
                 ntx, t0, nt, num_splats_per_pixel, (float*)final_weight_per_pixel, (float*)image, GS_SORT_PREFIX,
-                tile_flags, S, tile_cost, seg);
+                tile_flags, S, tile_cost, seg, (unsigned long long*)touch_masks);
         else
             k_render_fwd<float, 1><<<grid, RB, GS_FWD_LDS_PAD, s>>>(
                 (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians,
                 (const float*)background_rgb, W, H, ntx, t0, nt, num_splats_per_pixel,
                 (float*)final_weight_per_pixel, (float*)image, GS_SORT_PREFIX, tile_flags, S, tile_cost, nullptr, nullptr,
-                nullptr, nullptr);
+                nullptr, nullptr, (unsigned long long*)touch_masks);
     }
     if ((phases & GS_PREFIX_REPAIR) && S > GS_SORT_PREFIX) {
         // 2. flagged tiles: full sort + render again, one launch (exits at once on a dense scene)
@@ -1965,25 +1990,35 @@ int gs_render_tiles_prefix_phased(const void* packed, const void* rgb, const int
             k_render_fwd_flagged<true><<<nt < 512 ? nt : 512, RB, lds, s>>>(
                 (const float*)packed, (const float*)rgb, tile_ranges, sorted_gaussians, (const float*)background_rgb, W, H, ntx,
                 t0, nt, num_splats_per_pixel, (float*)final_weight_per_pixel, (float*)image, tile_flags, S, tile_cost, seg,
-                nullptr, nullptr, const_cast<uint64_t*>(keys), GS_SORT_PREFIX, 0);
+                nullptr, nullptr, const_cast<uint64_t*>(keys), GS_SORT_PREFIX, 0, (unsigned long long*)touch_masks);
         } else {
             repair_attr_once<false>();
             k_render_fwd_flagged<false><<<nt < 512 ? nt : 512, RB, lds, s>>>(
                 (const float*)packed, (const float*)rgb, tile_ranges, sorted_gaussians, (const float*)background_rgb, W, H, ntx,
                 t0, nt, num_splats_per_pixel, (float*)final_weight_per_pixel, (float*)image, tile_flags, S, tile_cost, seg,
-                nullptr, nullptr, const_cast<uint64_t*>(keys), GS_SORT_PREFIX, 0);
+                nullptr, nullptr, const_cast<uint64_t*>(keys), GS_SORT_PREFIX, 0, (unsigned long long*)touch_masks);
         }
     }
     return check_launch("render_tiles_prefix");
 }
 
+int gs_render_tiles_prefix_phased(const void* packed, const void* rgb, const int32_t* tile_ranges,
+                                  int32_t* sorted_gaussians, const uint64_t* keys, int64_t S,
+                                  const void* background_rgb, int W, int H, int tile_row0, int tile_row1,
+                                  int32_t* tile_flags, int32_t* num_splats_per_pixel, void* final_weight_per_pixel,
+                                  void* image, int32_t* tile_cost, void* segment_state, int phases, void* stream) {
+    return gs_render_tiles_prefix_phased_m(packed, rgb, tile_ranges, sorted_gaussians, keys, S, background_rgb, W, H, tile_row0,
+                                           tile_row1, tile_flags, num_splats_per_pixel, final_weight_per_pixel, image, tile_cost,
+                                           segment_state, phases, nullptr, stream);
+}
+
 // the fused renderer's forward on depth-cut lists (binning.hip "depth cut"; gs_tile_count_cut / gs_tile_emit_sort_cut)
-int gs_render_tiles_cut(const void* packed, const void* rgb, const int32_t* tile_ranges, const int32_t* sorted_gaussians,
+int gs_render_tiles_cut_m(const void* packed, const void* rgb, const int32_t* tile_ranges, const int32_t* sorted_gaussians,
                         int64_t S, const int32_t* full_ranges, const void* bin_records, int N, float mh_dist,
                         int32_t* workspace, int32_t* cut_workspace, uint64_t* overflow_keys, int32_t* overflow_sorted,
                         int64_t overflow_capacity, const void* background_rgb, int W, int H, int tile_row0, int tile_row1,
                         int32_t* tile_flags, int32_t* num_splats_per_pixel, void* final_weight_per_pixel, void* image,
-                        int32_t* tile_cost, int32_t* host_flagged, void* stream) {
+                        int32_t* tile_cost, int32_t* host_flagged, uint64_t* touch_masks, void* stream) {
     GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
     GS_REQUIRE(tile_flags != nullptr && full_ranges != nullptr, "tile_flags and full_ranges must not be null");
     if (int e = check_rows(H, tile_row0, tile_row1)) return e;
@@ -1998,7 +2033,7 @@ int gs_render_tiles_cut(const void* packed, const void* rgb, const int32_t* tile
     k_render_fwd<float, 1><<<grid, RB, GS_FWD_LDS_PAD, s>>>(
         (const float*)packed, (const float*)rgb, nullptr, tile_ranges, sorted_gaussians, (const float*)background_rgb, W, H,
         ntx, t0, nt, num_splats_per_pixel, (float*)final_weight_per_pixel, (float*)image, 0, tile_flags, S, tile_cost,
-        nullptr, nullptr, full_ranges, flag_counter);
+        nullptr, nullptr, full_ranges, flag_counter, (unsigned long long*)touch_masks);
     // 2. + 3. flagged tiles: complete lists into the overflow buffers; sorted and rendered again by one workgroup each
     // (both launches exit at once while the frame has no flagged tile)
     if (int e = depth_cut_repair((const float*)bin_records, N, ntx, nty, mh_dist, tile_row0, tile_row1, full_ranges, workspace,
@@ -2008,8 +2043,20 @@ int gs_render_tiles_cut(const void* packed, const void* rgb, const int32_t* tile
     k_render_fwd_flagged<false><<<nt < 512 ? nt : 512, RB, sort_lds_bytes(SORT_MAX_LDS_KEYS), s>>>(
         (const float*)packed, (const float*)rgb, full_ranges, overflow_sorted, (const float*)background_rgb, W, H, ntx, t0,
         nt, num_splats_per_pixel, (float*)final_weight_per_pixel, (float*)image, tile_flags, overflow_capacity, tile_cost,
-        SEG_NONE, flag_counter, host_flagged, overflow_keys, 0, 1);
+        SEG_NONE, flag_counter, host_flagged, overflow_keys, 0, 1, (unsigned long long*)touch_masks);
     return check_launch("render_tiles_cut");
+}
+
+int gs_render_tiles_cut(const void* packed, const void* rgb, const int32_t* tile_ranges, const int32_t* sorted_gaussians,
+                        int64_t S, const int32_t* full_ranges, const void* bin_records, int N, float mh_dist,
+                        int32_t* workspace, int32_t* cut_workspace, uint64_t* overflow_keys, int32_t* overflow_sorted,
+                        int64_t overflow_capacity, const void* background_rgb, int W, int H, int tile_row0, int tile_row1,
+                        int32_t* tile_flags, int32_t* num_splats_per_pixel, void* final_weight_per_pixel, void* image,
+                        int32_t* tile_cost, int32_t* host_flagged, void* stream) {
+    return gs_render_tiles_cut_m(packed, rgb, tile_ranges, sorted_gaussians, S, full_ranges, bin_records, N, mh_dist, workspace,
+                                 cut_workspace, overflow_keys, overflow_sorted, overflow_capacity, background_rgb, W, H, tile_row0,
+                                 tile_row1, tile_flags, num_splats_per_pixel, final_weight_per_pixel, image, tile_cost,
+                                 host_flagged, nullptr, stream);
 }
 
 static int launch_render_bwd(const void* packed_or_uvs, const void* opacity, const void* conic, const void* rgb,
@@ -2036,7 +2083,7 @@ static int launch_render_bwd(const void* packed_or_uvs, const void* opacity, con
                                      (const T*)grad_image, W, H, ntx, tile_row0 * ntx, nt,
                                      (T*)grad_rgb, (T*)grad_opacity, (T*)grad_uv,
                                      (T*)grad_conic, 0, exact, nullptr, (const T*)opacity,
-                                     (const T*)conic, SEG_NONE, nullptr, nullptr, nullptr))));
+                                     (const T*)conic, SEG_NONE, nullptr, nullptr, nullptr, nullptr))));
     return check_launch("render_tiles_backward");
 }
 
@@ -2095,14 +2142,14 @@ int gs_render_backward_prologue(void* grad_slab, int64_t zero_slab_rows, const i
     return check_launch("render_backward_prologue");
 }
 
-int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int32_t* tile_ranges,
+int gs_render_tiles_backward_slab_m(const void* packed, const void* rgb, const int32_t* tile_ranges,
                                   const int32_t* sorted_gaussians, const void* background_rgb,
                                   const int32_t* num_splats_per_pixel,
                                   const void* final_weight_per_pixel, const void* grad_image, int W,
                                   int H, int tile_row0, int tile_row1, void* grad_slab, int64_t zero_slab_rows,
                                   const int32_t* tile_cost, int32_t* tile_order, const void* segment_state,
                                   const int32_t* cut_flags, const int32_t* full_ranges, const int32_t* overflow_sorted,
-                                  int backward_mode, void* stream) {
+                                  int backward_mode, const uint64_t* touch_masks, void* stream) {
     GS_REQUIRE(W > 0 && H > 0, "image must be non-empty");
     GS_REQUIRE(tile_cost == nullptr || tile_order != nullptr, "tile_cost needs tile_order (tile_cost and tile_order go together)");
     GS_REQUIRE((cut_flags == nullptr) == (full_ranges == nullptr) && (cut_flags == nullptr) == (overflow_sorted == nullptr),
@@ -2137,7 +2184,7 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
             (const float*)background_rgb, num_splats_per_pixel, (const float*)final_weight_per_pixel,
             (const float*)grad_image, W, H, ntx, tile_row0 * ntx, nt, (float*)grad_slab, nullptr,
             nullptr, nullptr, 1, exact, nullptr, nullptr, nullptr, seg_state_of((void*)segment_state, W, H, tile_row0, tile_row1),
-            cut_flags, full_ranges, overflow_sorted);
+            cut_flags, full_ranges, overflow_sorted, (const unsigned long long*)touch_masks);
         return check_launch("render_tiles_backward_slab");
     }
     k_render_bwd<float, 1><<<grid, RB, GS_BWD_LDS_PAD, s>>>(
@@ -2145,8 +2192,22 @@ int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int
         (const float*)background_rgb, num_splats_per_pixel, (const float*)final_weight_per_pixel,
         (const float*)grad_image, W, H, ntx, tile_row0 * ntx, nt, (float*)grad_slab, nullptr,
         nullptr, nullptr, 1, exact, use_order ? tile_order : nullptr, nullptr, nullptr,
-        SEG_NONE, cut_flags, full_ranges, overflow_sorted);
+        SEG_NONE, cut_flags, full_ranges, overflow_sorted, (const unsigned long long*)touch_masks);
     return check_launch("render_tiles_backward_slab");
+}
+
+int gs_render_tiles_backward_slab(const void* packed, const void* rgb, const int32_t* tile_ranges,
+                                  const int32_t* sorted_gaussians, const void* background_rgb,
+                                  const int32_t* num_splats_per_pixel,
+                                  const void* final_weight_per_pixel, const void* grad_image, int W,
+                                  int H, int tile_row0, int tile_row1, void* grad_slab, int64_t zero_slab_rows,
+                                  const int32_t* tile_cost, int32_t* tile_order, const void* segment_state,
+                                  const int32_t* cut_flags, const int32_t* full_ranges, const int32_t* overflow_sorted,
+                                  int backward_mode, void* stream) {
+    return gs_render_tiles_backward_slab_m(packed, rgb, tile_ranges, sorted_gaussians, background_rgb, num_splats_per_pixel,
+                                           final_weight_per_pixel, grad_image, W, H, tile_row0, tile_row1, grad_slab, zero_slab_rows,
+                                           tile_cost, tile_order, segment_state, cut_flags, full_ranges, overflow_sorted,
+                                           backward_mode, nullptr, stream);
 }
 
 int gs_render_depth(const void* packed, const void* xyz_camera_frame, const int32_t* tile_ranges,

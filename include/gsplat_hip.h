@@ -480,6 +480,34 @@ int gs_preprocess_forward_list(const void* xyz, const void* quaternion, const vo
                                const void* uv, const void* opacity_act, void* uv_l, void* xyz_camera_frame_l, void* conic_l,
                                void* packed_l, void* stream);
 
+/* ---- touch masks handed from the render forward to the render backward (ABI 8; no reference counterpart) -------
+ * The fused backward walks the lists its forward walked and needs the same (64 entries x 4 patches) touch masks.  The
+ * `_m` forms of the fused frame's three render entries take touch_masks: uint64[n_tiles_of_the_GRID * 16 * 4] (512 bytes
+ * per tile; NULL = the forms without `_m`).  The forward (its repair pass included) stores the masks of the first 1024
+ * list entries of every tile it renders: touch_masks[(tile * 16 + word) * 4 + patch]; the backward reads them instead
+ * of evaluating 256 ellipse-rectangle tests per 64-entry chunk, and builds the words beyond itself.  Results are
+ * bit-identical with and without.  The buffer must be the one the SAME frame's forward wrote. */
+int gs_render_tiles_prefix_phased_m(const void* packed, const void* rgb, const int32_t* tile_ranges,
+                                    int32_t* sorted_gaussians, const uint64_t* keys, int64_t S,
+                                    const void* background_rgb, int W, int H, int tile_row0, int tile_row1,
+                                    int32_t* tile_flags, int32_t* num_splats_per_pixel, void* final_weight_per_pixel,
+                                    void* image, int32_t* tile_cost, void* segment_state, int phases, uint64_t* touch_masks,
+                                    void* stream);
+int gs_render_tiles_cut_m(const void* packed, const void* rgb, const int32_t* tile_ranges, const int32_t* sorted_gaussians,
+                          int64_t S, const int32_t* full_ranges, const void* bin_records, int N, float mh_dist,
+                          int32_t* workspace, int32_t* cut_workspace, uint64_t* overflow_keys, int32_t* overflow_sorted,
+                          int64_t overflow_capacity, const void* background_rgb, int W, int H, int tile_row0, int tile_row1,
+                          int32_t* tile_flags, int32_t* num_splats_per_pixel, void* final_weight_per_pixel, void* image,
+                          int32_t* tile_cost, int32_t* host_flagged, uint64_t* touch_masks, void* stream);
+int gs_render_tiles_backward_slab_m(const void* packed, const void* rgb, const int32_t* tile_ranges,
+                                    const int32_t* sorted_gaussians, const void* background_rgb,
+                                    const int32_t* num_splats_per_pixel, const void* final_weight_per_pixel,
+                                    const void* grad_image, int W, int H, int tile_row0, int tile_row1, void* grad_slab,
+                                    int64_t zero_slab_rows, const int32_t* tile_cost, int32_t* tile_order,
+                                    const void* segment_state, const int32_t* cut_flags, const int32_t* full_ranges,
+                                    const int32_t* overflow_sorted, int backward_mode, const uint64_t* touch_masks,
+                                    void* stream);
+
 /* ---- multi-GPU: the fused band frontend (ABI 8; no reference counterpart) --------------------------------------
  * gs_band_frontend = gs_band_project + gs_halo_plan_masked + gs_preprocess_forward_list in four launches instead of
  * nine, with every count taken per 256-block of the GAUSSIAN index (owner slices are whole such blocks, so the
