@@ -1160,7 +1160,7 @@ def time_train_loop(iters, dev, n_start=140_000, n_cameras=24, W=1297, H=840, tr
                     "185 s to 1.52 M Gaussians on an RTX 4090 (BASELINE.md, README.md:26)"}
 
 
-def _time_workload(name, fused_mod, dev, steps, warmup, spinup=20):
+def _time_workload(name, fused_mod, dev, steps, warmup, spinup=60, respin=10):
     """A BASELINE.json configuration next to the headline one (other_workloads): the same step (forward +
     backward to dense gradients, inputs resident), its measured counts, the per-entry GPU times (events over
     the warm-up frames) and a `roofline` sub-object for its dominant entry point, whose launch duration is
@@ -1196,6 +1196,8 @@ def _time_workload(name, fused_mod, dev, steps, warmup, spinup=20):
     per_entry = {k: (sum(v) / len(v), len(v) / max(warmup, 1)) for k, v in table.items() if v}
     ranked = [k for k in per_entry if k.startswith("gs_")]
     dom = max(ranked, key=lambda k: per_entry[k][0] * per_entry[k][1]) if ranked else None
+    for _ in range(respin):   # (no idle GPU -- no clock ramp -- in front of the timed frames; see timed() of the headline)
+        step()
     torch.cuda.synchronize()
     _hip.enable_timing(True, only=dom)
     t0 = time.perf_counter()
