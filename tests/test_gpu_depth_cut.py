@@ -300,3 +300,57 @@ def test_cut_frame_with_degenerate_depth_distributions(case, native):
     report(f"depth_cut_degenerate[{case}, {'native' if native else 'python'}]",
            flagged_tiles=-1 if flags is None else int(flags.sum()), tiles=((W + 15) // 16) * ((H + 15) // 16),
            max_grad_scaled_err=max(errs.values()))
+
+
+@pytest.mark.parametrize("case", ["dense_cut", "faint_cut_repair", "mixed_cut_repair", "prefix_no_cut", "band_segments"])
+def test_touch_masks_from_the_forward_change_no_result(case):
+    """The native frame's backward reads the touch masks its forward left (`_m` render entries, ABI 8) instead of
+    rebuilding them.  Same frame with and without the hand-off: image bit-identical and gradients up to summation
+    order -- on kept depth prefixes, on tiles repaired from their complete lists (the repair pass rewrites their
+    words), on prefix-sorted complete lists deeper than the 1024 entries the buffer covers (the backward builds
+    the words beyond itself), and on a band with the depth-segmented backward."""
+    nat = fused.native()
+    if nat is None:
+        pytest.skip("native frame module not built")
+    W, H = (320, 240) if case != "band_segments" else (640, 480)
+    N = {"dense_cut": 400_000, "faint_cut_repair": 300_000, "mixed_cut_repair": 300_000, "prefix_no_cut": 400_000,
+         "band_segments": 600_000}[case]
+    g, cam, T = make_scene(N, W, H, 0, seed=9, device=DEV)
+    if case == "faint_cut_repair":
+        g.opacity.fill_(-5.0)
+    if case == "mixed_cut_repair":
+        g.opacity[g.xyz[:, 0] < 0] = -5.5
+    if case == "prefix_no_cut":
+        g.opacity.fill_(-4.0)   # pixels composite deeper than 1024 entries: words beyond the buffer
+    gi = make_grad_image(W, H, seed=3, device=DEV)
+    cut = case.endswith("cut") or case.endswith("repair")
+    rows = (8, 14) if case == "band_segments" else None
+
+    def frame(masks_on):
+        nat.set_touch_masks(masks_on)
+        prev = fused.DEPTH_CUT, fused.NATIVE
+        fused.DEPTH_CUT, fused.NATIVE = cut, True
+        try:
+            for k in PARAMS:
+                p = getattr(g, k)
+                if p is not None:
+                    p.grad = None
+                    p.requires_grad_(True)
+            bg = torch.full((3,), 0.5, device=DEV)
+            img, mask, uv = fused.rasterize(g, T, cam, use_sh_precompute=True, background_rgb=bg, tile_rows=rows, **DEFAULTS)
+            img.backward(gi)
+            return img.detach().clone(), {k: getattr(g, k).grad.clone() for k in PARAMS if getattr(g, k) is not None}
+        finally:
+            fused.DEPTH_CUT, fused.NATIVE = prev
+
+    try:
+        frame(True)   # (capacity hints of the shape)
+        img1, g1 = frame(True)
+        img0, g0 = frame(False)
+    finally:
+        nat.set_touch_masks(True)
+    assert torch.equal(img1, img0)
+    errs = {k: scaled_err(g1[k], g0[k]) for k in g0}
+    assert max(errs.values()) < 1e-5, errs
+    assert any(bool((v != 0).any()) for v in g1.values())
+    report(f"touch_mask_handoff[{case}]", max_grad_scaled_err=max(errs.values()))
