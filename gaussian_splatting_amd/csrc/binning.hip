@@ -45,6 +45,7 @@ constexpr int BIN_BLOCK = 256;
 struct Sat {
     float mnx, mxx, mny, mxy;
     float ax[2], ay[2], mn_o[2], mx_o[2];
+    bool separable;   // the per-candidate test may take the separable form (sat_separable below)
 };
 
 __device__ inline Sat sat_setup(const Obb& o) {
@@ -84,6 +85,61 @@ __device__ inline bool sat_overlaps(const Sat& s, float l, float r, float t, flo
     return true;
 }
 
+// The separable form of the two OBB-axis tests.  With tile corners (l|r, t|b) the reference projects all four onto
+// the axis, ax*x + ay*y, and takes their least and greatest.  Rounding is monotone: fl(ax*x) is least at the same x
+// for every y, and fl(p + q) does not decrease when p or q grows -- so, as long as no product is NaN or infinite,
+//     min over corners fl(fl(ax*x) + fl(ay*y))  ==  fl( min(fl(ax*l), fl(ax*r)) + min(fl(ay*t), fl(ay*b)) )
+// bit for bit, and likewise the greatest: 4 products and 2 sums per axis instead of 8 and 4, the x half the same for
+// a whole tile column, and a tile's bottom products its lower neighbour's top products.  sat_separable() says when
+// that holds: axes and extents finite and far from overflow (tile coordinates are < 2^24, so |axis| < 1e30 keeps
+// every product and sum finite).  Such a Gaussian's candidate window has also been shrunk to the tiles that pass the
+// x and y tests (tile_walk_setup_vals), so those two are not evaluated again; the extents must not be denormal for
+// that (the shrink divides them by 16).  Any other Gaussian takes sat_overlaps, the reference's form.
+__device__ inline bool sat_separable(const Sat& s) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 2; k++) ok = ok && __builtin_fabsf(s.ax[k]) < 1.0e30f && __builtin_fabsf(s.ay[k]) < 1.0e30f;
+    const float e[4] = {s.mnx, s.mxx, s.mny, s.mxy};
+#pragma unroll
+    for (int k = 0; k < 4; k++) ok = ok && __builtin_fabsf(e[k]) < 1.0e30f && (e[k] == 0.0f || __builtin_fabsf(e[k]) > 1.0e-30f);
+    return ok;   // (a NaN fails every comparison above)
+}
+// the x half of both axes for the tile column [l, r]
+struct SatColumn {
+    float mn[2], mx[2];
+};
+__device__ inline SatColumn sat_column(const Sat& s, float l, float r) {
+    SatColumn c;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const float pl = s.ax[k] * l, pr = s.ax[k] * r;
+        c.mn[k] = fminf(pl, pr);
+        c.mx[k] = fmaxf(pl, pr);
+    }
+    return c;
+}
+// yt[k] = ay[k] * t, yb[k] = ay[k] * b
+__device__ inline bool sat_overlaps_separable(const Sat& s, const SatColumn& c, const float* yt, const float* yb) {
+    // (all four comparisons, then one decision: ~20 instructions straight through cost less than four exec-mask
+    // branches that most candidates leave at different points)
+    int rejected = 0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const float mn_t = c.mn[k] + fminf(yt[k], yb[k]);
+        const float mx_t = c.mx[k] + fmaxf(yt[k], yb[k]);
+        rejected |= (int)(mn_t > s.mx_o[k]) | (int)(mx_t < s.mn_o[k]);
+    }
+    return rejected == 0;
+}
+
+// one candidate tile (the walks that hand a lane one tile at a time)
+__device__ inline bool sat_overlaps_tile(const Sat& s, int tx, int ty) {
+    const float l = (float)tx * 16.0f, r = (float)(tx + 1) * 16.0f, t = (float)ty * 16.0f, b = (float)(ty + 1) * 16.0f;
+    if (!s.separable) return sat_overlaps(s, l, r, t, b);
+    const float yt[2] = {s.ay[0] * t, s.ay[1] * t}, yb[2] = {s.ay[0] * b, s.ay[1] * b};
+    return sat_overlaps_separable(s, sat_column(s, l, r), yt, yb);
+}
+
 // Per-Gaussian part of the tile walk: OBB, separating-axis constants and the candidate window
 // (empty window: w.sx >= w.ex).
 struct TileWalk {
@@ -116,6 +172,7 @@ __device__ inline TileWalk tile_walk_setup_vals(float u, float v, float conic0, 
         w.ey = min(w.ey, f2i(fminf(fmaxf(__builtin_floorf(s.mxy / 16.0f) + 1.0f, -big), big)));
     }
     if (w.sx >= w.ex || w.sy >= w.ey) w.sx = w.ex = w.sy = w.ey = 0;
+    tw.s.separable = sat_separable(s);
     tw.w = w;
     return tw;
 }
@@ -170,11 +227,26 @@ __device__ inline void wave_for_each_tile(bool active, const TileWalk& tw, int n
     const int area = active ? (w.ex - w.sx) * (w.ey - w.sy) : 0;
     if (area > 0 && area <= COOP_MIN) {
         if constexpr (LPG == 1) {
-            for (int tx = w.sx; tx < w.ex; tx++) {
-                const float l = (float)tx * 16.0f, r = (float)(tx + 1) * 16.0f;
-                for (int ty = w.sy; ty < w.ey; ty++) {
-                    const float t = (float)ty * 16.0f, b2 = (float)(ty + 1) * 16.0f;
-                    if (want(ty * ntx + tx) && sat_overlaps(tw.s, l, r, t, b2)) emit(ty * ntx + tx, payload);
+            if (tw.s.separable) {
+                for (int tx = w.sx; tx < w.ex; tx++) {
+                    const SatColumn col = sat_column(tw.s, (float)tx * 16.0f, (float)(tx + 1) * 16.0f);
+                    const float t0 = (float)w.sy * 16.0f;
+                    float yt[2] = {tw.s.ay[0] * t0, tw.s.ay[1] * t0};
+                    for (int ty = w.sy; ty < w.ey; ty++) {
+                        const float b2 = (float)(ty + 1) * 16.0f;
+                        const float yb[2] = {tw.s.ay[0] * b2, tw.s.ay[1] * b2};
+                        if (want(ty * ntx + tx) && sat_overlaps_separable(tw.s, col, yt, yb)) emit(ty * ntx + tx, payload);
+                        yt[0] = yb[0];
+                        yt[1] = yb[1];
+                    }
+                }
+            } else {
+                for (int tx = w.sx; tx < w.ex; tx++) {
+                    const float l = (float)tx * 16.0f, r = (float)(tx + 1) * 16.0f;
+                    for (int ty = w.sy; ty < w.ey; ty++) {
+                        const float t = (float)ty * 16.0f, b2 = (float)(ty + 1) * 16.0f;
+                        if (want(ty * ntx + tx) && sat_overlaps(tw.s, l, r, t, b2)) emit(ty * ntx + tx, payload);
+                    }
                 }
             }
         } else {
@@ -182,9 +254,7 @@ __device__ inline void wave_for_each_tile(bool active, const TileWalk& tw, int n
             for (int c = sub; c < area; c += LPG) {
                 const int cx = c / h;
                 const int tx = w.sx + cx, ty = w.sy + (c - cx * h);
-                if (want(ty * ntx + tx) &&
-                    sat_overlaps(tw.s, (float)tx * 16.0f, (float)(tx + 1) * 16.0f, (float)ty * 16.0f, (float)(ty + 1) * 16.0f))
-                    emit(ty * ntx + tx, payload);
+                if (want(ty * ntx + tx) && sat_overlaps_tile(tw.s, tx, ty)) emit(ty * ntx + tx, payload);
             }
         }
     }
@@ -201,6 +271,7 @@ __device__ inline void wave_for_each_tile(bool active, const TileWalk& tw, int n
             s.ax[k] = lane_bcast(tw.s.ax[k], src); s.ay[k] = lane_bcast(tw.s.ay[k], src);
             s.mn_o[k] = lane_bcast(tw.s.mn_o[k], src); s.mx_o[k] = lane_bcast(tw.s.mx_o[k], src);
         }
+        s.separable = lane_bcast((int)tw.s.separable, src) != 0;
         const int sx = lane_bcast(w.sx, src), ex = lane_bcast(w.ex, src), sy = lane_bcast(w.sy, src),
                   ey = lane_bcast(w.ey, src);
         const uint64_t pl = ((uint64_t)(uint32_t)lane_bcast((int)(payload >> 32), src) << 32) |
@@ -209,9 +280,7 @@ __device__ inline void wave_for_each_tile(bool active, const TileWalk& tw, int n
         for (int t = lane; t < n; t += 64) {
             const int cx = t / h;
             const int tx = sx + cx, ty = sy + (t - cx * h);
-            if (want(ty * ntx + tx) &&
-                sat_overlaps(s, (float)tx * 16.0f, (float)(tx + 1) * 16.0f, (float)ty * 16.0f, (float)(ty + 1) * 16.0f))
-                emit(ty * ntx + tx, pl);
+            if (want(ty * ntx + tx) && sat_overlaps_tile(s, tx, ty)) emit(ty * ntx + tx, pl);
         }
     }
 }
@@ -314,31 +383,17 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int* __restrict__ counts, i
 }
 
 // ---- privatized (LDS histogram) count / emit -----------------------------------------------------
-#ifndef GS_PRIV_BLOCK
-#define GS_PRIV_BLOCK 512
-#endif
-#ifndef GS_PRIV_NB
-#define GS_PRIV_NB 1024
-#endif
-#ifndef GS_PRIV_XCD
-#define GS_PRIV_XCD 0
-#endif
-constexpr int PRIV_BLOCK = GS_PRIV_BLOCK;
+constexpr int PRIV_BLOCK = 512;
 constexpr int PRIV_MAX_TILES = 16384;   // 64 KiB of LDS
-constexpr int PRIV_NB = GS_PRIV_NB;     // workgroups = slices of the Gaussian list
+constexpr int PRIV_NB = 1024;           // workgroups = slices of the Gaussian list
 
 // slice of workgroup b.  A tile's segment is filled slice by slice (hist row = slice) and a slice's run in
-// it is a few keys long.  GS_PRIV_XCD gives the workgroups of one XCD (b % 8) consecutive slices so that
-// runs sharing a cache line go through the same L2 -- measured at workload D: emit 0.293 -> 0.287 ms, and
-// fewer, larger slices (512 x 1024 threads, 256 x 1024) are no faster either: the 2.6x write amplification
-// of the scattered 8-byte keys is not what bounds k_bin_emit.  Defaults unchanged.
-__device__ inline int slice_index(int b) {
-#if GS_PRIV_XCD
-    return (b & 7) * (PRIV_NB / 8) + (b >> 3);
-#else
-    return b;
-#endif
-}
+// it is a few keys long.  Giving the workgroups of one XCD (b % 8) consecutive slices, so that runs sharing a cache
+// line go through the same L2, measured 0.293 -> 0.287 ms for the emit at workload D (and runs of 8 depth buckets per
+// XCD in the depth-bucketed emit 87.8 -> 87.2 us, round 6); fewer, larger slices (512 x 1024 threads, 256 x 1024) are
+// no faster either: the 2.6x write amplification of the scattered 8-byte keys is not what bounds the emit.  The A/B
+// branches are kept as scripts/experiments/binning_macro_experiments.patch.
+__device__ inline int slice_index(int b) { return b; }
 __device__ inline void slice_of(int sl, int V, int& g0, int& g1) {
     const int chunk = (V + PRIV_NB - 1) / PRIV_NB;
     g0 = min(V, sl * chunk);
@@ -375,9 +430,7 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_count(const float* __restric
 // 1024-thread workgroup = 64 tiles x 16 row segments of 64 rows: every thread loads and sums its segment
 // (coalesced: a wave reads 64 consecutive tiles of one row), the 16 segment sums of a tile are
 // prefixed through LDS, then the thread writes the exclusive offsets of its segment.
-#ifndef GS_CS_TILES
-#define GS_CS_TILES 64   // 68 workgroups at workload D; 32 or 16 tiles per workgroup (more, narrower ones) are no faster
-#endif
+constexpr int GS_CS_TILES = 64;   // 68 workgroups at workload D; 32 or 16 tiles per workgroup (more, narrower ones) are no faster
 // CS_TILES tiles x (1024 / CS_TILES) row segments per workgroup.  The narrow form (16 tiles) is for a multi-GPU
 // rank's band: ~570 tiles are 9 workgroups of 64 tiles -- 12 us of a 0.5 ms frame -- but 36 of 16
 template <int CS_TILES>
@@ -471,15 +524,7 @@ __global__ __launch_bounds__(PRIV_BLOCK) void k_bin_emit(
         // trip overlaps the following separating-axis test, changes nothing: 0.293 vs 0.291 ms)
         wave_for_each_tile(active, tw, ntx, key, [&](int tile, uint64_t k) {
             const int pos = atomicAdd(&s_cursor[tile - t0], 1);
-#if defined(GS_EMIT_NOSTORE)      // experiment builds (timing only): the walk + LDS cursors without the key stores
-            if (pos < 0) keys[pos] = k;
-#elif defined(GS_EMIT_CELL)       // ... and with the stores going to (4x4-tile cell, workgroup) runs instead of tile segments
-            const int cell = ((tile / ntx) >> 2) * ((ntx + 3) >> 2) + ((tile % ntx) >> 2);
-            const int64_t at = ((int64_t)cell * PRIV_NB + sl) * 40 + (pos % 40);
-            if (at < cap) keys[at] = k;
-#else
             if (pos < cap) keys[pos] = k;
-#endif
         });
     }
 }
@@ -846,11 +891,9 @@ __global__ __launch_bounds__(1024) void k_scan_tiles_cut(const int* __restrict__
 // segment of `keys`; MODE 2 (rest): the COMPLETE lists of the flagged tiles into the overflow buffer at
 // full_ranges -- the repair pass, exits at once while the frame has no flagged tile.  hist holds, after the column
 // scan, the tile's entries in front of bucket b: the offset in either layout.
-#ifndef GS_CUT_EMIT_BLOCK
 // Only the buckets in front of the deepest cut do anything (42 % of them at workload D): with the count pass's 512
 // threads per bucket a CU is left with one or two 8-wave workgroups; 1024 threads per bucket halve the trips.
-#define GS_CUT_EMIT_BLOCK 1024
-#endif
+constexpr int GS_CUT_EMIT_BLOCK = 1024;
 template <int MODE, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_bin_emit_buckets(const float* __restrict__ rec, int ntx, int nty, float mh,
                                                                  int row0, int row1, const int* __restrict__ ranges,
@@ -871,32 +914,12 @@ __global__ __launch_bounds__(BLOCK) void k_bin_emit_buckets(const float* __restr
     }
     const int g0 = cs.boff2[sl], g1 = cs.boff2[sl + 1];
     __syncthreads();
-#ifdef GS_CUT_EMIT_PREFETCH   // (A/B build: the next trip's record in flight during this trip's walk)
-    BinRec nxt;
-    int nxt_g = 0;
-    bool nxt_active = g0 + (int)threadIdx.x < g1;
-    if (nxt_active) {
-        nxt_g = cs.list[g0 + threadIdx.x];
-        nxt = load_bin_record(rec, nxt_g);
-    }
-#endif
+    // (the next trip's record in flight during this trip's walk: no faster, as in the count pass)
     for (int base = g0; base < g1; base += BLOCK) {   // wave-uniform trip count
-#ifdef GS_CUT_EMIT_PREFETCH
-        const BinRec r = nxt;
-        const int g = nxt_g;
-        const bool active = nxt_active;
-        const int i2 = base + BLOCK + threadIdx.x;
-        nxt_active = i2 < g1;
-        if (nxt_active) {
-            nxt_g = cs.list[i2];
-            nxt = load_bin_record(rec, nxt_g);
-        }
-#else
         const bool active = base + (int)threadIdx.x < g1;
         const int g = active ? cs.list[base + threadIdx.x] : 0;
         BinRec r{};
         if (active) r = load_bin_record(rec, g);
-#endif
         TileWalk tw;
         uint64_t key = 0;
         if (active) {
@@ -1218,9 +1241,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort(
 // long: four consecutive keys per thread in registers, the pair across two threads through LDS, until a pass swaps
 // nothing (then every adjacent pair is in order).  Correct for any input (n passes sort anything); a list that has
 // not settled after RUN_PASSES passes goes through the general 1024-key sort instead.
-#ifndef GS_CUT_RUN_PASSES
-#define GS_CUT_RUN_PASSES 24
-#endif
+constexpr int GS_CUT_RUN_PASSES = 24;
 __global__ __launch_bounds__(SORT_BLOCK) void k_tile_sort_runs(const int* __restrict__ ranges,
                                                                const uint64_t* __restrict__ keys,
                                                                int* __restrict__ sorted, int tile0, int64_t cap) {
@@ -1638,11 +1659,7 @@ int gs_tile_emit_sort_cut(const void* bin_records, int N, int n_tiles_x, int n_t
         (const float*)bin_records, n_tiles_x, n_tiles_y, mh_dist, tile_row0, tile_row1, tile_ranges, workspace + T, keys,
         S, nullptr, cs);
     // every kept list has at most GS_SORT_PREFIX entries, laid out as short runs in depth order
-#ifdef GS_CUT_GENERAL_SORT   // (A/B build: the general <= 1024 sorts)
-    k_tile_sort<false><<<Tb, SORT_BLOCK, 0, s>>>(tile_ranges, keys, sorted_gaussians, t0, S, S);
-#else
     k_tile_sort_runs<<<Tb, SORT_BLOCK, 0, s>>>(tile_ranges, keys, sorted_gaussians, t0, S);
-#endif
     return check_launch("tile_emit_sort_cut");
 }
 
