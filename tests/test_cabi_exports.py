@@ -123,7 +123,8 @@ def test_python_call_sites_pass_as_many_arguments_as_the_header_declares():
 def test_product_sources_carry_no_experiment_builds():
     """timing-only emulations and A/B switches live in scripts/experiments/*.patch, not in the shipping translation
     units (round-5 review): no GS_EMU_* token and none of the retired A/B macros in csrc/ or include/"""
-    banned = re.compile(r"GS_EMU_|GS_CK_NOREC|GS_CK_NOEPI|GS_XCD_SEG|GS_ARITH_FAST|GS_BWD_RCP_REFINE")
+    banned = re.compile(r"GS_EMU_|GS_CK_NOREC|GS_CK_NOEPI|GS_XCD_SEG|GS_ARITH_FAST|GS_BWD_RCP_REFINE|"
+                        r"GS_PRIV_XCD|GS_EMIT_NOSTORE|GS_EMIT_CELL|GS_CUT_EMIT_PREFETCH|GS_CUT_GENERAL_SORT")
     hits = []
     for d in (os.path.join(ROOT, "gaussian_splatting_amd", "csrc"), os.path.join(ROOT, "include")):
         for name in sorted(os.listdir(d)):
