@@ -174,6 +174,50 @@ def test_tile_lists_bit_exact(hip_backend, N, W, H, seed):
     assert ref_sorted.numel() > N
 
 
+def extreme_footprints(seed, W, H, n=600):
+    """uv / depth / conic rows around the edges of the tile walk's arithmetic: conics from 1e-38 to 3e38, inf, NaN, zero
+    and negative (axes beyond the range where the separable test applies, binning.hip: sat_separable), centres on tile
+    boundaries, denormal, far outside the image, non-finite"""
+    rng = np.random.default_rng(seed)
+    uv = np.stack([rng.uniform(-40, W + 40, n), rng.uniform(-40, H + 40, n)], 1).astype(np.float32)
+    a, c = 10 ** rng.uniform(-2, 3, n), 10 ** rng.uniform(-2, 3, n)
+    b = rng.uniform(-0.9, 0.9, n) * np.sqrt(a * c)
+    conic = np.stack([a, 2 * b, c], 1).astype(np.float32)
+    z = rng.uniform(0.5, 50, n).astype(np.float32)
+    k = 0
+    with np.errstate(all="ignore"):
+        for v in (1e30, 1e33, 3e38, np.inf, np.nan, 1e-30, 1e-38, 0.0, -1.0):
+            for row in ([v, 0.0, 1.0], [1.0, 0.0, v], [v, 0.0, v], [4.0, v, 4.0], [v, v, v]):
+                conic[k] = row
+                k += 1
+        for u in (0.0, 16.0, 32.0, -16.0, 1e-40, -1e-40, 15.999999, 16.000002, 1e9, -1e9, np.inf, np.nan, float(W),
+                  W - 1e-3):
+            uv[k] = [u, 50.0]
+            uv[k + 1] = [50.0, u]
+            uv[k + 2], conic[k + 2] = [u, u], [0.05, 0.0, 0.05]
+            k += 3
+    xyz_c = np.stack([np.zeros(n), np.zeros(n), z], 1).astype(np.float32)
+    return torch.from_numpy(uv), torch.from_numpy(xyz_c), torch.from_numpy(conic)
+
+
+@pytest.mark.parametrize("seed,W,H,n", [(0, 256, 192, 600), (1, 640, 480, 600), (2, 50, 40, 600), (3, 50, 40, 4000),
+                                         (4, 128, 96, 12000)])
+def test_tile_lists_bit_exact_on_extreme_footprints(hip_backend, seed, W, H, n):
+    """the tile walk's two forms of the separating-axis test (separable for finite, moderate axes; the reference's
+    four-corner form otherwise) and its closed-form window give the oracle's lists on the rows where they could part
+    (600 rows: the atomic-counter kernels with 16 lanes per Gaussian; 4000 and 12000: the LDS-histogram kernels with
+    the column-hoisted walk)"""
+    orc = oracle()
+    uv, xyz_c, conic = extreme_footprints(seed, W, H, n)
+    ntx, nty = (W + 15) // 16, (H + 15) // 16
+    ref_sorted, ref_ranges = orc.get_sorted_gaussian_list(1024, uv, xyz_c, conic, ntx, nty, 3.0)
+    got_sorted, got_ranges = hip_backend.get_sorted_gaussian_list(1024, uv.to(DEV), xyz_c.to(DEV), conic.to(DEV), ntx, nty,
+                                                                  3.0)
+    assert torch.equal(got_ranges.cpu(), ref_ranges)
+    assert torch.equal(got_sorted.cpu(), ref_sorted)
+    assert ref_sorted.numel() > 600
+
+
 def test_tile_lists_with_duplicate_depths(hip_backend):
     """ties in z: broken by ascending Gaussian index == the oracle's stable sort"""
     orc = oracle()
