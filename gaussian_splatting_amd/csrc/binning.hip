@@ -230,14 +230,15 @@ __device__ inline void wave_for_each_tile(bool active, const TileWalk& tw, int n
             if (tw.s.separable) {
                 for (int tx = w.sx; tx < w.ex; tx++) {
                     const SatColumn col = sat_column(tw.s, (float)tx * 16.0f, (float)(tx + 1) * 16.0f);
-                    const float t0 = (float)w.sy * 16.0f;
-                    float yt[2] = {tw.s.ay[0] * t0, tw.s.ay[1] * t0};
+                    // (the top products are formed again rather than carried over from the tile above: min / max of a
+                    // loop-carried value first pay a canonicalising v_max each, twice the cost of the multiplication)
+                    float t = (float)w.sy * 16.0f;
                     for (int ty = w.sy; ty < w.ey; ty++) {
-                        const float b2 = (float)(ty + 1) * 16.0f;
+                        const float b2 = t + 16.0f;   // exact: tile coordinates are integers < 2^24
+                        const float yt[2] = {tw.s.ay[0] * t, tw.s.ay[1] * t};
                         const float yb[2] = {tw.s.ay[0] * b2, tw.s.ay[1] * b2};
                         if (want(ty * ntx + tx) && sat_overlaps_separable(tw.s, col, yt, yb)) emit(ty * ntx + tx, payload);
-                        yt[0] = yb[0];
-                        yt[1] = yb[1];
+                        t = b2;
                     }
                 }
             } else {
