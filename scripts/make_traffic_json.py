@@ -21,7 +21,7 @@ ENTRY_UNCUT = {
     "gs_render_tiles_prefix": ["gs::k_render_fwd<float, 1>", "gs::k_render_fwd_flagged", "gs::k_render_fwd_flagged<false>",
                                "gs::k_tile_sort_flagged<8192>", "gs::k_tile_sort_flagged<4096>"],
     "gs_preprocess_forward": ["gs::k_preprocess<16, false>", "gs::k_cull_count", "gs::k_scan_counts"],
-    "gs_preprocess_backward": ["gs::k_preprocess_bwd<16>"],
+    "gs_preprocess_backward": ["gs::k_preprocess_bwd<16>", "gs::k_preprocess_bwd<16, false>"],
     "gs_tile_count": ["gs::k_bin_count", "gs::k_bin_colscan", "gs::k_bin_colscan<64>", "gs::k_scan_tiles"],
     "gs_tile_emit_sort": ["gs::k_bin_emit", "gs::k_tile_sort<true>", "gs::k_tile_sort_big<true>"],
 }
@@ -31,7 +31,7 @@ ENTRY_CUT = {
     "gs_render_tiles_prefix": ["gs::k_render_fwd<float, 1>", "gs::k_bin_emit_buckets<2, 512>", "gs::k_tile_sort_overflow",
                                "gs::k_render_fwd_flagged<false>"],
     "gs_preprocess_forward": ["gs::k_preprocess<16, false>", "gs::k_cull_count", "gs::k_scan_counts<true>"],
-    "gs_preprocess_backward": ["gs::k_preprocess_bwd<16>"],
+    "gs_preprocess_backward": ["gs::k_preprocess_bwd<16>", "gs::k_preprocess_bwd<16, false>"],
     "gs_tile_count": ["gs::k_depth_hist", "gs::k_depth_colscan", "gs::k_depth_scatter", "gs::k_bin_count_buckets",
                       "gs::k_bin_colscan_cut<64>", "gs::k_scan_tiles_cut"],
     "gs_tile_emit_sort": ["gs::k_bin_emit_buckets<1, 1024>", "gs::k_tile_sort_runs"],
