@@ -97,10 +97,12 @@ def test_fused_forward_stages_bit_exact(N, W, H, deg, seed):
     assert torch.equal(image.cpu(), img)
 
 
-@pytest.mark.parametrize("N,W,H,deg,seed,bgval", [(1000, 256, 256, 0, 0, 0.0), (20000, 640, 472, 3, 1, 0.5)])
+@pytest.mark.parametrize("N,W,H,deg,seed,bgval", [(1000, 256, 256, 0, 0, 0.0), (20000, 640, 472, 3, 1, 0.5),
+                                                   (150000, 3840, 2160, 1, 7, 0.0)])
 def test_fused_matches_reference_shaped_path(hip_backend, N, W, H, deg, seed, bgval):
     """same frame through the six-node path and through the fused path: forward within the
-    tolerance of an ulp-level difference in the world->camera transform, gradients 1e-4"""
+    tolerance of an ulp-level difference in the world->camera transform, gradients 1e-4.  The third case is a 4K
+    frame: 32 400 tiles, more than an LDS histogram holds -- the fused frame bins with the global-counter kernels"""
     bg = torch.full((3,), bgval, device=DEV)
     gi = make_grad_image(W, H, seed=seed + 9, device=DEV)
     outs = []
