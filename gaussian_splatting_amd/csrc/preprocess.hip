@@ -264,8 +264,37 @@ __global__ __launch_bounds__(PP_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))
     }
     bool vis = false;
     float c[3] = {0, 0, 1}, uv[2] = {0, 0}, p[3] = {0, 0, 0};
+    // Every load of the Gaussian's own parameters and the workgroup's whole SH block are requested before
+    // anything is computed (loads return in order: what is asked for first can be used first, the SH block lands while
+    // the covariance is projected).  A workgroup that asks for its 23 KiB of SH only after its geometry is done has
+    // 3-8 KiB in flight for half of its life: the kernel ran at 4.8 TB/s where its backward twin, whose traffic is
+    // stores, reaches 5.9 (round 6).
+    typedef float vfloat4 __attribute__((ext_vector_type(4)));
+    constexpr int SH_PRE = (N_SH > 1 && !BAND) ? (HALF * SHW / 4 + PP_BLOCK - 1) / PP_BLOCK : 1;
+    vfloat4 pre[2][SH_PRE];   // both halves: 48 registers at degree 3 -- the LDS staging, not the registers, sets the occupancy
+    float q4[4] = {0, 0, 0, 1}, s3[3] = {0, 0, 0}, opa_raw = 0;
     if (g < N) {
         p[0] = xyz[g * 3 + 0]; p[1] = xyz[g * 3 + 1]; p[2] = xyz[g * 3 + 2];
+        if constexpr (!BAND) {
+            q4[0] = quat[g * 4 + 0]; q4[1] = quat[g * 4 + 1]; q4[2] = quat[g * 4 + 2]; q4[3] = quat[g * 4 + 3];
+            s3[0] = scale[g * 3 + 0]; s3[1] = scale[g * 3 + 1]; s3[2] = scale[g * 3 + 2];
+            opa_raw = opacity[g];
+        }
+    }
+    if constexpr (N_SH > 1 && !BAND) {   // the SH block -> pre[][] (coalesced 16-byte non-temporal loads)
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int g0 = blockIdx.x * PP_BLOCK + half * HALF;
+            const int count = max(0, min(HALF, N - g0)) * SHW;
+            const vfloat4* src4 = reinterpret_cast<const vfloat4*>(sh + (size_t)g0 * SHW);   // 16-byte aligned: g0 % 128 == 0
+#pragma unroll
+            for (int k = 0; k < SH_PRE; k++) {
+                const int i = k * PP_BLOCK + (int)threadIdx.x;
+                if (i < (count >> 2)) pre[half][k] = __builtin_nontemporal_load(src4 + i);
+            }
+        }
+    }
+    if (g < N) {
         to_camera(M, p[0], p[1], p[2], c);
         vis = !is_culled(c, K, fr, uv);
     }
@@ -294,8 +323,11 @@ __global__ __launch_bounds__(PP_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))
             o.xyz_cam[v * 3 + 2] = c[2];
         }
 
-        const float q4[4] = {quat[g * 4 + 0], quat[g * 4 + 1], quat[g * 4 + 2], quat[g * 4 + 3]};
-        const float s3[3] = {scale[g * 3 + 0], scale[g * 3 + 1], scale[g * 3 + 2]};
+        if constexpr (BAND) {
+            q4[0] = quat[g * 4 + 0]; q4[1] = quat[g * 4 + 1]; q4[2] = quat[g * 4 + 2]; q4[3] = quat[g * 4 + 3];
+            s3[0] = scale[g * 3 + 0]; s3[1] = scale[g * 3 + 1]; s3[2] = scale[g * 3 + 2];
+            opa_raw = opacity[g];
+        }
         float S9[9], W[9], J6[6];
         sigma_world_of(q4, s3, S9);
         load_rotation(M, W);
@@ -312,7 +344,7 @@ __global__ __launch_bounds__(PP_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))
             o.conic[v * 3 + 2] = c3[2];
         }
 
-        opa = sigmoid_det(opacity[g]);
+        opa = sigmoid_det(opa_raw);
         o.opacity[v] = opa;
         if constexpr (!BAND) {
             if (o.bin_rec != nullptr) {
@@ -370,19 +402,21 @@ __global__ __launch_bounds__(PP_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))
         if constexpr (BAND) {
             if (act && in_band) colour_from(sh + (size_t)g * SHW);
         } else {
-#pragma unroll 1
+#pragma unroll
             for (int half = 0; half < 2; half++) {
                 const int g0 = blockIdx.x * PP_BLOCK + half * HALF;
                 const int rows = max(0, min(HALF, N - g0));
                 const int count = rows * SHW;
                 const float* src = sh + (size_t)g0 * SHW;   // 16-byte aligned: g0 is a multiple of 128
-                // read once per frame: non-temporal, so that the 0.5 GB stream does not push the
-                // records this kernel writes (and the render gathers) out of the caches
-                typedef float vfloat4 __attribute__((ext_vector_type(4)));
-                const vfloat4* src4 = reinterpret_cast<const vfloat4*>(src);
+                // (read once per frame: non-temporal, so that the 0.5 GB stream does not push the records this kernel
+                // writes -- and the render gathers -- out of the caches).  pre[half][] holds it, requested at the kernel's top
                 vfloat4* dst4 = reinterpret_cast<vfloat4*>(s_sh);
                 if (half) __syncthreads();   // the first half has been consumed
-                for (int i = threadIdx.x; i < (count >> 2); i += PP_BLOCK) dst4[i] = __builtin_nontemporal_load(src4 + i);
+#pragma unroll
+                for (int k = 0; k < SH_PRE; k++) {
+                    const int i = k * PP_BLOCK + (int)threadIdx.x;
+                    if (i < (count >> 2)) dst4[i] = pre[half][k];
+                }
                 for (int i = (count & ~3) + threadIdx.x; i < count; i += PP_BLOCK) s_sh[i] = src[i];
                 __syncthreads();
                 if (act && (threadIdx.x / HALF) == half) colour_from(s_sh + (threadIdx.x % HALF) * SHW);
