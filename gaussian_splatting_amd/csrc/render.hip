@@ -278,6 +278,24 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
+// background weight of the backward's first contributor, render_backward.cu:175:
+//     const T background_weight = 1.0 - (alpha * weight + 1.0 - weight);
+// fp32: x = alpha * weight is a float product; the double literals promote the rest -- (x + 1.0) - weight, then 1.0 - that
+// -- and the result is narrowed to float.  With alpha in [1/255, 0.9999] (the branch it sits in) and weight = the
+// forward's final weight 1 - acc in [1e-4, 1], x and weight are multiples of 2^-45 below 2, so every one of the three
+// double operations is EXACT (46 bits of 53) and the value narrowed is weight - x itself: RN_float(weight - x), which is
+// what one IEEE float subtraction returns.  One v_sub_f32 for 2 conversions + 3 fp64 adds + the conversion back (fp64-rate
+// instructions, ~4 cycles each, executed in every visit in which some pixel of the wave meets its first contributor);
+// bit-identical (4e8 random and edge-mantissa pairs on the host: tests/test_host_logic.py holds a sample).
+template <typename T> __device__ __forceinline__ T background_weight(T alpha, T weight);
+template <> __device__ __forceinline__ float background_weight<float>(float alpha, float weight) {
+    const float x = alpha * weight;
+    return weight - x;
+}
+template <> __device__ __forceinline__ double background_weight<double>(double alpha, double weight) {
+    return 1.0 - (alpha * weight + 1.0 - weight);
+}
+
 template <typename T> __device__ inline T tmin(T a, T b) { return b < a ? b : a; }
 template <typename T> __device__ inline T tmax(T a, T b) { return b > a ? b : a; }
 
@@ -919,7 +937,7 @@ __device__ __forceinline__ void render_tile_fwd(
                 const T e = exp_neg_half(mh);
                 T alpha = g0.w * ((mh > T(0)) ? e : T(0));
                 if (alpha > Thr<T>::sat_gt()) alpha = Thr<T>::alpha_cap();
-                const T bw = 1.0 - (alpha * fw + 1.0 - fw);   // render_backward.cu:172-181
+                const T bw = background_weight<T>(alpha, fw);   // render_backward.cu:172-181
                 if (bw > Thr<T>::bgw_gt()) bgw = bw;
                 oma_last = T(1) - alpha;
             }
@@ -1494,7 +1512,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                     if (alpha > Thr<T>::sat_gt()) alpha = Thr<T>::alpha_cap();   // min(0.9999, .)
                     if (alpha >= Thr<T>::alpha_min()) {
                         if (!bg_init) {   // render_backward.cu:172-181
-                            const T bw = 1.0 - (alpha * weight + 1.0 - weight);
+                            const T bw = background_weight<T>(alpha, weight);
                             if (bw > Thr<T>::bgw_gt()) {
                                 color_accum[0] += bg0 * bw;
                                 color_accum[1] += bg1 * bw;
@@ -1575,7 +1593,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                 if (!fast || alpha >= Thr<T>::alpha_min()) {
                     contrib = true;
                     if (!bg_init) {   // render_backward.cu:172-181
-                        const T bw = 1.0 - (alpha * weight + 1.0 - weight);
+                        const T bw = background_weight<T>(alpha, weight);
                         if (bw > Thr<T>::bgw_gt()) {
                             color_accum[0] += bg0 * bw;
                             color_accum[1] += bg1 * bw;

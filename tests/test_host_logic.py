@@ -358,3 +358,33 @@ def test_every_python_file_of_the_repo_compiles(tmp_path):
     assert len(files) > 40
     for f in files:
         py_compile.compile(f, doraise=True, cfile=str(tmp_path / "out.pyc"))
+
+
+def test_background_weight_in_float_equals_the_reference_double_chain():
+    """csrc/render.hip background_weight<float>: `1.0 - (alpha * weight + 1.0 - weight)` narrowed to float
+    (render_backward.cu:175, the double literals promote everything behind the float product) equals the float
+    subtraction `weight - alpha * weight` bit for bit wherever the kernel evaluates it: alpha in [1/255, 0.9999],
+    weight = 1 - acc in [1e-4, 1] -- the three double operations are exact there."""
+    import numpy as np
+    rng = np.random.default_rng(7)
+
+    def mismatches(a, w):
+        a, w = a.astype(np.float32), w.astype(np.float32)
+        x = (a * w).astype(np.float32)
+        ref = (1.0 - ((x.astype(np.float64) + 1.0) - w.astype(np.float64))).astype(np.float32)
+        new = (w - x).astype(np.float32)
+        return int((ref.view(np.uint32) != new.view(np.uint32)).sum())
+
+    n = 2_000_000
+    assert mismatches(rng.uniform(1 / 255, 0.9999, n), rng.uniform(1e-4, 1, n)) == 0
+    assert mismatches(np.exp(rng.uniform(np.log(1 / 255), np.log(0.9999), n)), np.exp(rng.uniform(np.log(1e-4), 0, n))) == 0
+    # weight as the forward forms it (1 - acc, acc up to 0.9999) and mantissas at the ends of their range
+    assert mismatches(rng.uniform(1 / 255, 0.9999, n), 1 - rng.uniform(0, 0.9999, n).astype(np.float32)) == 0
+    m = np.concatenate([np.arange(0, 512), np.arange(2 ** 23 - 512, 2 ** 23)]).astype(np.uint32)
+    for ea in range(119, 127):
+        for ew in range(113, 128):
+            A = ((np.uint32(ea) << 23) | m).view(np.float32)
+            Wt = ((np.uint32(ew) << 23) | m).view(np.float32)
+            AA, WW = [t.ravel() for t in np.meshgrid(A, Wt)]
+            ok = (AA >= np.float32(1 / 255)) & (AA <= np.float32(0.9999)) & (WW <= 1) & (WW >= np.float32(1e-4))
+            assert mismatches(AA[ok], WW[ok]) == 0, (ea, ew)
