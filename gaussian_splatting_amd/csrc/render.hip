@@ -296,6 +296,22 @@ template <> __device__ __forceinline__ double background_weight<double>(double a
     return 1.0 - (alpha * weight + 1.0 - weight);
 }
 
+// a register the compiler must treat as defined without an instruction that defines it (its content is whatever the
+// lane held): for values only SOME lanes compute and the others are masked out of afterwards
+template <typename T> __device__ __forceinline__ T unset() {
+    T x;
+    asm volatile("" : "=v"(x));
+    return x;
+}
+// a * b with 0 * x = 0 for EVERY x (v_mul_legacy_f32: NaN and infinity included): the masked-out factor of a lane may be
+// anything.  Equal to a * b whenever both are finite
+__device__ __forceinline__ float mul_zero_wins(float a, float b) {
+    float r;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double mul_zero_wins(double a, double b) { return b == 0.0 ? 0.0 : a * b; }
+
 template <typename T> __device__ inline T tmin(T a, T b) { return b < a ? b : a; }
 template <typename T> __device__ inline T tmax(T a, T b) { return b > a ? b : a; }
 
@@ -1498,12 +1514,16 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                 asm volatile("" ::"v"(g1.x), "v"(g1.y), "v"(g1.z), "v"(g2.x), "v"(g2.y), "v"(g2.z), "v"(g2.w));
                 const T du = pu - g0.x, dv = pv - g0.y;
                 const T du2 = du * du, dv2 = dv * dv;
-                T aw = 0, w = 0, q0 = 0, q1 = 0, q2 = 0;
+                // aw, w and mh are formed by the lanes that pass the alpha test only; the others are cut out of the
+                // nine sums by `contrib` below -- no zero-filled registers in front of (and, for the ones the
+                // exponential reuses, again inside) the branches: they were 11 of the visit's ~120 vector instructions
+                T aw = unset<T>(), w = unset<T>(), mh = unset<T>(), duv = unset<T>();
+                bool contrib = false;
                 if (reach && !(du2 + dv2 > g0.z)) {   // inside the cutoff radius
                     GS_STAT_SET(st_in);
                     // render_backward.cu:153-165 (multiplies by 1/det; the forward divides)
-                    const T duv = du * dv;
-                    const T mh = (g1.z * du * du - (g1.y + g1.y) * du * dv + g1.x * dv * dv) * g2.x;
+                    duv = du * dv;
+                    mh = (g1.z * du * du - (g1.y + g1.y) * du * dv + g1.x * dv * dv) * g2.x;
                     // (a select, not a branch around the exponential: mh <= 0 does not occur for a positive
                     // definite conic, and the branch costs every visit its exec-mask round trip)
                     const T e = exp_neg_half(mh);
@@ -1511,6 +1531,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                     T alpha = g0.w * norm_prob;
                     if (alpha > Thr<T>::sat_gt()) alpha = Thr<T>::alpha_cap();   // min(0.9999, .)
                     if (alpha >= Thr<T>::alpha_min()) {
+                        contrib = true;
                         if (!bg_init) {   // render_backward.cu:172-181
                             const T bw = background_weight<T>(alpha, weight);
                             if (bw > Thr<T>::bgw_gt()) {
@@ -1540,29 +1561,34 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                             color_accum[1] += c1 * aw;
                             color_accum[2] += c2 * aw;
                             w = norm_prob * ga;
-                            q0 = (dv2 - g1.z * mh) * w;
-                            q1 = (g1.y * mh - duv) * w;
-                            q2 = (du2 - g1.x * mh) * w;
                         }
                     }
                 }
                 // a lane contributes iff it passed the alpha test; aw > 0 there (alpha >= 1/255, weight > 0)
-                const unsigned long long cmask = ballot(aw != T(0));
+                const T awz = contrib ? aw : T(0);
+                const unsigned long long cmask = ballot(awz != T(0));
                 GS_STAT(3, ballot(st_in) != 0);
                 GS_STAT(4, cmask != 0);
                 GS_STAT(5, __popcll(cmask));
                 GS_HALF_VISIT(ballot(st_in));
                 if (cmask == 0) continue;   // every reaching lane skipped the splat
                 T val[9];
-                const T awy = aw * Y[0];   // (the compiler re-formed Y0 * gi[ch] at every visit to save registers)
+                const T wz = contrib ? w : T(0);
+                const T awy = awz * Y[0];   // (the compiler re-formed Y0 * gi[ch] at every visit to save registers)
                 val[0] = awy * gi[0]; val[1] = awy * gi[1]; val[2] = awy * gi[2];
-                val[3] = w; val[4] = w * du; val[5] = w * dv;
-                val[6] = q0; val[7] = q1; val[8] = q2;
+                val[3] = wz; val[4] = wz * du; val[5] = wz * dv;
+                // (mh and duv of a lane that stayed outside are whatever an earlier visit left: 0 * x = 0 for every x)
+                {
+#pragma clang fp contract(fast)
+                    val[6] = mul_zero_wins((dv2 - g1.z * mh), wz);
+                    val[7] = mul_zero_wins((g1.y * mh - duv), wz);
+                    val[8] = mul_zero_wins((du2 - g1.x * mh), wz);
+                }
                 reduce9_to_slot(val, lane, slot_off, &s_acc[(wave * RCHUNK + i) * SV]);
                 hit |= 1ull << bit;
                 if constexpr (SHMM) {
                     // column nb of the batch's B: this splat's aw at the wave's 64 pixels (0 where it does not contribute)
-                    s_B[(wave * MB + nb) * BROW + lane] = aw;
+                    s_B[(wave * MB + nb) * BROW + lane] = awz;
                     if (lane == 0) s_bidx[wave * MB + nb] = s_idx[i];
                     if (++nb == MB) {
                         mma_flush(MB);
