@@ -712,12 +712,16 @@ __device__ __forceinline__ void render_tile_fwd(
         Y[0] = T(GS_SH_0);
     }
 
-    T acc = 0, fw = 0;
+    // A pixel is done when its accumulated alpha exceeds 0.9999 (render.cu:146,162) -- or when it lies outside the
+    // image: those lanes start saturated.  "done" is READ OFF acc (one compare per visit) instead of being carried as a
+    // flag: the compiler kept the flag as a 0/1 VGPR across the pipelined visits and spent an and, a compare and five
+    // moves of every visit's ~52 vector instructions on it.  acc of an outside lane is never used (nothing is stored).
+    T acc = valid ? T(0) : T(2), fw = 0;
+    auto is_done = [&]() { return acc > Thr<T>::sat_gt(); };
     T img[3] = {0, 0, 0};
     // num_splats_per_pixel == index of the first splat at whose turn the pixel is saturated
     // (render.cu:106,146,162), or the list length: set when the pixel saturates
     int nsp = n_tile;
-    bool done = !valid;
     const T pu = T(px.u), pv = T(px.v);
     const int wave = tid >> 6;
     constexpr int NW = RCHUNK / 64 > 0 ? RCHUNK / 64 : 1;
@@ -764,10 +768,10 @@ __device__ __forceinline__ void render_tile_fwd(
             // pipelined walk: the record of the next visit is in flight while this one is composited
             auto visit = [&](const LdsRecord& r, int i) {
                 GS_STAT(2, 1);
-                GS_STAT(6, __popcll(ballot(!done)));
+                GS_STAT(6, __popcll(ballot(!is_done())));
                 GS_STAT_FLAG(st_in);
                 GS_STAT_FLAG(st_hit);
-                if (!done) {
+                if (!is_done()) {
                     const T du = pu - r.g0.x, dv = pv - r.g0.y;
                     if (!(du * du + dv * dv > r.g0.z)) {
                         GS_STAT_SET(st_in);
@@ -822,7 +826,6 @@ __device__ __forceinline__ void render_tile_fwd(
                             img[2] += r.g2.w * weight;
                             acc += weight;
                             if (acc > Thr<T>::sat_gt()) {   // saturated: the next splat's check fails
-                                done = true;
                                 nsp = base + i + 1;
                             }
                         }
@@ -842,7 +845,7 @@ __device__ __forceinline__ void render_tile_fwd(
                         b_cur = sidx;
                     }
                 }
-                if (ballot(!done) == 0) {   // wave-uniform: every pixel of the patch saturated
+                if (ballot(!is_done()) == 0) {   // wave-uniform: every pixel of the patch saturated
                     if constexpr (CK) {
                         if (!wave_fin) write_record();
                         wave_fin = true;
@@ -878,16 +881,16 @@ __device__ __forceinline__ void render_tile_fwd(
             }
         } else {
             for (int word = 0; word < NW && word * 64 < cnt; word++) {
-                if (ballot(!done) == 0) break;   // wave-uniform: every pixel of the patch saturated
+                if (ballot(!is_done()) == 0) break;   // wave-uniform: every pixel of the patch saturated
                 unsigned long long m = wave_uniform(s_mask[wave][word]);
                 while (m) {
                     const int i = word * 64 + __builtin_ctzll(m);
                     m &= m - 1;
                     GS_STAT(2, 1);                        // visits (touch-mask bits walked)
-                    GS_STAT(6, __popcll(ballot(!done)));   // live lanes at the visit
+                    GS_STAT(6, __popcll(ballot(!is_done())));   // live lanes at the visit
                     GS_STAT_FLAG(st_in);
                     GS_STAT_FLAG(st_hit);
-                    if (!done) {
+                    if (!is_done()) {
                         const T* rec = s_geom + i * GS_PACKED_WIDTH;
                         const Vec4<T> g0 = *reinterpret_cast<const Vec4<T>*>(rec);   // u v r2 opacity
                         const T du = pu - g0.x, dv = pv - g0.y;
@@ -910,7 +913,6 @@ __device__ __forceinline__ void render_tile_fwd(
                                 for (int ch = 0; ch < 3; ch++) img[ch] += col[ch] * weight;
                                 acc += weight;
                                 if (acc > Thr<T>::sat_gt()) {   // saturated: the next splat's check fails
-                                    done = true;
                                     nsp = base + i + 1;
                                 }
                             }
@@ -924,7 +926,7 @@ __device__ __forceinline__ void render_tile_fwd(
         }
         GS_PHASE(2);
         GS_HALF_CHUNK(9);
-        all_done = __syncthreads_and(done);
+        all_done = __syncthreads_and(is_done());
         GS_PHASE(3);
         if (all_done) break;
     }
