@@ -779,7 +779,11 @@ __device__ __forceinline__ void render_tile_fwd(
                         const T mh_num = c * du * du - (b + b) * du * dv + a * dv * dv;
                         const T mh = div_by_reciprocal(mh_num, det, r.g2.x);
                         T alpha = r.g0.w * exp_neg_half(mh);
-                        alpha = (mh > T(0)) ? alpha : T(0);                 // render.cu:133
+                        // render.cu:133: alpha = 0 unless mh > 0 -- and a zero alpha fails the 1/255 test below.  Without
+                        // the segment state only that test reads alpha before it is known to pass: `mh > 0` joins the
+                        // test's lane mask (one scalar and) instead of a select in front of it
+                        const bool mh_pos = mh > T(0);
+                        if constexpr (CK) alpha = mh_pos ? alpha : T(0);
                         if constexpr (CK) {
                             // What the BACKWARD's walk will see at this entry.  It forms alpha from mh * (1 / det)
                             // (render_backward.cu:153-157; the forward divides), a last-ulp difference that matters
@@ -809,7 +813,7 @@ __device__ __forceinline__ void render_tile_fwd(
                             }
                             kend = cb ? base + i + 1 : kend;
                         }
-                        if (!(alpha < Thr<T>::alpha_min())) {               // render.cu:145
+                        if (mh_pos & !(alpha < Thr<T>::alpha_min())) {      // render.cu:145
                             GS_STAT_SET(st_hit);
                             // render.cu:149-150: final_weight = 1.0 - acc and weight = alpha * (1.0 - acc), the literal
                             // making both double expressions that are narrowed to float -- six fp64-rate instructions
@@ -1526,13 +1530,12 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                     // render_backward.cu:153-165 (multiplies by 1/det; the forward divides)
                     duv = du * dv;
                     mh = (g1.z * du * du - (g1.y + g1.y) * du * dv + g1.x * dv * dv) * g2.x;
-                    // (a select, not a branch around the exponential: mh <= 0 does not occur for a positive
-                    // definite conic, and the branch costs every visit its exec-mask round trip)
-                    const T e = exp_neg_half(mh);
-                    const T norm_prob = (mh > T(0)) ? e : T(0);
+                    // norm_prob = 0 unless mh > 0 (render_backward.cu:158-165) -- and then alpha = 0 fails the 1/255 test:
+                    // `mh > 0` joins the test's lane mask (a scalar and), behind it norm_prob IS the exponential
+                    const T norm_prob = exp_neg_half(mh);
                     T alpha = g0.w * norm_prob;
                     if (alpha > Thr<T>::sat_gt()) alpha = Thr<T>::alpha_cap();   // min(0.9999, .)
-                    if (alpha >= Thr<T>::alpha_min()) {
+                    if ((mh > T(0)) & (alpha >= Thr<T>::alpha_min())) {
                         contrib = true;
                         if (!bg_init) {   // render_backward.cu:172-181
                             const T bw = background_weight<T>(alpha, weight);
