@@ -196,7 +196,9 @@ __device__ inline PixelMap pixel_of_thread(int tile_x, int tile_y, int tid) {
 // src_opacity != nullptr: the splats come as the reference's separate arrays (render_tiles_cuda's
 // uvs / opacity / conic / rgb: `packed` is then uvs[V,2]) and the record is formed here, with the
 // function gs_pack_splats uses -- the same values, no packing pass and no [V,12] buffer for the caller.
-template <typename T, int N_SH>
+// TWO_B (the backward, which never reads det): word 7 of the staged record holds b + b instead -- the cross term's
+// factor of render_backward.cu:155, the same for every pixel: one add per staged record where it was one per visit.
+template <typename T, int N_SH, bool TWO_B = false>
 __device__ inline void stage_chunk(const T* __restrict__ packed, const T* __restrict__ rgb,
                                    const int* __restrict__ sorted, int first, int count, int tid,
                                    T* s_geom, T* s_col, int* s_idx, const T* __restrict__ src_opacity = nullptr,
@@ -220,6 +222,10 @@ __device__ inline void stage_chunk(const T* __restrict__ packed, const T* __rest
             dst[0] = src[0];
             dst[1] = src[1];
             dst[2] = src[2];
+        }
+        if constexpr (TWO_B) {
+            const T b = s_geom[tid * GS_PACKED_WIDTH + 5];
+            s_geom[tid * GS_PACKED_WIDTH + 7] = b + b;
         }
         if (s_idx) s_idx[tid] = g;
     }
@@ -1154,7 +1160,7 @@ __device__ __forceinline__ int slot_lane_offset(int lane) {
     const int e = ((bank & 1) ? 4 : 0) + ((bank & 2) ? 2 : 0);
     return lane < 16 ? e : e + 1;
 }
-__device__ __forceinline__ void reduce9_to_slot(const float* val, int lane, int lane_offset, float* slot) {
+__device__ __forceinline__ void reduce9_to_slot(const float* val, bool stores, float* slots, int lane_slot) {
     // Rows first (16 lanes), hand-scheduled.  A DPP add with a BANK mask writes only the enabled quads
     // (bank = the four lanes i/4 of a row), so the trade "keep one half of the values, send the other"
     // needs no select when it is done ACROSS quads:
@@ -1193,7 +1199,6 @@ __device__ __forceinline__ void reduce9_to_slot(const float* val, int lane, int 
         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(s2[0]), "=&v"(s2[1]), "=&v"(s8)
         : "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5]), "v"(val[6]), "v"(val[7]),
           "v"(val[8]));
-    (void)lane;
     // rows -> wave
     float x = s2[0], y = s2[1];
     permlane16_swap(x, y);           // x: rows (x0, y0, x2, y2); y: rows (x1, y1, x3, y3)
@@ -1203,7 +1208,9 @@ __device__ __forceinline__ void reduce9_to_slot(const float* val, int lane, int 
     float e = t + u;                 // ninth value: rows 0, 1 hold rows 0+1, rows 2, 3 hold rows 2+3
     permlane32_swap(z, e);           // z: (z.lo, e.lo); e: (z.hi, e.hi)
     const float total = z + e;       // lanes 0..31: even / odd values' totals; lanes 32..63: the ninth
-    if (lane_offset >= 0) slot[lane_offset] = total;
+    // (lane_slot: the wave's slot of this splat + slot_lane_offset(lane), formed by the caller from a per-lane base that
+    // holds everything but the splat -- one vector add per visit where (wave, splat, lane) -> address took three)
+    if (stores) slots[lane_slot] = total;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1320,6 +1327,8 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
 
     const T pu = T(px.u), pv = T(px.v);
     const int slot_off = slot_lane_offset(lane);
+    const bool slot_stores = slot_off >= 0;
+    const int slot_lane_base = wave * RCHUNK * SV + (slot_stores ? slot_off : 0);
     T color_accum[3] = {0, 0, 0};
     bool bg_init = false;
     const T bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
@@ -1460,7 +1469,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
         const int cnt = min(RCHUNK, seg_hi - base);
         GS_STAT(1, 1);
         __syncthreads();   // previous chunk fully flushed
-        stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, s_idx, src_opacity, src_conic);
+        stage_chunk<T, N_SH, SLOTS>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, s_idx, src_opacity, src_conic);
         if constexpr (!SLOTS)
             for (int k = tid; k < cnt * NV; k += RB) s_acc[k] = 0;
         GS_PHASE(0);
@@ -1517,7 +1526,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                 // ones; LDS bandwidth is no longer what bounds this kernel): 0.70 -> 0.69 ms
                 const Vec4<T> g1 = *reinterpret_cast<const Vec4<T>*>(rec + 4);   // a b c det
                 const Vec4<T> g2 = *reinterpret_cast<const Vec4<T>*>(rec + 8);   // 1/det, colour
-                asm volatile("" ::"v"(g1.x), "v"(g1.y), "v"(g1.z), "v"(g2.x), "v"(g2.y), "v"(g2.z), "v"(g2.w));
+                asm volatile("" ::"v"(g1.x), "v"(g1.y), "v"(g1.z), "v"(g1.w), "v"(g2.x), "v"(g2.y), "v"(g2.z), "v"(g2.w));
                 const T du = pu - g0.x, dv = pv - g0.y;
                 const T du2 = du * du, dv2 = dv * dv;
                 // aw, w and mh are formed by the lanes that pass the alpha test only; the others are cut out of the
@@ -1529,7 +1538,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                     GS_STAT_SET(st_in);
                     // render_backward.cu:153-165 (multiplies by 1/det; the forward divides)
                     duv = du * dv;
-                    mh = (g1.z * du * du - (g1.y + g1.y) * du * dv + g1.x * dv * dv) * g2.x;
+                    mh = (g1.z * du * du - g1.w * du * dv + g1.x * dv * dv) * g2.x;   // g1.w = b + b (stage_chunk)
                     // norm_prob = 0 unless mh > 0 (render_backward.cu:158-165) -- and then alpha = 0 fails the 1/255 test:
                     // `mh > 0` joins the test's lane mask (a scalar and), behind it norm_prob IS the exponential
                     const T norm_prob = exp_neg_half(mh);
@@ -1589,7 +1598,9 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
                     val[7] = mul_zero_wins((g1.y * mh - duv), wz);
                     val[8] = mul_zero_wins((du2 - g1.x * mh), wz);
                 }
-                reduce9_to_slot(val, lane, slot_off, &s_acc[(wave * RCHUNK + i) * SV]);
+                int slot_i = i * SV;   // (kept scalar: the compiler otherwise folds it into a 64-bit vector multiply-add)
+                asm volatile("" : "+s"(slot_i));
+                reduce9_to_slot(val, slot_stores, reinterpret_cast<float*>(s_acc), slot_lane_base + slot_i);
                 hit |= 1ull << bit;
                 if constexpr (SHMM) {
                     // column nb of the batch's B: this splat's aw at the wave's 64 pixels (0 where it does not contribute)
