@@ -196,9 +196,11 @@ __device__ inline PixelMap pixel_of_thread(int tile_x, int tile_y, int tid) {
 // src_opacity != nullptr: the splats come as the reference's separate arrays (render_tiles_cuda's
 // uvs / opacity / conic / rgb: `packed` is then uvs[V,2]) and the record is formed here, with the
 // function gs_pack_splats uses -- the same values, no packing pass and no [V,12] buffer for the caller.
-// TWO_B (the backward, which never reads det): word 7 of the staged record holds b + b instead -- the cross term's
-// factor of render_backward.cu:155, the same for every pixel: one add per staged record where it was one per visit.
-template <typename T, int N_SH, bool TWO_B = false>
+// TWO_B: the cross term's factor b + b (render.cu:129, render_backward.cu:155) is the same for every pixel -- one add per
+// staged record where it was one per visit.  1 (the backward, which never reads det): in word 7 of the staged record;
+// 2 (the pipelined forward, which needs det): in word 5, INSTEAD of b -- its only other reader, the touch-mask test of
+// the same thread, halves it again (exact).
+template <typename T, int N_SH, int TWO_B = 0>
 __device__ inline void stage_chunk(const T* __restrict__ packed, const T* __restrict__ rgb,
                                    const int* __restrict__ sorted, int first, int count, int tid,
                                    T* s_geom, T* s_col, int* s_idx, const T* __restrict__ src_opacity = nullptr,
@@ -223,9 +225,9 @@ __device__ inline void stage_chunk(const T* __restrict__ packed, const T* __rest
             dst[1] = src[1];
             dst[2] = src[2];
         }
-        if constexpr (TWO_B) {
+        if constexpr (TWO_B != 0) {
             const T b = s_geom[tid * GS_PACKED_WIDTH + 5];
-            s_geom[tid * GS_PACKED_WIDTH + 7] = b + b;
+            s_geom[tid * GS_PACKED_WIDTH + (TWO_B == 1 ? 7 : 5)] = b + b;
         }
         if (s_idx) s_idx[tid] = g;
     }
@@ -335,7 +337,7 @@ __device__ inline unsigned long long wave_uniform(unsigned long long m) {
 // 0, float multiply/add are monotone, so dx*dx + dy*dy > r2 implies du*du + dv*dv > r2 for every
 // pixel of the patch, i.e. every lane would have taken the "alpha < 1/255" path.  NaNs compare
 // false and keep the splat.
-template <typename T, int CHUNK>
+template <typename T, int CHUNK, bool B_DOUBLED = false>
 __device__ inline void build_touch_masks(const T* s_geom, int cnt, int tid, int tile_x, int tile_y,
                                          unsigned long long (*s_mask)[CHUNK / 64 > 0 ? CHUNK / 64 : 1]) {
     if (tid < CHUNK) {   // CHUNK <= 256 == workgroup size
@@ -356,7 +358,7 @@ __device__ inline void build_touch_masks(const T* s_geom, int cnt, int tid, int 
             bool use_q = false;
             T a = 0, b = 0, c = 0, rdet = 0, tau_m = 0, b_over_a = 0, b_over_c = 0;
             if (fast_mode<T>() && r2 > T(0) && r2 < T(1e30)) {
-                a = rec[4]; b = rec[5]; c = rec[6]; rdet = rec[8];
+                a = rec[4]; b = B_DOUBLED ? T(0.5) * rec[5] : rec[5]; c = rec[6]; rdet = rec[8];
                 const T half = T(0.5) * (a + c);
                 const T lmax = half + fast_sqrt(T(0.25) * (a - c) * (a - c) + b * b);
                 tau_m = (r2 * fast_rcp(lmax)) * T(1.001);
@@ -757,10 +759,11 @@ __device__ __forceinline__ void render_tile_fwd(
         const int cnt = min(RCHUNK, n_list - base);
         GS_STAT(1, 1);      // chunks
         GS_STAT(8, cnt);    // list entries staged
-        stage_chunk<T, N_SH>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, nullptr, src_opacity, src_conic);
+        constexpr bool B2 = fast && N_SH == 1;   // the pipelined walk below reads b + b from the record
+        stage_chunk<T, N_SH, B2 ? 2 : 0>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, nullptr, src_opacity, src_conic);
         GS_PHASE(0);
         // (no barrier in between: thread t tests the record thread t staged)
-        build_touch_masks<T, RCHUNK>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
+        build_touch_masks<T, RCHUNK, B2>(s_geom, cnt, tid, tile % ntx, tile / ntx, s_mask);
         __syncthreads();
         if constexpr (fast && N_SH == 1) {
             // the chunk's masks for the backward (see GS_MASK_WORDS): thread (word, patch) stores one 8-byte word
@@ -781,8 +784,8 @@ __device__ __forceinline__ void render_tile_fwd(
                     const T du = pu - r.g0.x, dv = pv - r.g0.y;
                     if (!(du * du + dv * dv > r.g0.z)) {
                         GS_STAT_SET(st_in);
-                        const T a = r.g1.x, b = r.g1.y, c = r.g1.z, det = r.g1.w;
-                        const T mh_num = c * du * du - (b + b) * du * dv + a * dv * dv;
+                        const T a = r.g1.x, tb = r.g1.y, c = r.g1.z, det = r.g1.w;   // tb = b + b (stage_chunk)
+                        const T mh_num = c * du * du - tb * du * dv + a * dv * dv;
                         const T mh = div_by_reciprocal(mh_num, det, r.g2.x);
                         T alpha = r.g0.w * exp_neg_half(mh);
                         // render.cu:133: alpha = 0 unless mh > 0 -- and a zero alpha fails the 1/255 test below.  Without
@@ -1469,7 +1472,7 @@ __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
         const int cnt = min(RCHUNK, seg_hi - base);
         GS_STAT(1, 1);
         __syncthreads();   // previous chunk fully flushed
-        stage_chunk<T, N_SH, SLOTS>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, s_idx, src_opacity, src_conic);
+        stage_chunk<T, N_SH, SLOTS ? 1 : 0>(packed, rgb, sorted, s0 + base, cnt, tid, s_geom, s_col, s_idx, src_opacity, src_conic);
         if constexpr (!SLOTS)
             for (int k = tid; k < cnt * NV; k += RB) s_acc[k] = 0;
         GS_PHASE(0);
