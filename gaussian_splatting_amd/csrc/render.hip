@@ -1151,13 +1151,13 @@ __device__ __forceinline__ void permlane32_swap(float& a, float& b) {
 // trade halves of the value set -- after the stride-4 step a lane keeps 4 of the first 8 values, after the
 // stride-8 step 2 (see the function body) -- one v_permlane16_swap puts the even values' row pairs in
 // rows 0/2 and the odd values' in rows 1/3, one v_permlane32_swap joins the halves: totals of the even
-// values end in row 0, of the odd values in row 1, the ninth in lanes 32..63; nine lanes store with
+// values end in row 0, of the odd values in row 1, the ninth in lanes 48..63 (rows 1 + 3, joined by a row_bcast:15 add); nine lanes store with
 // ONE ds_write_b32 (slot_lane_offset gives each its element, -1 elsewhere).
 // Lanes that do not contribute must hold zeros.
 __device__ __forceinline__ int slot_lane_offset(int lane) {
     // after the reduction: row 0 holds the totals of the even values, row 1 of the odd ones, bank k of a
-    // row (lanes 4k..4k+3) the pair e(k) = (0, 4, 2, 6)[k]; lanes 32..63 hold the ninth value
-    if (lane == 32) return 8;
+    // row (lanes 4k..4k+3) the pair e(k) = (0, 4, 2, 6)[k]; lanes 48..63 hold the ninth value (lane 63 stores it)
+    if (lane == 63) return 8;
     if (lane >= 32 || (lane & 3) != 0) return -1;
     const int bank = (lane >> 2) & 3;
     const int e = ((bank & 1) ? 4 : 0) + ((bank & 2) ? 2 : 0);
@@ -1171,7 +1171,7 @@ __device__ __forceinline__ void reduce9_to_slot(const float* val, bool stores, f
     //   stride 8   s_j = banks 0,1: r_j + r_j@(i+8)          banks 2,3: r_{j+2} + r_{j+2}@(i-8)     (j = 0, 1)
     //   inside the quads the two survivors are summed plainly (xor 1, xor 2): every lane of bank k then
     //   holds the ROW totals of values e(k), e(k)+1 with e = (0, 4, 2, 6); the ninth value takes xor 1,
-    //   xor 2, row_ror 4, row_ror 8 (row total in every lane).
+    //   xor 2, row_ror 12, row_ror 8 (row total in every lane).
     // 20 DPP adds and no v_cndmask (the compiler's form of the same trade: 12 selects + 17 DPP ops).
     // Every DPP source was written at least two instructions earlier (the DPP read-after-VALU-write hazard
     // needs two wait states; the s_nop covers the compiler's code in front of the block).
@@ -1194,7 +1194,7 @@ __device__ __forceinline__ void reduce9_to_slot(const float* val, bool stores, f
         "v_add_f32_dpp %6, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %6, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %6, %6, %6 row_ror:12 row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
@@ -1206,11 +1206,15 @@ __device__ __forceinline__ void reduce9_to_slot(const float* val, bool stores, f
     float x = s2[0], y = s2[1];
     permlane16_swap(x, y);           // x: rows (x0, y0, x2, y2); y: rows (x1, y1, x3, y3)
     float z = x + y;                 // rows 0, 2: even values of row pairs (0,1), (2,3); rows 1, 3: odd values
-    float t = s8, u = s8;
-    permlane16_swap(t, u);
-    float e = t + u;                 // ninth value: rows 0, 1 hold rows 0+1, rows 2, 3 hold rows 2+3
+    // ninth value (its row total in every lane): rows 1 and 3 add lane 15 of the row in front of them (DPP row_bcast:15)
+    // -- rows 0+1 and 2+3 as the two-register lane swap + add formed them, for one DPP add instead of a move, an
+    // 8-cycle swap with its hazard padding and an add.  Lane 63 stores it: with the third step of the row reduction
+    // rotating by 12 (quad q + quad q+1) lane 15 of every row holds ((Q3+Q0)+(Q1+Q2)), bit for bit the association
+    // lane 0 held -- and lane 32 stored -- when that step rotated by 4
+    float e = s8;
+    asm volatile("v_add_f32_dpp %0, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 0" : "+v"(e) : "v"(s8));
     permlane32_swap(z, e);           // z: (z.lo, e.lo); e: (z.hi, e.hi)
-    const float total = z + e;       // lanes 0..31: even / odd values' totals; lanes 32..63: the ninth
+    const float total = z + e;       // lanes 0..31: even / odd values' totals; lanes 48..63: the ninth (rows 0+1 + rows 2+3)
     // (lane_slot: the wave's slot of this splat + slot_lane_offset(lane), formed by the caller from a per-lane base that
     // holds everything but the splat -- one vector add per visit where (wave, splat, lane) -> address took three)
     if (stores) slots[lane_slot] = total;
