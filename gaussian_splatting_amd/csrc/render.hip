@@ -1223,10 +1223,14 @@ __device__ __forceinline__ void reduce9_to_slot(const float* val, bool stores, f
 // ---------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------
+// At most 7 waves per SIMD (no minimum: the per-pixel-SH and fp64 instantiations sit far below).  Squeezed into the 64
+// registers of 8 waves, k_render_bwd<float, 1> reloads a coefficient of the exponential in every visit; with the 72
+// of 7 it stays resident (104 -> 103 vector instructions per visit, 0.4506 -> 0.4466 ms at D alternating on one box),
+// and the kernel never held 8 waves anyway (5-7).
 #ifdef GS_BWD_WAVES
 #define GS_BWD_OCC __attribute__((amdgpu_waves_per_eu(GS_BWD_WAVES, GS_BWD_WAVES)))
 #else
-#define GS_BWD_OCC
+#define GS_BWD_OCC __attribute__((amdgpu_waves_per_eu(1, 7)))
 #endif
 template <typename T, int N_SH>
 __global__ __launch_bounds__(RB) GS_BWD_OCC void k_render_bwd(
